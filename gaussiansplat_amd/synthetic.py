@@ -1,0 +1,61 @@
+"""Deterministic synthetic scenes for parity tests and the benchmark.
+
+Not part of the reference (it only loads trained PLY files, splat.jl:106-119); this is the
+workload generator BASELINE.json's configs are stated on.  PCG64 via numpy default_rng, seed =
+1234 + config index.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .camera import Camera, default_camera
+
+# BASELINE.json configs: (n_gaussians, W, H, sh_degree)
+CONFIGS = {
+    "C1": (10_000, 256, 256, 0),
+    "C2": (100_000, 800, 800, 3),
+    "C3": (1_000_000, 1920, 1080, 3),
+    "C4": (1_000_000, 1920, 1080, 3),     # x 8 views, one per GPU
+    "C5": (5_000_000, 3840, 2160, 3),
+}
+
+
+def scene_camera(W: int, view: int = 0) -> Camera:
+    """Reference defaultCamera with fx=fy scaled by W/1920 (footprints resolution independent);
+    view k rotates the eye about +y by k*45 degrees (8-view batches)."""
+    cam = default_camera(id=view)
+    cam.fx = cam.fy = float(np.float32(3200.0 * W / 1920.0))
+    if view:
+        a = np.deg2rad(45.0 * view)
+        e = cam.eye.astype(np.float64)
+        cam.eye = np.array([np.cos(a) * e[0] + np.sin(a) * e[2], e[1], -np.sin(a) * e[0] + np.cos(a) * e[2]], np.float32)
+    return cam
+
+
+def make_scene(n: int, W: int, H: int, sh_degree: int, seed: int = 1234):
+    """Returns dict(means[n,3], scales[n,3], quats[n,4], opacities[n], shs[n,K,3]) float32.
+
+    Quaternions are drawn N(0,1)^4 and normalised HERE: the reference kernel does not
+    normalise (projection.jl:126) and applies R four times (J*R*Sigma*(J*R)'), so raw N(0,1)
+    draws would inflate every footprint by |q|^4; trained scenes carry near-unit quaternions.
+    """
+    rng = np.random.default_rng(seed)
+    fx = 3200.0 * W / 1920.0
+    Wv, Hv = W * 30.0 / fx, H * 30.0 / fx
+    means = np.empty((n, 3), np.float32)
+    means[:, 0] = rng.uniform(-0.5 * Wv, 0.5 * Wv, n)
+    means[:, 1] = rng.uniform(-0.5 * Hv, 0.5 * Hv, n)
+    means[:, 2] = rng.uniform(-4.0, 4.0, n)
+    scales = rng.uniform(-4.5, -2.5, (n, 3)).astype(np.float32)
+    q = rng.standard_normal((n, 4))
+    quats = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    opacities = rng.uniform(-2.0, 4.0, n).astype(np.float32)
+    K = (sh_degree + 1) ** 2
+    shs = (rng.standard_normal((n, K, 3)) * 0.1).astype(np.float32)
+    shs[:, 0, :] = (rng.standard_normal((n, 3)) * 0.3).astype(np.float32)
+    return dict(means=means, scales=scales, quats=quats, opacities=opacities, shs=shs)
+
+
+def make_dC(W: int, H: int, seed: int = 1234) -> np.ndarray:
+    """Upstream image gradient, [3, H, W] float32 ~ N(0,1)."""
+    return np.random.default_rng(seed + 7919).standard_normal((3, H, W)).astype(np.float32)
