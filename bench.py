@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X Gaussian-splat hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched through torch.distributed.run)
+
+A step = one fwd+bwd pass of the hot path over one camera view of the synthetic scene:
+preprocess -> tile|depth keys + radix sort -> composite forward -> composite backward ->
+per-gaussian backward (+ ONE RCCL all-reduce of the flat gradient buffer when N > 1).
+Weak scaling: every GPU renders its own view (one camera per GPU) of the replicated model.
+Inputs (model, dC) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+
+
+def algorithmic_bytes(stage: str, N: int, I: int, Iw_f: int, Iw_b: int, P: int, Tn: int, K: int) -> float:
+    """SURVEY.md section 8(d) per-unit figures (I = instances, Iw = list entries actually walked)."""
+    per_g_params = 4 * (3 + 3 + 4 + 1 + 3 * K)
+    return {
+        "preprocess": (per_g_params + 48) * N,
+        "depth_sort": 16 * N,                       # one read + one write of the 8-byte (depth|id) pair
+        "count_scan": 12 * N,
+        "emit": 12 * I,
+        "tile_sort": 24 * I,
+        "ranges": 8 * I + 8 * Tn,
+        "composite_fwd": 40 * Iw_f + 16 * P,
+        "composite_bwd": 40 * Iw_b + 20 * P + 36 * Iw_b,
+        "preprocess_bwd": (36 + per_g_params) * N + per_g_params * N,
+    }[stage]
+
+
+def cpu_baseline(t_min: float, order: int):
+    """The oracle (CPU restatement of the reference arithmetic, OpenMP build) on a bounded sample:
+    BASELINE config C2 (100k gaussians, 800x800, SH3), one fwd+bwd."""
+    from oracle import oracle as O
+    from gaussiansplat_amd import camera as gcam, synthetic
+    n, W, H, deg = synthetic.CONFIGS["C2"]
+    sc = synthetic.make_scene(n, W, H, deg, seed=1235)
+    cam = synthetic.scene_camera(W)
+    ocam = O.camera_from_arrays(gcam.compute_transform(cam), gcam.compute_projection(cam, W, H), np.float32(cam.fx), np.float32(cam.fy),
+                                np.float32(cam.near), np.float32(cam.far), cam.eye, cam.lookAt, W, H)
+    dC = synthetic.make_dC(W, H, 1235)
+    O.lib(omp=True)
+    t0 = time.perf_counter()
+    r = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=order, t_min=t_min, omp=True)
+    O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, r["ranges"], r["ids"], dC, t_min=t_min, omp=True)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt / 1e6, "unit": "Msplats/s", "cores": int(O.lib(omp=True).gso_num_threads()), "kind": "port",
+            "sample": f"C2: {n} gaussians, {W}x{H}, SH{deg}, one fwd+bwd, t_min={t_min:g}, {dt:.2f} s "
+                      "(oracle/gs_oracle.c, OpenMP; fp64 adjoint)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--t-min", type=float, default=1e-5, help="transmittance early-out (0 = literal reference)")
+    ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-literal", action="store_true", help="skip the extra literal (t_min=0) measurement")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gaussiansplat_amd import renderer as R, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    n, W, H, deg = synthetic.CONFIGS[args.config]
+    seed = 1234 + list(synthetic.CONFIGS).index(args.config)
+    scene = synthetic.make_scene(n, W, H, deg, seed=seed)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    cam = synthetic.scene_camera(W, view=rank % 8)
+    dC = torch.as_tensor(synthetic.make_dC(W, H, seed + rank)).cuda()
+
+    def make(t_min):
+        return R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene, device=local, order=args.order, t_min=t_min,
+                             profile_stages=True)
+
+    def step(r):
+        R.resetGrads(r)
+        tps = R.preprocess(r, cam)
+        R.compactIdxs(r, (16, 16), (gx, gy))
+        R.forward(r, tps, (16, 16), (gx, gy))
+        R.backward(r, dC)
+        if world > 1:
+            dist.all_reduce(r.splatGrads.flat)           # ONE flat RCCL all-reduce (59 N floats at SH3)
+
+    def timed(r, steps, warmup):
+        for _ in range(warmup):
+            step(r)
+        torch.cuda.synchronize()
+        r.ctx.stage_stats(reset=True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(r)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    r = make(args.t_min)
+    dt = timed(r, args.steps, args.warmup)
+    stats = r.ctx.stage_stats()
+    I = r.ctx.num_instances
+    wf, wb = r.ctx.work_counters()
+    value = world * n * args.steps / dt / 1e6
+
+    out = None
+    if rank == 0:
+        P, Tn, K = W * H, gx * gy, (deg + 1) ** 2
+        stage_ms = {k: (s / c if c else 0.0) for k, (s, c) in stats.items()}
+        dom = max(stage_ms, key=stage_ms.get)
+        by = algorithmic_bytes(dom, n, I, wf, wb, P, Tn, K)
+        ach = by / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        out = {
+            "metric": "fwd+bwd Msplats/sec at 1M Gaussians, 1920x1080, SH deg 3" if args.config == "C3" else f"fwd+bwd Msplats/sec ({args.config})",
+            "value": value, "unit": "Msplats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n} gaussians, {W}x{H}, SH{deg}, one camera view per GPU per step, fwd+bwd"
+                                   + (", one RCCL all-reduce of 59N f32" if world > 1 else ""),
+                       "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
+                       "instances": I, "walked_fwd": wf, "walked_bwd": wb, "seed": seed},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": by, "avg_ms": stage_ms[dom],
+                         "note": "composite kernels are VALU-bound (DESIGN.md s5); HBM fraction reported as measured"},
+        }
+    if not args.no_literal and args.t_min > 0:
+        del r
+        torch.cuda.empty_cache()
+        r0 = make(0.0)
+        k0 = max(2, min(args.steps, 5))
+        dt0 = timed(r0, k0, 1)
+        st0 = r0.ctx.stage_stats()
+        if rank == 0:
+            out["literal_t_min_0"] = {"value": world * n * k0 / dt0 / 1e6, "unit": "Msplats/s", "ms_per_step": dt0 / k0 * 1e3, "steps": k0,
+                                      "stage_ms": {k: round(s / c if c else 0.0, 4) for k, (s, c) in st0.items()}}
+        del r0
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.t_min, args.order)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

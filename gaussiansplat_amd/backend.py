@@ -1,0 +1,220 @@
+"""ctypes binding of libgsplat_hip.so (include/gsplat.h) -- the Python twin of julia/backend.jl.
+
+This is the only way the package reaches the GPU: there is NO CPU fallback here.  If the
+shared library is missing or the HIP device is absent every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgsplat_hip.so")
+
+GS_MEM_HOST, GS_MEM_DEVICE = 0, 1
+ORDER_INDEX, ORDER_DEPTH_DESC, ORDER_DEPTH_ASC = 0, 1, 2
+
+(ARR_TS, ARR_TPS, ARR_MU, ARR_COV3D, ARR_COV2D, ARR_INVCOV, ARR_BBS, ARR_RGB, ARR_SIG, ARR_DEPTH_KEY,
+ ARR_TILE_RECT, ARR_SORT_IDXS, ARR_TILE_RANGES, ARR_SORTED_IDS, ARR_SORTED_KEYS, ARR_GRAD2D) = range(16)
+
+STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges", "composite_fwd",
+          "composite_bwd", "preprocess_bwd")
+
+# every symbol include/gsplat.h declares (tests/test_abi.py checks the header against this)
+SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
+           "gs_synchronize", "gs_set_model", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
+           "gs_backward", "gs_reset_grads", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
+           "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters")
+
+
+class GsConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("tile_size", C.c_int32), ("order", C.c_int32), ("t_min", C.c_float),
+                ("deterministic", C.c_int32), ("export_debug", C.c_int32), ("profile_stages", C.c_int32),
+                ("reserved", C.c_int32 * 9)]
+
+
+class GsGrads(C.Structure):
+    _fields_ = [("d_means", C.c_void_p), ("d_scales", C.c_void_p), ("d_quats", C.c_void_p),
+                ("d_opacities", C.c_void_p), ("d_shs", C.c_void_p)]
+
+
+class GsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libgsplat_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library; raises if it has not been built (python -m gaussiansplat_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        # ONE HIP runtime per process: torch bundles its own libamdhip64.so.7 / libhsa-runtime64;
+        # loading it first makes our library's NEEDED libamdhip64.so.7 resolve to the same copy
+        # (loading /opt/rocm's copy first leaves torch with "No HIP GPUs are available").
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not found: build it with `python -m gaussiansplat_amd.build` "
+                                "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, fp = C.c_void_p, C.POINTER(C.c_float)
+    L.gs_default_config.argtypes = [C.POINTER(GsConfig)]; L.gs_default_config.restype = None
+    L.gs_abi_version.restype = C.c_int
+    L.gs_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(GsConfig)]
+    L.gs_destroy.argtypes = [vp]
+    L.gs_last_error.argtypes = [vp]; L.gs_last_error.restype = C.c_char_p
+    L.gs_set_stream.argtypes = [vp, vp]
+    L.gs_synchronize.argtypes = [vp]
+    L.gs_set_model.argtypes = [vp, C.c_int64, C.c_int, vp, vp, vp, vp, vp, C.c_int]
+    L.gs_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, C.c_int32, C.c_int32]
+    L.gs_preprocess.argtypes = [vp]
+    L.gs_bin.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gs_forward.argtypes = [vp, vp, vp, C.c_int]
+    L.gs_backward.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads)]
+    L.gs_reset_grads.argtypes = [vp, C.POINTER(GsGrads)]
+    L.gs_num_gaussians.argtypes = [vp]; L.gs_num_gaussians.restype = C.c_int64
+    L.gs_num_instances.argtypes = [vp]; L.gs_num_instances.restype = C.c_int64
+    L.gs_get_array.argtypes = [vp, C.c_int, vp, C.c_int64]
+    L.gs_get_stage_times.argtypes = [vp, fp]
+    L.gs_get_stage_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+    L.gs_get_work_counters.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    _lib = L
+    return L
+
+
+def default_config() -> GsConfig:
+    cfg = GsConfig()
+    load().gs_default_config(C.byref(cfg))
+    return cfg
+
+
+class Context:
+    """Owns one gs_ctx (one GPU, one stream)."""
+
+    def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
+                 profile_stages: bool = False, deterministic: bool = False):
+        self.L = load()
+        cfg = default_config()
+        cfg.order, cfg.t_min = int(order), float(t_min)
+        cfg.export_debug, cfg.profile_stages, cfg.deterministic = int(export_debug), int(profile_stages), int(deterministic)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = self.L.gs_create(C.byref(self.h), device, C.byref(cfg))
+        if rc != 0:
+            raise GsError(rc, (self.L.gs_last_error(None) or b"").decode())
+        self._keep = []
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise GsError(rc, (self.L.gs_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.gs_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing
+    def set_stream(self, hip_stream: int | None):
+        self._chk(self.L.gs_set_stream(self.h, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        self._chk(self.L.gs_synchronize(self.h))
+
+    # -- model / camera
+    def set_model_host(self, means, scales, quats, opacities, shs, sh_degree: int):
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (means, scales, quats, opacities, shs)]
+        n = arrs[0].shape[0]
+        self._chk(self.L.gs_set_model(self.h, n, sh_degree, *(C.c_void_p(a.ctypes.data) for a in arrs), GS_MEM_HOST))
+
+    def set_model_device(self, n: int, sh_degree: int, ptrs):
+        """ptrs: five device pointers (means, scales, quats, opacities, shs); borrowed, not copied."""
+        self._chk(self.L.gs_set_model(self.h, n, sh_degree, *(C.c_void_p(int(p)) for p in ptrs), GS_MEM_DEVICE))
+
+    def set_camera(self, T, P, fx, fy, near, far, eye, lookAt, W, H):
+        fp = C.POINTER(C.c_float)
+        a = [np.ascontiguousarray(v, np.float32).reshape(-1) for v in (T, P, eye, lookAt)]
+        self._chk(self.L.gs_set_camera(self.h, a[0].ctypes.data_as(fp), a[1].ctypes.data_as(fp), fx, fy, near, far,
+                                       a[2].ctypes.data_as(fp), a[3].ctypes.data_as(fp), int(W), int(H)))
+        self.W, self.H = int(W), int(H)
+
+    # -- pipeline
+    def preprocess(self):
+        self._chk(self.L.gs_preprocess(self.h))
+
+    def bin(self, gx: int = 0, gy: int = 0):
+        self._chk(self.L.gs_bin(self.h, gx, gy))
+
+    def forward_host(self):
+        img = np.empty((3, self.H, self.W), np.float32)
+        tr = np.empty((self.H, self.W), np.float32)
+        self._chk(self.L.gs_forward(self.h, C.c_void_p(img.ctypes.data), C.c_void_p(tr.ctypes.data), GS_MEM_HOST))
+        return img, tr
+
+    def forward_device(self, image_ptr: int = 0, trans_ptr: int = 0):
+        self._chk(self.L.gs_forward(self.h, C.c_void_p(image_ptr), C.c_void_p(trans_ptr), GS_MEM_DEVICE))
+
+    def backward(self, dC_ptr_or_array, grads: GsGrads):
+        if isinstance(dC_ptr_or_array, np.ndarray):
+            a = np.ascontiguousarray(dC_ptr_or_array, np.float32)
+            self._chk(self.L.gs_backward(self.h, C.c_void_p(a.ctypes.data), GS_MEM_HOST, C.byref(grads)))
+        else:
+            self._chk(self.L.gs_backward(self.h, C.c_void_p(int(dC_ptr_or_array)), GS_MEM_DEVICE, C.byref(grads)))
+
+    def reset_grads(self, grads: GsGrads):
+        self._chk(self.L.gs_reset_grads(self.h, C.byref(grads)))
+
+    # -- introspection
+    @property
+    def num_gaussians(self) -> int:
+        return int(self.L.gs_num_gaussians(self.h))
+
+    @property
+    def num_instances(self) -> int:
+        return int(self.L.gs_num_instances(self.h))
+
+    def get_array(self, which: int, gx: int | None = None, gy: int | None = None) -> np.ndarray:
+        n, ni = self.num_gaussians, self.num_instances
+        spec = {ARR_TS: ((n, 4), np.float32), ARR_TPS: ((n, 4), np.float32), ARR_MU: ((n, 2), np.float32),
+                ARR_COV3D: ((n, 9), np.float32), ARR_COV2D: ((n, 4), np.float32), ARR_INVCOV: ((n, 4), np.float32),
+                ARR_BBS: ((n, 4), np.float32), ARR_RGB: ((n, 3), np.float32), ARR_SIG: ((n,), np.float32),
+                ARR_DEPTH_KEY: ((n,), np.uint32), ARR_TILE_RECT: ((n, 4), np.uint16), ARR_SORT_IDXS: ((n,), np.uint32),
+                ARR_SORTED_IDS: ((ni,), np.uint32), ARR_SORTED_KEYS: ((ni,), np.uint64), ARR_GRAD2D: ((n, 10), np.float32)}
+        if which == ARR_TILE_RANGES:
+            ntiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+            shape, dt = (ntiles, 2), np.uint32
+        else:
+            shape, dt = spec[which]
+        out = np.empty(shape, dt)
+        self._chk(self.L.gs_get_array(self.h, which, C.c_void_p(out.ctypes.data), out.nbytes))
+        return out
+
+    def stage_stats(self, reset: bool = False) -> dict:
+        """{stage: (sum_ms, launches)} accumulated by hipEvents on the ctx stream since the last reset."""
+        sm = (C.c_double * len(STAGES))()
+        ct = (C.c_int64 * len(STAGES))()
+        self._chk(self.L.gs_get_stage_stats(self.h, sm, ct, int(reset)))
+        return {k: (float(sm[i]), int(ct[i])) for i, k in enumerate(STAGES)}
+
+    def work_counters(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._chk(self.L.gs_get_work_counters(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def stage_times(self) -> dict:
+        ms = (C.c_float * len(STAGES))()
+        self._chk(self.L.gs_get_stage_times(self.h, ms))
+        return {k: float(ms[i]) for i, k in enumerate(STAGES)}

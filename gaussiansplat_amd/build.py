@@ -1,0 +1,74 @@
+"""Build libgsplat_hip.so in-tree with hipcc for gfx950 (no CMake, no JIT cache).
+
+    python -m gaussiansplat_amd.build [--force]
+
+The preprocess translation unit is compiled with -ffp-contract=off (numeric spec: tile ids
+and depth keys must be bit-identical to the CPU oracle); the composite kernels keep hipcc's
+default contraction (pixels/gradients are tolerance-checked).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT_DIR, "libgsplat_hip.so")
+ARCH = "gfx950"
+
+SOURCES = {
+    "gs_preprocess.hip": ["-ffp-contract=off"],
+    "gs_preprocess_bwd.hip": [],
+    "gs_sort.hip": [],
+    "gs_composite.hip": [],
+    "gs_api.hip": [],
+}
+COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _deps() -> float:
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "gsplat.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OUT_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdr_time = _deps()
+    objs, jobs = [], []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        return r
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or not os.path.exists(LIB):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,541 @@
+// gs_api.hip -- host side of the C ABI declared in include/gsplat.h.
+//
+// Mirrors the reference's host drivers -- getRenderer (src/renderer.jl:119-149), preprocess
+// (src/forward.jl:35-111), compactIdxs (src/forward.jl:118-161), forward (src/forward.jl:163-198),
+// backward (src/backward.jl:3-38), resetGrads (src/splat.jl:158-173) -- without their
+// per-frame costs: the model stays resident (the reference re-uploads it with `|> CuArray`
+// on every call, forward.jl:63-69,169-170), scratch is grow-only (the reference re-allocates
+// hitIdxs/hits/hitScans each frame, forward.jl:120,137,142), every stage is enqueued on one
+// stream with a single host read-back (the instance count; the reference syncs after every
+// kernel and reads maxHits back, forward.jl:72-156).
+#include "../../include/gsplat.h"
+#include "gs_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;                 // grow-only with slack
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+std::string g_create_error;
+
+}  // namespace
+
+struct gs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    gs_config cfg{};
+    std::string err;
+
+    int64_t n = 0;
+    int sh_degree = 0;
+    const float *means = nullptr, *scales = nullptr, *quats = nullptr, *opac = nullptr, *shs = nullptr;
+    DevBuf model[5];
+    GsCamera cam{};
+    bool have_cam = false, did_pre = false, did_bin = false, did_fwd = false, did_bwd = false;
+    int gx = 0, gy = 0;
+
+    DevBuf payload, depth_key, rect, pairs_a, pairs_b, perm, offsets, block_sums;
+    DevBuf inst_a, inst_b, table, digit_total, ranges, image, trans, g2d, stage_in;
+    DevBuf dbg[7];
+    uint64_t *inst_sorted = nullptr;
+    uint32_t *perm_ptr = nullptr;
+    int64_t n_inst = 0;
+    uint32_t *pinned = nullptr;
+
+    hipEvent_t ev[GS_STAGE_COUNT][2] = {};
+    bool ev_valid[GS_STAGE_COUNT] = {};      // a start/stop pair has been recorded
+    bool ev_fresh[GS_STAGE_COUNT] = {};      // ... and not yet added to the accumulators
+    double ev_sum[GS_STAGE_COUNT] = {};
+    int64_t ev_cnt[GS_STAGE_COUNT] = {};
+    DevBuf counters;                         // 2 x u64: entries walked fwd / bwd
+};
+
+namespace {
+
+int fail(gs_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+int hipfail(gs_ctx *c, hipError_t e, const char *what) {
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    return fail(c, e == hipErrorOutOfMemory ? GS_ERR_OOM : GS_ERR_HIP, m);
+}
+#define HIPCHK(c, call)                                              \
+    do {                                                             \
+        hipError_t e__ = (call);                                     \
+        if (e__ != hipSuccess) return hipfail((c), e__, #call);      \
+    } while (0)
+
+struct StageTimer {
+    gs_ctx *c; int st; bool on;
+    StageTimer(gs_ctx *c_, int st_) : c(c_), st(st_), on(c_->cfg.profile_stages != 0) {
+        if (on) (void)hipEventRecord(c->ev[st][0], c->stream);
+    }
+    ~StageTimer() {
+        if (on) { (void)hipEventRecord(c->ev[st][1], c->stream); c->ev_valid[st] = true; c->ev_fresh[st] = true; }
+    }
+};
+
+// After a stream synchronise every recorded pair is complete: fold it into the accumulators.
+void harvest_events(gs_ctx *c) {
+    if (!c->cfg.profile_stages) return;
+    for (int s = 0; s < GS_STAGE_COUNT; ++s)
+        if (c->ev_fresh[s]) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) { c->ev_sum[s] += ms; c->ev_cnt[s] += 1; }
+            c->ev_fresh[s] = false;
+        }
+}
+
+int bind_device(gs_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    return GS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void gs_default_config(gs_config *cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int32_t)sizeof(gs_config);
+    cfg->tile_size = GS_TILE;
+    cfg->order = GS_ORDER_DEPTH_DESC;
+    cfg->t_min = 1e-5f;
+    cfg->deterministic = 0;
+    cfg->export_debug = 0;
+    cfg->profile_stages = 0;
+}
+
+int gs_abi_version(void) { return GS_ABI_VERSION; }
+
+const char *gs_last_error(const gs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
+    if (!out) return fail(nullptr, GS_ERR_INVALID, "gs_create: out is NULL");
+    *out = nullptr;
+    gs_config c0;
+    gs_default_config(&c0);
+    if (cfg) {
+        if (cfg->struct_size != (int32_t)sizeof(gs_config)) return fail(nullptr, GS_ERR_INVALID, "gs_create: gs_config.struct_size mismatch");
+        c0 = *cfg;
+    }
+    if (c0.tile_size != GS_TILE) return fail(nullptr, GS_ERR_UNSUPPORTED, "gs_create: only tile_size 16 is supported (reference threads=(16,16))");
+    if (c0.order < GS_ORDER_INDEX || c0.order > GS_ORDER_DEPTH_ASC) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad order");
+    if (!(c0.t_min >= 0.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: t_min must be >= 0");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, GS_ERR_NO_DEVICE, "gs_create: no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, GS_ERR_INVALID, "gs_create: device index out of range");
+    gs_ctx *c = new (std::nothrow) gs_ctx();
+    if (!c) return fail(nullptr, GS_ERR_OOM, "gs_create: host allocation failed");
+    c->device = device;
+    c->cfg = c0;
+    if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipSetDevice"); }
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipStreamCreate"); }
+    c->own_stream = true;
+    if ((e = hipHostMalloc((void **)&c->pinned, 64, hipHostMallocDefault)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return hipfail(nullptr, e, "hipHostMalloc"); }
+    for (int s = 0; s < GS_STAGE_COUNT; ++s)
+        for (int k = 0; k < 2; ++k)
+            if ((e = hipEventCreate(&c->ev[s][k])) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
+    *out = c;
+    return GS_OK;
+}
+
+int gs_destroy(gs_ctx *c) {
+    if (!c) return GS_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
+                      &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
+                      &c->counters};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &b : c->model) b.release();
+    for (auto &b : c->dbg) b.release();
+    for (int s = 0; s < GS_STAGE_COUNT; ++s)
+        for (int k = 0; k < 2; ++k)
+            if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GS_OK;
+}
+
+int gs_set_stream(gs_ctx *c, void *hip_stream) {
+    if (!c) return GS_ERR_INVALID;
+    if (bind_device(c)) return GS_ERR_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; }
+    else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    return GS_OK;
+}
+
+int gs_synchronize(gs_ctx *c) {
+    if (!c) return GS_ERR_INVALID;
+    if (bind_device(c)) return GS_ERR_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int gs_set_model(gs_ctx *c, int64_t n, int sh_degree, const float *means, const float *scales, const float *quats,
+                 const float *opacities, const float *shs, int mem) {
+    if (!c) return GS_ERR_INVALID;
+    if (n < 0 || n > 0x7FFFFFF0LL) return fail(c, GS_ERR_INVALID, "gs_set_model: n out of range");
+    if (sh_degree < 0 || sh_degree > 3) return fail(c, GS_ERR_UNSUPPORTED, "gs_set_model: sh_degree must be 0..3");
+    if (n > 0 && (!means || !scales || !quats || !opacities || !shs)) return fail(c, GS_ERR_INVALID, "gs_set_model: NULL array");
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(c, GS_ERR_INVALID, "gs_set_model: bad mem");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const int K = (sh_degree + 1) * (sh_degree + 1);
+    const float *src[5] = {means, scales, quats, opacities, shs};
+    const size_t width[5] = {3, 3, 4, 1, (size_t)3 * K};
+    const float *dst[5];
+    if (mem == GS_MEM_HOST) {
+        for (int i = 0; i < 5; ++i) {
+            const size_t bytes = sizeof(float) * width[i] * (size_t)n;
+            HIPCHK(c, c->model[i].ensure(bytes ? bytes : 4));
+            if (bytes) HIPCHK(c, hipMemcpyAsync(c->model[i].p, src[i], bytes, hipMemcpyHostToDevice, c->stream));
+            dst[i] = c->model[i].as<float>();
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));            // caller may free its host arrays on return
+    } else {
+        for (int i = 0; i < 5; ++i) dst[i] = src[i];
+    }
+    c->n = n; c->sh_degree = sh_degree;
+    c->means = dst[0]; c->scales = dst[1]; c->quats = dst[2]; c->opac = dst[3]; c->shs = dst[4];
+    c->did_pre = c->did_bin = c->did_fwd = c->did_bwd = false;
+    return GS_OK;
+}
+
+int gs_set_camera(gs_ctx *c, const float T[16], const float P[16], float fx, float fy, float near_, float far_,
+                  const float eye[3], const float lookAt[3], int32_t W, int32_t H) {
+    if (!c) return GS_ERR_INVALID;
+    if (!T || !P || !eye || !lookAt) return fail(c, GS_ERR_INVALID, "gs_set_camera: NULL argument");
+    if (W <= 0 || H <= 0 || W > 32767 || H > 32767) return fail(c, GS_ERR_INVALID, "gs_set_camera: image size must be in 1..32767");
+    std::memcpy(c->cam.T, T, sizeof(float) * 16);
+    std::memcpy(c->cam.P, P, sizeof(float) * 16);
+    c->cam.fx = fx; c->cam.fy = fy; c->cam.near_ = near_; c->cam.far_ = far_;
+    for (int i = 0; i < 3; ++i) { c->cam.eye[i] = eye[i]; c->cam.lookAt[i] = lookAt[i]; }
+    c->cam.W = W; c->cam.H = H;
+    c->have_cam = true;
+    c->did_pre = c->did_bin = c->did_fwd = c->did_bwd = false;
+    return GS_OK;
+}
+
+int gs_preprocess(gs_ctx *c) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->have_cam) return fail(c, GS_ERR_INVALID, "gs_preprocess: gs_set_camera first");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t n = (size_t)c->n, n1 = n ? n : 1;
+    HIPCHK(c, c->payload.ensure(sizeof(GsPayload) * n1));
+    HIPCHK(c, c->depth_key.ensure(sizeof(uint32_t) * n1));
+    HIPCHK(c, c->rect.ensure(sizeof(uint16_t) * 4 * n1));
+    GsPreprocessArgs a{};
+    a.n = c->n; a.sh_degree = c->sh_degree; a.order = c->cfg.order;
+    // the tile grid is fixed by the image: the reference passes blocks = size/threads (main.jl:9-11)
+    c->gx = (c->cam.W + GS_TILE - 1) / GS_TILE;
+    c->gy = (c->cam.H + GS_TILE - 1) / GS_TILE;
+    a.gx = c->gx; a.gy = c->gy;
+    a.means = c->means; a.scales = c->scales; a.quats = c->quats; a.opac = c->opac; a.shs = c->shs;
+    a.payload = c->payload.as<GsPayload>();
+    a.depth_key = c->depth_key.as<uint32_t>();
+    a.rect = c->rect.as<uint16_t>();
+    if (c->cfg.export_debug) {
+        const size_t w[7] = {4, 4, 2, 9, 4, 4, 4};
+        for (int i = 0; i < 7; ++i) HIPCHK(c, c->dbg[i].ensure(sizeof(float) * w[i] * n1));
+        a.dbg.ts = c->dbg[0].as<float>(); a.dbg.tps = c->dbg[1].as<float>(); a.dbg.mu = c->dbg[2].as<float>();
+        a.dbg.cov3d = c->dbg[3].as<float>(); a.dbg.cov2d = c->dbg[4].as<float>(); a.dbg.invcov = c->dbg[5].as<float>();
+        a.dbg.bbs = c->dbg[6].as<float>();
+    }
+    {
+        StageTimer t(c, GS_STAGE_PREPROCESS);
+        HIPCHK(c, gs_launch_preprocess(a, c->cam, c->stream));
+    }
+    c->did_pre = true; c->did_bin = c->did_fwd = c->did_bwd = false;
+    return GS_OK;
+}
+
+int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->did_pre) return fail(c, GS_ERR_INVALID, "gs_bin: gs_preprocess first");
+    if ((gx != 0 || gy != 0) && (gx != c->gx || gy != c->gy))
+        return fail(c, GS_ERR_UNSUPPORTED, "gs_bin: blocks must equal ceil(W/16) x ceil(H/16)");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t n = (size_t)c->n, n1 = n ? n : 1;
+    const int64_t ntiles = (int64_t)c->gx * c->gy;
+    uint32_t *perm = nullptr;
+    if (c->cfg.order != GS_ORDER_INDEX) {
+        StageTimer t(c, GS_STAGE_DEPTH_SORT);
+        HIPCHK(c, c->pairs_a.ensure(sizeof(uint64_t) * n1));
+        HIPCHK(c, c->pairs_b.ensure(sizeof(uint64_t) * n1));
+        HIPCHK(c, c->perm.ensure(sizeof(uint32_t) * n1));
+        HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n)));
+        HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 256));
+        HIPCHK(c, gs_launch_depth_pairs(c->depth_key.as<uint32_t>(), c->pairs_a.as<uint64_t>(), c->n, c->stream));
+        int in_b = 0;
+        HIPCHK(c, gs_radix_sort_u64(c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, 32, 64, c->table.as<uint32_t>(),
+                                    c->digit_total.as<uint32_t>(), &in_b, c->stream));
+        perm = c->perm.as<uint32_t>();
+        HIPCHK(c, gs_launch_unpack_perm(in_b ? c->pairs_b.as<uint64_t>() : c->pairs_a.as<uint64_t>(), perm, c->n, c->stream));
+    }
+    c->perm_ptr = perm;
+    {
+        StageTimer t(c, GS_STAGE_COUNT_SCAN);
+        HIPCHK(c, c->offsets.ensure(sizeof(uint32_t) * (n + 1)));
+        HIPCHK(c, c->block_sums.ensure(sizeof(uint32_t) * (n / 2048 + 2)));
+        HIPCHK(c, gs_launch_count_scan(c->rect.as<uint16_t>(), perm, c->offsets.as<uint32_t>(), c->block_sums.as<uint32_t>(), c->n, c->stream));
+    }
+    // the one host read-back of the frame (the reference reads maxHits back, forward.jl:139)
+    HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    harvest_events(c);
+    c->n_inst = (int64_t)c->pinned[0];
+    const size_t ni1 = c->n_inst ? (size_t)c->n_inst : 1;
+    HIPCHK(c, c->inst_a.ensure(sizeof(uint64_t) * ni1));
+    HIPCHK(c, c->inst_b.ensure(sizeof(uint64_t) * ni1));
+    HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
+    HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 256));
+    HIPCHK(c, c->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)(ntiles ? ntiles : 1)));
+    {
+        StageTimer t(c, GS_STAGE_EMIT);
+        HIPCHK(c, gs_launch_emit(c->rect.as<uint16_t>(), perm, c->offsets.as<uint32_t>(), c->inst_a.as<uint64_t>(), c->n, c->gx, c->stream));
+    }
+    {
+        StageTimer t(c, GS_STAGE_TILE_SORT);
+        int tile_bits = 1;
+        while ((1LL << tile_bits) < ntiles) ++tile_bits;
+        const int hi = 32 + ((tile_bits + 7) / 8) * 8;
+        int in_b = 0;
+        HIPCHK(c, gs_radix_sort_u64(c->inst_a.as<uint64_t>(), c->inst_b.as<uint64_t>(), c->n_inst, 32, hi, c->table.as<uint32_t>(),
+                                    c->digit_total.as<uint32_t>(), &in_b, c->stream));
+        c->inst_sorted = in_b ? c->inst_b.as<uint64_t>() : c->inst_a.as<uint64_t>();
+    }
+    {
+        StageTimer t(c, GS_STAGE_RANGES);
+        HIPCHK(c, gs_launch_ranges(c->inst_sorted, c->n_inst, c->ranges.as<uint32_t>(), ntiles, c->stream));
+    }
+    c->did_bin = true; c->did_fwd = c->did_bwd = false;
+    return GS_OK;
+}
+
+int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->did_bin) return fail(c, GS_ERR_INVALID, "gs_forward: gs_bin first");
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(c, GS_ERR_INVALID, "gs_forward: bad mem");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t px = (size_t)c->cam.W * c->cam.H;
+    HIPCHK(c, c->image.ensure(sizeof(float) * 3 * px));
+    HIPCHK(c, c->trans.ensure(sizeof(float) * px));
+    GsCompositeArgs a{};
+    a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
+    a.ranges = c->ranges.as<uint32_t>(); a.inst = c->inst_sorted; a.payload = c->payload.as<GsPayload>();
+    a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
+    HIPCHK(c, c->counters.ensure(16));
+    a.walked = c->counters.as<unsigned long long>();
+    {
+        StageTimer t(c, GS_STAGE_COMPOSITE_FWD);
+        HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16, c->stream));
+        HIPCHK(c, gs_launch_composite_fwd(a, c->stream));
+    }
+    const hipMemcpyKind kind = mem == GS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (image) HIPCHK(c, hipMemcpyAsync(image, c->image.p, sizeof(float) * 3 * px, kind, c->stream));
+    if (transmittance) HIPCHK(c, hipMemcpyAsync(transmittance, c->trans.p, sizeof(float) * px, kind, c->stream));
+    if (mem == GS_MEM_HOST && (image || transmittance)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->did_fwd = true; c->did_bwd = false;
+    return GS_OK;
+}
+
+int gs_backward(gs_ctx *c, const float *dC, int mem, const gs_grads *grads) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_backward: gs_forward first");
+    if (!dC || !grads) return fail(c, GS_ERR_INVALID, "gs_backward: NULL argument");
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(c, GS_ERR_INVALID, "gs_backward: bad mem");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t px = (size_t)c->cam.W * c->cam.H, n1 = c->n ? (size_t)c->n : 1;
+    const float *dC_dev = dC;
+    if (mem == GS_MEM_HOST) {
+        HIPCHK(c, c->stage_in.ensure(sizeof(float) * 3 * px));
+        HIPCHK(c, hipMemcpyAsync(c->stage_in.p, dC, sizeof(float) * 3 * px, hipMemcpyHostToDevice, c->stream));
+        dC_dev = c->stage_in.as<float>();
+    }
+    HIPCHK(c, c->g2d.ensure(sizeof(float) * 10 * n1));
+    GsCompositeArgs a{};
+    a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
+    a.ranges = c->ranges.as<uint32_t>(); a.inst = c->inst_sorted; a.payload = c->payload.as<GsPayload>();
+    a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
+    a.dC = dC_dev; a.g2d = c->g2d.as<float>();
+    a.walked = c->counters.as<unsigned long long>() + 1;
+    {
+        StageTimer t(c, GS_STAGE_COMPOSITE_BWD);
+        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, sizeof(float) * 10 * n1, c->stream));
+        HIPCHK(c, hipMemsetAsync(a.walked, 0, 8, c->stream));
+        HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
+    }
+    GsPreprocessBwdArgs b{};
+    b.n = c->n; b.sh_degree = c->sh_degree;
+    b.means = c->means; b.scales = c->scales; b.quats = c->quats; b.opac = c->opac; b.shs = c->shs;
+    b.g2d = c->g2d.as<float>();
+    b.d_means = grads->d_means; b.d_scales = grads->d_scales; b.d_quats = grads->d_quats;
+    b.d_opac = grads->d_opacities; b.d_shs = grads->d_shs;
+    {
+        StageTimer t(c, GS_STAGE_PREPROCESS_BWD);
+        HIPCHK(c, gs_launch_preprocess_bwd(b, c->cam, c->stream));
+    }
+    if (mem == GS_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));   // dC host buffer no longer needed
+    c->did_bwd = true;
+    return GS_OK;
+}
+
+int gs_reset_grads(gs_ctx *c, const gs_grads *g) {
+    if (!c || !g) return GS_ERR_INVALID;
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t n = (size_t)c->n;
+    const int K = (c->sh_degree + 1) * (c->sh_degree + 1);
+    if (g->d_means) HIPCHK(c, hipMemsetAsync(g->d_means, 0, sizeof(float) * 3 * n, c->stream));
+    if (g->d_scales) HIPCHK(c, hipMemsetAsync(g->d_scales, 0, sizeof(float) * 3 * n, c->stream));
+    if (g->d_quats) HIPCHK(c, hipMemsetAsync(g->d_quats, 0, sizeof(float) * 4 * n, c->stream));
+    if (g->d_opacities) HIPCHK(c, hipMemsetAsync(g->d_opacities, 0, sizeof(float) * n, c->stream));
+    if (g->d_shs) HIPCHK(c, hipMemsetAsync(g->d_shs, 0, sizeof(float) * 3 * K * n, c->stream));
+    return GS_OK;
+}
+
+int64_t gs_num_gaussians(const gs_ctx *c) { return c ? c->n : 0; }
+int64_t gs_num_instances(const gs_ctx *c) { return c ? c->n_inst : 0; }
+
+int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
+    if (!c || !dst) return GS_ERR_INVALID;
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t n = (size_t)c->n;
+    const void *src = nullptr;
+    size_t need = 0;
+    auto need_dbg = [&](int i, size_t w) -> int {
+        if (!c->cfg.export_debug) return fail(c, GS_ERR_INVALID, "gs_get_array: needs gs_config.export_debug = 1");
+        src = c->dbg[i].p; need = sizeof(float) * w * n; return GS_OK;
+    };
+    if (which <= GS_ARR_TILE_RECT && !c->did_pre) return fail(c, GS_ERR_INVALID, "gs_get_array: gs_preprocess first");
+    if (which >= GS_ARR_SORT_IDXS && which <= GS_ARR_SORTED_KEYS && !c->did_bin) return fail(c, GS_ERR_INVALID, "gs_get_array: gs_bin first");
+    switch (which) {
+        case GS_ARR_TS: if (int r = need_dbg(0, 4)) return r; break;
+        case GS_ARR_TPS: if (int r = need_dbg(1, 4)) return r; break;
+        case GS_ARR_COV3D: if (int r = need_dbg(3, 9)) return r; break;
+        case GS_ARR_COV2D: if (int r = need_dbg(4, 4)) return r; break;
+        case GS_ARR_BBS: if (int r = need_dbg(6, 4)) return r; break;
+        case GS_ARR_MU: case GS_ARR_INVCOV: case GS_ARR_RGB: case GS_ARR_SIG: {
+            const size_t w = which == GS_ARR_MU ? 2 : which == GS_ARR_INVCOV ? 4 : which == GS_ARR_RGB ? 3 : 1;
+            if ((size_t)bytes != sizeof(float) * w * n) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
+            std::vector<GsPayload> h(n ? n : 1);
+            HIPCHK(c, hipMemcpyAsync(h.data(), c->payload.p, sizeof(GsPayload) * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            float *o = static_cast<float *>(dst);
+            for (size_t g = 0; g < n; ++g) {
+                const GsPayload &p = h[g];
+                if (which == GS_ARR_MU) { o[2 * g] = p.mx; o[2 * g + 1] = p.my; }
+                else if (which == GS_ARR_INVCOV) { o[4 * g] = p.i0; o[4 * g + 1] = p.i1; o[4 * g + 2] = p.i2; o[4 * g + 3] = p.i3; }
+                else if (which == GS_ARR_RGB) { o[3 * g] = p.r; o[3 * g + 1] = p.g; o[3 * g + 2] = p.b; }
+                else o[g] = p.sig;
+            }
+            return GS_OK;
+        }
+        case GS_ARR_DEPTH_KEY: src = c->depth_key.p; need = sizeof(uint32_t) * n; break;
+        case GS_ARR_TILE_RECT: src = c->rect.p; need = sizeof(uint16_t) * 4 * n; break;
+        case GS_ARR_SORT_IDXS: {
+            if ((size_t)bytes != sizeof(uint32_t) * n) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
+            if (c->perm_ptr) { src = c->perm_ptr; need = sizeof(uint32_t) * n; break; }
+            uint32_t *o = static_cast<uint32_t *>(dst);
+            for (size_t g = 0; g < n; ++g) o[g] = (uint32_t)g;
+            return GS_OK;
+        }
+        case GS_ARR_TILE_RANGES: src = c->ranges.p; need = sizeof(uint32_t) * 2 * (size_t)c->gx * c->gy; break;
+        case GS_ARR_SORTED_IDS: case GS_ARR_SORTED_KEYS: {
+            const size_t ni = (size_t)c->n_inst;
+            const size_t w = which == GS_ARR_SORTED_IDS ? sizeof(uint32_t) : sizeof(uint64_t);
+            if ((size_t)bytes != w * ni) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
+            std::vector<uint64_t> h(ni ? ni : 1);
+            std::vector<uint32_t> dk(n ? n : 1);
+            HIPCHK(c, hipMemcpyAsync(h.data(), c->inst_sorted, sizeof(uint64_t) * ni, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(dk.data(), c->depth_key.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (which == GS_ARR_SORTED_IDS) {
+                uint32_t *o = static_cast<uint32_t *>(dst);
+                for (size_t p = 0; p < ni; ++p) o[p] = (uint32_t)h[p];
+            } else {
+                uint64_t *o = static_cast<uint64_t *>(dst);
+                const bool by_index = c->cfg.order == GS_ORDER_INDEX;
+                for (size_t p = 0; p < ni; ++p) {
+                    const uint32_t g = (uint32_t)h[p];
+                    o[p] = (h[p] & 0xFFFFFFFF00000000ull) | (by_index ? g : dk[g]);
+                }
+            }
+            return GS_OK;
+        }
+        case GS_ARR_GRAD2D:
+            if (!c->did_bwd) return fail(c, GS_ERR_INVALID, "gs_get_array: gs_backward first");
+            src = c->g2d.p; need = sizeof(float) * 10 * n; break;
+        default: return fail(c, GS_ERR_INVALID, "gs_get_array: unknown array");
+    }
+    if ((size_t)bytes != need) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
+    if (need) HIPCHK(c, hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int gs_get_stage_times(gs_ctx *c, float ms[GS_STAGE_COUNT]) {
+    if (!c || !ms) return GS_ERR_INVALID;
+    if (!c->cfg.profile_stages) return fail(c, GS_ERR_INVALID, "gs_get_stage_times: needs gs_config.profile_stages = 1");
+    if (bind_device(c)) return GS_ERR_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < GS_STAGE_COUNT; ++s) {
+        ms[s] = 0.0f;
+        if (c->ev_valid[s]) HIPCHK(c, hipEventElapsedTime(&ms[s], c->ev[s][0], c->ev[s][1]));
+    }
+    return GS_OK;
+}
+
+int gs_get_stage_stats(gs_ctx *c, double sum_ms[GS_STAGE_COUNT], int64_t count[GS_STAGE_COUNT], int reset) {
+    if (!c || !sum_ms || !count) return GS_ERR_INVALID;
+    if (!c->cfg.profile_stages) return fail(c, GS_ERR_INVALID, "gs_get_stage_stats: needs gs_config.profile_stages = 1");
+    if (bind_device(c)) return GS_ERR_HIP;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    harvest_events(c);
+    for (int s = 0; s < GS_STAGE_COUNT; ++s) {
+        sum_ms[s] = c->ev_sum[s]; count[s] = c->ev_cnt[s];
+        if (reset) { c->ev_sum[s] = 0.0; c->ev_cnt[s] = 0; }
+    }
+    return GS_OK;
+}
+
+int gs_get_work_counters(gs_ctx *c, int64_t *walked_fwd, int64_t *walked_bwd) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_work_counters: gs_forward first");
+    if (bind_device(c)) return GS_ERR_HIP;
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, c->counters.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (walked_fwd) *walked_fwd = (int64_t)h[0];
+    if (walked_bwd) *walked_bwd = (int64_t)h[1];
+    return GS_OK;
+}
+
+}  // extern "C"

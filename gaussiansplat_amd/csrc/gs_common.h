@@ -1,0 +1,94 @@
+// gs_common.h -- shared device/host declarations of libgsplat_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GS_TILE 16
+#define GS_WAVE 64
+
+// Per-gaussian, per-view splat payload staged through LDS by the composite kernels.
+// 48 bytes, 16-byte aligned (three dwordx4 loads).  Replaces the 26 scattered floats the
+// reference gathers per (pixel, slot) (src/splat.jl:224-252).
+struct __attribute__((aligned(16))) GsPayload {
+    float mx, my;        // renderer.positions (mu')                      projection.jl:88-93
+    float sig;           // cusigmoid(opacity)                            splat.jl:175-178
+    uint32_t bbx;        // int16 xmin | int16 xmax << 16  (renderer.bbs)  boundingbox.jl:24-25
+    float i0, i1, i2, i3;// renderer.invCov2ds, column-major              cov2d.jl:30-45
+    float r, g, b;       // sh2color                                      splat.jl:180-193
+    uint32_t bby;        // int16 ymin | int16 ymax << 16                 boundingbox.jl:26-27
+};
+static_assert(sizeof(GsPayload) == 48, "payload must be 48 bytes");
+
+struct GsCamera {
+    float T[16], P[16];
+    float fx, fy, near_, far_;
+    float eye[3], lookAt[3];
+    int32_t W, H;
+};
+
+// Optional scratch arrays of the reference renderer (export_debug).
+struct GsDebugArrays {
+    float *ts, *tps, *mu, *cov3d, *cov2d, *invcov, *bbs;
+};
+
+struct GsPreprocessArgs {
+    int64_t n;
+    int sh_degree;
+    int order;
+    int gx, gy;
+    const float *means, *scales, *quats, *opac, *shs;
+    GsPayload *payload;
+    uint32_t *depth_key;
+    uint16_t *rect;       // 4 x n : x0 x1 y0 y1 (1-based inclusive, x0 == 0 -> no tile)
+    GsDebugArrays dbg;
+};
+
+// launchers (each enqueues on `stream`, returns hipGetLastError())
+hipError_t gs_launch_preprocess(const GsPreprocessArgs &a, const GsCamera &cam, hipStream_t stream);
+
+struct GsSortScratch {     // sized by gs_sort_scratch_bytes
+    uint32_t *block_hist;  // [256][nblocks]
+    uint32_t *digit_total; // [256]
+};
+size_t gs_sort_table_entries(int64_t n_max);
+// Stable LSD radix sort of n 64-bit keys on bits [bit_lo, bit_hi); result ends in *out_is_b.
+hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
+                             uint32_t *block_hist, uint32_t *digit_total, int *result_in_b,
+                             hipStream_t stream);
+
+hipError_t gs_launch_depth_pairs(const uint32_t *depth_key, uint64_t *pairs, int64_t n, hipStream_t s);
+hipError_t gs_launch_unpack_perm(const uint64_t *pairs, uint32_t *perm, int64_t n, hipStream_t s);
+// counts[s] = tiles of gaussian perm[s] (perm may be null = identity), then exclusive scan
+// into offsets[0..n]; offsets[n] = total instances.
+hipError_t gs_launch_count_scan(const uint16_t *rect, const uint32_t *perm, uint32_t *offsets,
+                                uint32_t *block_sums, int64_t n, hipStream_t s);
+hipError_t gs_launch_emit(const uint16_t *rect, const uint32_t *perm, const uint32_t *offsets,
+                          uint64_t *inst, int64_t n, int gx, hipStream_t s);
+hipError_t gs_launch_ranges(const uint64_t *inst, int64_t n_inst, uint32_t *ranges, int64_t n_tiles,
+                            hipStream_t s);
+hipError_t gs_launch_split_ids(const uint64_t *inst, uint32_t *ids, int64_t n_inst, hipStream_t s);
+
+struct GsCompositeArgs {
+    int W, H, gx, gy;
+    float t_min;
+    const uint32_t *ranges;    // 2 x tiles
+    const uint64_t *inst;      // sorted instances (tile<<32 | gaussian id)
+    const GsPayload *payload;
+    float *image;              // W*H*3 planar
+    float *trans;              // W*H
+    // backward only
+    const float *dC;           // W*H*3
+    float *g2d;                // 10 x n (atomic accumulate): drgb3 dsig dmu2 dinv4
+    unsigned long long *walked; // list entries walked by this launch (one atomic per tile)
+};
+hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
+hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);
+
+struct GsPreprocessBwdArgs {
+    int64_t n;
+    int sh_degree;
+    const float *means, *scales, *quats, *opac, *shs;
+    const float *g2d;
+    float *d_means, *d_scales, *d_quats, *d_opac, *d_shs;   // accumulate (+=); may be null
+};
+hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s);

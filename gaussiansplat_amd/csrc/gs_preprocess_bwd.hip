@@ -1,0 +1,226 @@
+// gs_preprocess_bwd.hip -- per-gaussian chain rule from the 2-D splat gradients back to the
+// model parameters (means, scales, quaternions, opacities, SH coefficients).
+//
+// The reference has no 3-D backward: backward.jl:3-38 launches splatGrads (splat.jl:271-396),
+// the adjoint of an older 2-D fitting forward, and grads.jl:1-3 (updateColorGrads) is an empty
+// stub.  What is contractual is kept: gradients ACCUMULATE into arrays shaped like the
+// parameters (splat.jl:137-156) until resetGrads (splat.jl:158-173).  The mathematics is the
+// derived adjoint of the reference FORWARD (projection.jl:39-155, cov2d.jl:30-45,
+// splat.jl:175-193), including its quirks: R22 = 1 - 2(x^2 - z^2), the gaussian's own R in
+// J*R, +0.3 on all four covariance entries, clip-space view direction for SH.
+//
+// One thread per gaussian, no atomics (each thread owns its rows).  HBM-bound: reads
+// 4*(11+3K)+40 B, writes 4*(11+3K) B per gaussian (read-modify-write for the += contract).
+#include "gs_common.h"
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.48860251190291990f
+__constant__ float bC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                             -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float bC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                             -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+template <int DEG>
+__global__ __launch_bounds__(256) void gs_preprocess_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n) return;
+    const float *g2 = a.g2d + 10 * g;
+    const float grgb[3] = {g2[0], g2[1], g2[2]};
+    const float gsig = g2[3], gmx = g2[4], gmy = g2[5];
+    const float G[2][2] = {{g2[6], g2[8]}, {g2[7], g2[9]}};            // G[r][c] = dL/dM[r][c], column-major storage
+    const float *T = cam.T, *P = cam.P;
+
+    // ---- forward recompute (same formulas as gs_preprocess.hip)
+    const float m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
+    float t[4], p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = T[i] * m1 + T[i + 4] * m2 + T[i + 8] * m3 + T[i + 12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = P[i] * t[0] + P[i + 4] * t[1] + P[i + 8] * t[2] + P[i + 12] * t[3];
+    const float tx = t[0], ty = t[1], tz = t[2], fx = cam.fx, fy = cam.fy;
+    const float itz = 1.0f / tz, itz2 = itz * itz;
+    const float J[2][3] = {{fx * itz, 0.0f, -fx * tx * itz2}, {0.0f, fy * itz, -fy * ty * itz2}};
+    const float w = a.quats[4 * g], x = a.quats[4 * g + 1], y = a.quats[4 * g + 2], z = a.quats[4 * g + 3];
+    const float R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+                           {2 * (x * y + w * z), 1 - 2 * (x * x - z * z), 2 * (y * z - w * x)},
+                           {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+    const float e[3] = {__expf(a.scales[3 * g]), __expf(a.scales[3 * g + 1]), __expf(a.scales[3 * g + 2])};
+    float Wm[3][3], Sg[3][3], A[2][3], ASg[2][3], cov[2][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Wm[i][j] = R[i][j] * e[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Sg[i][j] = Wm[i][0] * Wm[j][0] + Wm[i][1] * Wm[j][1] + Wm[i][2] * Wm[j][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) A[i][j] = J[i][0] * R[0][j] + J[i][1] * R[1][j] + J[i][2] * R[2][j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ASg[i][j] = A[i][0] * Sg[0][j] + A[i][1] * Sg[1][j] + A[i][2] * Sg[2][j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cov[i][j] = ASg[i][0] * A[j][0] + ASg[i][1] * A[j][1] + ASg[i][2] * A[j][2] + 0.3f;
+    const float idet = 1.0f / (cov[0][0] * cov[1][1] - cov[0][1] * cov[1][0]);
+    const float M[2][2] = {{cov[1][1] * idet, -cov[0][1] * idet}, {-cov[1][0] * idet, cov[0][0] * idet}};
+
+    // ---- M = cov^-1  =>  dcov = -M^T G M^T
+    float t1[2][2], dcov[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) t1[i][j] = M[0][i] * G[0][j] + M[1][i] * G[1][j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dcov[i][j] = -(t1[i][0] * M[j][0] + t1[i][1] * M[j][1]);
+    // ---- cov = A Sg A^T (+0.3): dA = (dcov + dcov^T) A Sg ; dSg = A^T dcov A
+    const float off = dcov[0][1] + dcov[1][0];
+    const float ds2[2][2] = {{2 * dcov[0][0], off}, {off, 2 * dcov[1][1]}};
+    float dA[2][3], dSg[3][3], dJ[2][3], dR[3][3], dWm[3][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dA[i][j] = ds2[i][0] * ASg[0][j] + ds2[i][1] * ASg[1][j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            dSg[i][j] = A[0][i] * (dcov[0][0] * A[0][j] + dcov[0][1] * A[1][j]) + A[1][i] * (dcov[1][0] * A[0][j] + dcov[1][1] * A[1][j]);
+    // ---- A = J R
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dJ[i][j] = dA[i][0] * R[j][0] + dA[i][1] * R[j][1] + dA[i][2] * R[j][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dR[i][j] = J[0][i] * dA[0][j] + J[1][i] * dA[1][j];
+    // ---- Sg = Wm Wm^T, Wm = R diag(e)
+    float de[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s += (dSg[i][k] + dSg[k][i]) * Wm[k][j];
+            dWm[i][j] = s;
+            dR[i][j] += s * e[j];
+            de[j] += R[i][j] * s;
+        }
+    // ---- R(q), with the reference's R22
+    float dw = 0, dx = 0, dy = 0, dz = 0;
+    dy += -4 * y * dR[0][0]; dz += -4 * z * dR[0][0];
+    dx += 2 * y * dR[1][0]; dy += 2 * x * dR[1][0]; dw += 2 * z * dR[1][0]; dz += 2 * w * dR[1][0];
+    dx += 2 * z * dR[2][0]; dz += 2 * x * dR[2][0]; dw += -2 * y * dR[2][0]; dy += -2 * w * dR[2][0];
+    dx += 2 * y * dR[0][1]; dy += 2 * x * dR[0][1]; dw += -2 * z * dR[0][1]; dz += -2 * w * dR[0][1];
+    dx += -4 * x * dR[1][1]; dz += 4 * z * dR[1][1];
+    dy += 2 * z * dR[2][1]; dz += 2 * y * dR[2][1]; dw += 2 * x * dR[2][1]; dx += 2 * w * dR[2][1];
+    dx += 2 * z * dR[0][2]; dz += 2 * x * dR[0][2]; dw += 2 * y * dR[0][2]; dy += 2 * w * dR[0][2];
+    dy += 2 * z * dR[1][2]; dz += 2 * y * dR[1][2]; dw += -2 * x * dR[1][2]; dx += -2 * w * dR[1][2];
+    dx += -4 * x * dR[2][2]; dy += -4 * y * dR[2][2];
+    // ---- J(t)
+    float dt[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0};
+    const float itz3 = itz2 * itz;
+    dt[0] += dJ[0][2] * (-fx * itz2);
+    dt[1] += dJ[1][2] * (-fy * itz2);
+    dt[2] += dJ[0][0] * (-fx * itz2) + dJ[1][1] * (-fy * itz2) + dJ[0][2] * (2 * fx * tx * itz3) + dJ[1][2] * (2 * fy * ty * itz3);
+    // ---- mu(p): mu = (W p0/p3 + 1)/2 + W/2
+    const float ip3 = 1.0f / p[3];
+    const float Wd = (float)cam.W, Hd = (float)cam.H;
+    dp[0] += gmx * 0.5f * Wd * ip3;
+    dp[1] += gmy * 0.5f * Hd * ip3;
+    dp[3] += -(gmx * 0.5f * Wd * p[0] + gmy * 0.5f * Hd * p[1]) * ip3 * ip3;
+    // ---- rgb(sh, dir(p))
+    const float v0 = p[0] - (cam.lookAt[0] - cam.eye[0]);
+    const float v1 = p[1] - (cam.lookAt[1] - cam.eye[1]);
+    const float v2 = p[2] - (cam.lookAt[2] - cam.eye[2]);
+    const float inrm = rsqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+    const float dxn = v0 * inrm, dyn = v1 * inrm, dzn = v2 * inrm;
+    float bs[K], db[K][3];
+#pragma unroll
+    for (int k = 0; k < K; ++k) db[k][0] = db[k][1] = db[k][2] = 0.0f;
+    bs[0] = SH_C0;
+    if constexpr (DEG >= 1) {
+        bs[1] = -dyn * SH_C1; db[1][1] = -SH_C1;
+        bs[2] = dzn * SH_C1;  db[2][2] = SH_C1;
+        bs[3] = -dxn * SH_C1; db[3][0] = -SH_C1;
+    }
+    if constexpr (DEG >= 2) {
+        const float X = dxn, Y = dyn, Z = dzn;
+        const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+        bs[4] = bC2[0] * xy;                 db[4][0] = bC2[0] * Y;  db[4][1] = bC2[0] * X;
+        bs[5] = bC2[1] * yz;                 db[5][1] = bC2[1] * Z;  db[5][2] = bC2[1] * Y;
+        bs[6] = bC2[2] * (2 * zz - xx - yy); db[6][0] = -2 * bC2[2] * X; db[6][1] = -2 * bC2[2] * Y; db[6][2] = 4 * bC2[2] * Z;
+        bs[7] = bC2[3] * xz;                 db[7][0] = bC2[3] * Z;  db[7][2] = bC2[3] * X;
+        bs[8] = bC2[4] * (xx - yy);          db[8][0] = 2 * bC2[4] * X; db[8][1] = -2 * bC2[4] * Y;
+        if constexpr (DEG >= 3) {
+            bs[9]  = bC3[0] * Y * (3 * xx - yy);           db[9][0] = 6 * bC3[0] * xy;  db[9][1] = bC3[0] * (3 * xx - 3 * yy);
+            bs[10] = bC3[1] * xy * Z;                      db[10][0] = bC3[1] * yz; db[10][1] = bC3[1] * xz; db[10][2] = bC3[1] * xy;
+            bs[11] = bC3[2] * Y * (4 * zz - xx - yy);      db[11][0] = -2 * bC3[2] * xy; db[11][1] = bC3[2] * (4 * zz - xx - 3 * yy); db[11][2] = 8 * bC3[2] * yz;
+            bs[12] = bC3[3] * Z * (2 * zz - 3 * xx - 3 * yy); db[12][0] = -6 * bC3[3] * xz; db[12][1] = -6 * bC3[3] * yz; db[12][2] = bC3[3] * (6 * zz - 3 * xx - 3 * yy);
+            bs[13] = bC3[4] * X * (4 * zz - xx - yy);      db[13][0] = bC3[4] * (4 * zz - 3 * xx - yy); db[13][1] = -2 * bC3[4] * xy; db[13][2] = 8 * bC3[4] * xz;
+            bs[14] = bC3[5] * Z * (xx - yy);               db[14][0] = 2 * bC3[5] * xz; db[14][1] = -2 * bC3[5] * yz; db[14][2] = bC3[5] * (xx - yy);
+            bs[15] = bC3[6] * X * (xx - 3 * yy);           db[15][0] = bC3[6] * (3 * xx - 3 * yy); db[15][1] = -6 * bC3[6] * xy;
+        }
+    }
+    const float *sh = a.shs + (int64_t)3 * K * g;
+    float ddir[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float cs = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            cs += grgb[c] * sh[c + 3 * k];
+            if (a.d_shs) a.d_shs[(int64_t)3 * K * g + c + 3 * k] += bs[k] * grgb[c];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ddir[q] += cs * db[k][q];
+    }
+    const float dd = dxn * ddir[0] + dyn * ddir[1] + dzn * ddir[2];
+    dp[0] += (ddir[0] - dxn * dd) * inrm;
+    dp[1] += (ddir[1] - dyn * dd) * inrm;
+    dp[2] += (ddir[2] - dzn * dd) * inrm;
+    // ---- p = P t ; t = T [m;1]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dt[j] += P[i + 4 * j] * dp[i];
+    if (a.d_means) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            a.d_means[3 * g + j] += T[4 * j] * dt[0] + T[1 + 4 * j] * dt[1] + T[2 + 4 * j] * dt[2] + T[3 + 4 * j] * dt[3];
+    }
+    if (a.d_scales) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a.d_scales[3 * g + j] += de[j] * e[j];
+    }
+    if (a.d_quats) {
+        a.d_quats[4 * g] += dw; a.d_quats[4 * g + 1] += dx; a.d_quats[4 * g + 2] += dy; a.d_quats[4 * g + 3] += dz;
+    }
+    if (a.d_opac) {
+        const float ez = __expf(a.opac[g]);
+        const float sg = ez / (1.0f + ez);
+        a.d_opac[g] += gsig * sg * (1.0f - sg);
+    }
+}
+
+hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    const dim3 block(256), grid((unsigned)((a.n + 255) / 256));
+    switch (a.sh_degree) {
+        case 0: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<0>, grid, block, 0, s, a, cam); break;
+        case 1: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<1>, grid, block, 0, s, a, cam); break;
+        case 2: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<2>, grid, block, 0, s, a, cam); break;
+        case 3: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<3>, grid, block, 0, s, a, cam); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

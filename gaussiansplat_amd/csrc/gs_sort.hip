@@ -1,0 +1,368 @@
+// gs_sort.hip -- tile binning for gfx950: instance count/scan/emit, stable LSD radix sort,
+// tile ranges.
+//
+// Replaces the reference's dense tiles x N machinery -- hitBinning (src/binning.jl:3-35), the
+// UInt16 CUDA.scan! over the gaussian axis and CUDA.maximum (src/forward.jl:137-141),
+// compactHits (src/compact.jl:3-21, one 1024-thread block PER GAUSSIAN) and
+// CUDA.sortperm(-tps[3,:]) (src/forward.jl:103) -- by sparse (tile | depth) keys.
+//
+// The 64-bit key tile<<32 | depth is sorted as a factorised LSD radix sort: the 32 depth bits
+// are identical for every tile-instance of a gaussian, so those four digit passes run on the
+// N gaussians BEFORE expansion (depth<<32 | id pairs); instances are then emitted in that
+// order and only the tile bits (two 8-bit digits) are sorted over the I instances.  Every
+// pass is stable, so the result is bit-identical to a stable sort of the full 64-bit keys
+// with ties in gaussian-index order.  All of this is HBM-bound integer work: coalesced 8-byte
+// streams, LDS histograms and an LDS-staged scatter; no MFMA.
+#include "gs_common.h"
+
+#define RS_THREADS 256
+#define RS_ITEMS 16
+#define RS_CHUNK (RS_THREADS * RS_ITEMS)   // 4096 keys per workgroup
+#define RS_RADIX 256
+#define RS_WAVES (RS_THREADS / GS_WAVE)
+
+size_t gs_sort_table_entries(int64_t n_max) {
+    const int64_t nb = (n_max + RS_CHUNK - 1) / RS_CHUNK;
+    return (size_t)(nb > 0 ? nb : 1) * RS_RADIX;
+}
+
+// ---------------------------------------------------------------- radix pass: histogram
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, int64_t n, int shift,
+                                                              uint32_t *__restrict__ block_hist, int nblocks) {
+    __shared__ uint32_t h[RS_RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int64_t idx = base + (int64_t)i * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & (RS_RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];   // [digit][block]
+}
+
+// ---------------------------------------------------------------- radix pass: scan
+// One workgroup per digit: exclusive scan of its row of per-block counts, offset by the total
+// of all smaller digits (each workgroup re-reduces the rows below it -- nblocks*256 dwords from
+// L2, negligible next to the key traffic).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < GS_WAVE; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__device__ uint32_t block_reduce_u32(uint32_t v, uint32_t *sm) {
+#pragma unroll
+    for (int d = GS_WAVE / 2; d > 0; d >>= 1) v += __shfl_down(v, d);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    uint32_t t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+    return t;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_digit_totals_kernel(const uint32_t *__restrict__ block_hist, int nblocks,
+                                                                      uint32_t *__restrict__ digit_total) {
+    __shared__ uint32_t sm[RS_WAVES];
+    const uint32_t *row = block_hist + (size_t)blockIdx.x * nblocks;
+    uint32_t s = 0;
+    for (int i = threadIdx.x; i < nblocks; i += RS_THREADS) s += row[i];
+    s = block_reduce_u32(s, sm);
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restrict__ block_hist, int nblocks,
+                                                              const uint32_t *__restrict__ digit_total) {
+    __shared__ uint32_t sm[RS_WAVES];
+    __shared__ uint32_t carry;
+    const int d = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t below = (threadIdx.x < d) ? digit_total[threadIdx.x] : 0u;
+    below = block_reduce_u32(below, sm);
+    if (threadIdx.x == 0) carry = below;
+    __syncthreads();
+    uint32_t *row = block_hist + (size_t)d * nblocks;
+    for (int base = 0; base < nblocks; base += RS_THREADS) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? row[i] : 0u;
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (lane == 63) sm[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += sm[k];
+        const uint32_t c = carry;
+        if (i < nblocks) row[i] = c + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == RS_THREADS - 1) carry = c + woff + incl;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- radix pass: stable scatter
+// Wave w owns keys [w*1024, (w+1)*1024) of the chunk in 16 rounds of 64 (wave-striped), so
+// the stable rank order is (wave, round, lane).  Ranks come from wave64 ballots (8 per round:
+// the set of lanes holding the same digit) and a per-wave running LDS counter; keys are then
+// placed digit-contiguously in LDS and written out in runs.
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                                 int64_t n, int shift, const uint32_t *__restrict__ block_hist,
+                                                                 int nblocks) {
+    __shared__ uint64_t skeys[RS_CHUNK];                 // 32 KiB
+    __shared__ uint32_t wcnt[RS_WAVES][RS_RADIX];        // running count per (wave, digit)
+    __shared__ uint32_t lpre[RS_RADIX];                  // exclusive prefix over digits in this chunk
+    __shared__ uint32_t gbase[RS_RADIX];
+    __shared__ uint32_t sm[RS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
+    const int64_t remain = n - base;
+    const int cnt = remain < RS_CHUNK ? (int)remain : RS_CHUNK;
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; ++k) wcnt[k][tid] = 0;
+    gbase[tid] = block_hist[(size_t)tid * nblocks + blockIdx.x];
+    __syncthreads();
+
+    uint64_t key[RS_ITEMS];
+    uint32_t rank[RS_ITEMS];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const int li = w * (GS_WAVE * RS_ITEMS) + r * GS_WAVE + lane;    // index inside the chunk
+        const bool valid = li < cnt;
+        key[r] = valid ? in[base + li] : ~0ull;
+        const uint32_t dg = (uint32_t)(key[r] >> shift) & (RS_RADIX - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((dg >> b) & 1u);
+            peers &= ((dg >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t before = wcnt[w][dg];                            // same-digit keys of earlier rounds
+        rank[r] = before + (uint32_t)__popcll(peers & lt_mask);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt_mask) == 0ull) wcnt[w][dg] = before + (uint32_t)__popcll(peers);   // group leader
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // thread `tid` == digit: per-wave exclusive offsets and the chunk's digit prefix
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; ++k) { const uint32_t c = wcnt[k][tid]; wcnt[k][tid] = tot; tot += c; }
+    {
+        const uint32_t incl = wave_incl_scan(tot, lane);
+        if (lane == 63) sm[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += sm[k];
+        lpre[tid] = woff + incl - tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const int li = w * (GS_WAVE * RS_ITEMS) + r * GS_WAVE + lane;
+        if (li < cnt) {
+            const uint32_t dg = (uint32_t)(key[r] >> shift) & (RS_RADIX - 1);
+            skeys[lpre[dg] + wcnt[w][dg] + rank[r]] = key[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const int li = r * RS_THREADS + tid;
+        if (li < cnt) {
+            const uint64_t k = skeys[li];
+            const uint32_t dg = (uint32_t)(k >> shift) & (RS_RADIX - 1);
+            out[(size_t)gbase[dg] + (uint32_t)(li - (int)lpre[dg])] = k;
+        }
+    }
+}
+
+hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
+                             uint32_t *block_hist, uint32_t *digit_total, int *result_in_b, hipStream_t stream) {
+    *result_in_b = 0;
+    if (n <= 0) return hipSuccess;
+    const int nblocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
+    uint64_t *src = a, *dst = b;
+    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, n, shift, block_hist, nblocks);
+        hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, block_hist, nblocks);
+        uint64_t *t = src; src = dst; dst = t;
+        *result_in_b ^= 1;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- depth pairs
+__global__ void depth_pairs_kernel(const uint32_t *__restrict__ key, uint64_t *__restrict__ pairs, int64_t n) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) pairs[g] = ((uint64_t)key[g] << 32) | (uint32_t)g;
+}
+__global__ void unpack_perm_kernel(const uint64_t *__restrict__ pairs, uint32_t *__restrict__ perm, int64_t n) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) perm[g] = (uint32_t)pairs[g];
+}
+hipError_t gs_launch_depth_pairs(const uint32_t *depth_key, uint64_t *pairs, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(depth_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, depth_key, pairs, n);
+    return hipGetLastError();
+}
+hipError_t gs_launch_unpack_perm(const uint64_t *pairs, uint32_t *perm, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pairs, perm, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- instance count + exclusive scan
+#define SC_THREADS 256
+#define SC_ITEMS 8
+#define SC_CHUNK (SC_THREADS * SC_ITEMS)
+
+__device__ __forceinline__ uint32_t rect_area(const uint16_t *__restrict__ rect, int64_t g) {
+    const uint2 r = reinterpret_cast<const uint2 *>(rect)[g];
+    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu, y1 = r.y >> 16;
+    return x0 == 0u ? 0u : (x1 - x0 + 1u) * (y1 - y0 + 1u);
+}
+
+// pass 1: per-chunk totals
+__global__ __launch_bounds__(SC_THREADS) void count_reduce_kernel(const uint16_t *__restrict__ rect, const uint32_t *__restrict__ perm,
+                                                                   int64_t n, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t sm[SC_THREADS / GS_WAVE];
+    const int64_t base = (int64_t)blockIdx.x * SC_CHUNK;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i) {
+        const int64_t idx = base + (int64_t)i * SC_THREADS + threadIdx.x;
+        if (idx < n) s += rect_area(rect, perm ? (int64_t)perm[idx] : idx);
+    }
+    s = block_reduce_u32(s, sm);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+}
+// pass 2: one workgroup scans the chunk totals in place (exclusive) and stores the grand total
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t *__restrict__ block_sums, int nb, uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t sm[16];
+    __shared__ uint32_t carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < nb) ? block_sums[i] : 0u;
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (lane == 63) sm[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += sm[k];
+        const uint32_t c = carry;
+        if (i < nb) block_sums[i] = c + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+// pass 3: per-chunk exclusive scan with the chunk base.  Thread t owns SC_ITEMS consecutive
+// gaussians so the scan order is the list order.
+__global__ __launch_bounds__(SC_THREADS) void count_scan_kernel(const uint16_t *__restrict__ rect, const uint32_t *__restrict__ perm,
+                                                                 int64_t n, const uint32_t *__restrict__ block_sums,
+                                                                 uint32_t *__restrict__ offsets) {
+    __shared__ uint32_t sm[SC_THREADS / GS_WAVE];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SC_CHUNK + (int64_t)threadIdx.x * SC_ITEMS;
+    uint32_t c[SC_ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i) {
+        const int64_t idx = base + i;
+        c[i] = (idx < n) ? rect_area(rect, perm ? (int64_t)perm[idx] : idx) : 0u;
+        s += c[i];
+    }
+    const uint32_t incl = wave_incl_scan(s, lane);
+    if (lane == 63) sm[w] = incl;
+    __syncthreads();
+    uint32_t off = block_sums[blockIdx.x] + incl - s;
+    for (int k = 0; k < w; ++k) off += sm[k];
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i) {
+        const int64_t idx = base + i;
+        if (idx < n) offsets[idx] = off;
+        off += c[i];
+    }
+}
+
+hipError_t gs_launch_count_scan(const uint16_t *rect, const uint32_t *perm, uint32_t *offsets, uint32_t *block_sums,
+                                int64_t n, hipStream_t s) {
+    if (n <= 0) return hipMemsetAsync(offsets, 0, sizeof(uint32_t), s);
+    const int nb = (int)((n + SC_CHUNK - 1) / SC_CHUNK);
+    hipLaunchKernelGGL(count_reduce_kernel, dim3(nb), dim3(SC_THREADS), 0, s, rect, perm, n, block_sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, offsets + n);
+    hipLaunchKernelGGL(count_scan_kernel, dim3(nb), dim3(SC_THREADS), 0, s, rect, perm, n, block_sums, offsets);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- instance emission
+// One wave per 64 list positions; the wave walks its 64 gaussians and writes each one's
+// tile instances with all lanes (coalesced 8-byte stores), so a gaussian covering hundreds of
+// tiles does not serialise on one lane.  Key = tile<<32 | gaussian id, tile = (ty-1)*gx+(tx-1)
+// (SURVEY 8a A6).
+__global__ __launch_bounds__(256) void emit_kernel(const uint16_t *__restrict__ rect, const uint32_t *__restrict__ perm,
+                                                    const uint32_t *__restrict__ offsets, uint64_t *__restrict__ inst,
+                                                    int64_t n, int gx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t s = wave * GS_WAVE + lane;
+    uint32_t g = 0, off = 0, x0 = 0, y0 = 0, wdt = 0, cnt = 0;
+    if (s < n) {
+        g = perm ? perm[s] : (uint32_t)s;
+        off = offsets[s];
+        const uint2 r = reinterpret_cast<const uint2 *>(rect)[g];
+        x0 = r.x & 0xFFFFu; y0 = r.y & 0xFFFFu;
+        if (x0 != 0u) { wdt = (r.x >> 16) - x0 + 1u; cnt = wdt * ((r.y >> 16) - y0 + 1u); }
+    }
+    unsigned long long todo = __ballot(cnt != 0u);
+    while (todo) {
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t kg = __shfl(g, k), koff = __shfl(off, k), kx0 = __shfl(x0, k), ky0 = __shfl(y0, k);
+        const uint32_t kw = __shfl(wdt, k), kc = __shfl(cnt, k);
+        for (uint32_t j = lane; j < kc; j += GS_WAVE) {
+            const uint32_t ty = ky0 + j / kw, tx = kx0 + j % kw;
+            const uint32_t tile = (ty - 1u) * (uint32_t)gx + (tx - 1u);
+            inst[(size_t)koff + j] = ((uint64_t)tile << 32) | kg;
+        }
+    }
+}
+hipError_t gs_launch_emit(const uint16_t *rect, const uint32_t *perm, const uint32_t *offsets, uint64_t *inst, int64_t n,
+                          int gx, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rect, perm, offsets, inst, n, gx);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- tile ranges
+__global__ void ranges_kernel(const uint64_t *__restrict__ inst, int64_t n_inst, uint32_t *__restrict__ ranges) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_inst) return;
+    const uint32_t t = (uint32_t)(inst[p] >> 32);
+    if (p == 0 || (uint32_t)(inst[p - 1] >> 32) != t) ranges[2 * (size_t)t] = (uint32_t)p;
+    if (p == n_inst - 1 || (uint32_t)(inst[p + 1] >> 32) != t) ranges[2 * (size_t)t + 1] = (uint32_t)(p + 1);
+}
+hipError_t gs_launch_ranges(const uint64_t *inst, int64_t n_inst, uint32_t *ranges, int64_t n_tiles, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)n_tiles, s);
+    if (e != hipSuccess || n_inst <= 0) return e;
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((n_inst + 255) / 256)), dim3(256), 0, s, inst, n_inst, ranges);
+    return hipGetLastError();
+}
+
+__global__ void split_ids_kernel(const uint64_t *__restrict__ inst, uint32_t *__restrict__ ids, int64_t n) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) ids[p] = (uint32_t)inst[p];
+}
+hipError_t gs_launch_split_ids(const uint64_t *inst, uint32_t *ids, int64_t n_inst, hipStream_t s) {
+    if (n_inst <= 0) return hipSuccess;
+    hipLaunchKernelGGL(split_ids_kernel, dim3((unsigned)((n_inst + 255) / 256)), dim3(256), 0, s, inst, ids, n_inst);
+    return hipGetLastError();
+}

@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference renderer API (src/renderer.jl, src/forward.jl,
+src/backward.jl, src/splat.jl) over the C ABI of libgsplat_hip.so.
+
+The reference's call sequence (src/examples/main.jl:14-34) works unchanged in spirit:
+
+    renderer = getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), path_or_scene)
+    tps = preprocess(renderer)
+    compactIdxs(renderer, (16, 16), (gx, gy))
+    forward(renderer, tps, (16, 16), (gx, gy))
+    backward(renderer, dC); ...optimiser...; resetGrads(renderer.splatGrads)
+
+Names, argument meaning and in-place semantics follow the reference: outputs land in
+`renderer.imageData` / `renderer.transmittance`, gradients ACCUMULATE in
+`renderer.splatGrads.*` until `resetGrads`.  Arrays are torch tensors on the renderer's GPU
+with the reference's memory layout ([n, comp] row-major == Julia [comp, n] column-major;
+imageData [3, H, W] == Julia [W, H, 3]).  torch is plumbing only (device memory, streams);
+all compute is in the HIP library and there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import backend as B
+from .camera import Camera, compute_projection, compute_transform, default_camera
+
+
+class RendererType(enum.Enum):          # renderer.jl:20-24
+    GAUSSIAN_2D = 0
+    GAUSSIAN_3D = 1
+    OPTIMAL_PROJECTION_3D = 2
+
+
+@dataclass
+class SplatData3D:                      # splat.jl:36-43
+    means: "torch.Tensor"               # [n, 3]
+    scales: "torch.Tensor"              # [n, 3]  log-space
+    shs: "torch.Tensor"                 # [n, 3K] element [3k + c]
+    quaternions: "torch.Tensor"         # [n, 4]  (w, x, y, z), not normalised by the kernels
+    opacities: "torch.Tensor"           # [n, 1]  logit
+    features: object = None
+
+
+@dataclass
+class SplatGrads3D:                     # splat.jl:45-52 -- views into ONE flat buffer (single all-reduce)
+    flat: "torch.Tensor"
+    Δmeans: "torch.Tensor"
+    Δscales: "torch.Tensor"
+    Δquaternions: "torch.Tensor"
+    Δopacities: "torch.Tensor"
+    Δshs: "torch.Tensor"
+    Δfeatures: object = None
+
+
+def initGrads(splatData: SplatData3D) -> SplatGrads3D:
+    """splat.jl:137-156; laid out as one flat fp32 buffer
+    [Δmeans 3N | Δscales 3N | Δquats 4N | Δopac N | Δshs 3K·N] so that a multi-view step needs a
+    single RCCL all-reduce."""
+    import torch
+    n = splatData.means.shape[0]
+    k3 = splatData.shs.shape[1]
+    sizes = [3 * n, 3 * n, 4 * n, n, k3 * n]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=splatData.means.device)
+    parts, o = [], 0
+    for s in sizes:
+        parts.append(flat[o:o + s]); o += s
+    return SplatGrads3D(flat, parts[0].view(n, 3), parts[1].view(n, 3), parts[2].view(n, 4), parts[3].view(n, 1),
+                        parts[4].view(n, k3))
+
+
+class GaussianRenderer3D:               # renderer.jl:205-219
+    def __init__(self, splatData: SplatData3D, imgSize, sh_degree: int, device: int = 0, order: int = B.ORDER_DEPTH_DESC,
+                 t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False):
+        import torch
+        self.splatData = splatData
+        self.splatGrads = initGrads(splatData)
+        W, H = int(imgSize[0]), int(imgSize[1])
+        dev = splatData.means.device
+        self.imageData = torch.zeros((3, H, W), dtype=torch.float32, device=dev)      # CUDA.zeros(imgSize...)
+        self.transmittance = torch.ones((H, W), dtype=torch.float32, device=dev)      # CUDA.ones(imgSize[1:2])
+        self.nGaussians = splatData.means.shape[0]
+        self.sh_degree = sh_degree
+        self.camera: Camera | None = None
+        self.ctx = B.Context(device=device, order=order, t_min=t_min, export_debug=export_debug, profile_stages=profile_stages)
+        # one HIP stream per renderer, shared by the library and by torch's in-place ops on the
+        # renderer's tensors; _begin/_end fence it against the caller's current torch stream
+        self.stream = torch.cuda.Stream(dev)
+        self.ctx.set_stream(self.stream.cuda_stream)
+        self.ctx.set_model_device(self.nGaussians, sh_degree,
+                                  [t.data_ptr() for t in (splatData.means, splatData.scales, splatData.quaternions,
+                                                          splatData.opacities, splatData.shs)])
+        g = self.splatGrads
+        self._grads = B.GsGrads(g.Δmeans.data_ptr(), g.Δscales.data_ptr(), g.Δquaternions.data_ptr(),
+                                g.Δopacities.data_ptr(), g.Δshs.data_ptr())
+
+    def _begin(self):
+        import torch
+        self.stream.wait_stream(torch.cuda.current_stream(self.imageData.device))
+
+    def _end(self):
+        import torch
+        torch.cuda.current_stream(self.imageData.device).wait_stream(self.stream)
+
+    # scratch arrays of the reference struct, fetched on demand (export_debug for the fp32 ones)
+    @property
+    def sortIdxs(self): return self.ctx.get_array(B.ARR_SORT_IDXS)
+    @property
+    def positions(self): return self.ctx.get_array(B.ARR_MU)
+    @property
+    def cov2ds(self): return self.ctx.get_array(B.ARR_COV2D)
+    @property
+    def cov3ds(self): return self.ctx.get_array(B.ARR_COV3D)
+    @property
+    def invCov2ds(self): return self.ctx.get_array(B.ARR_INVCOV)
+    @property
+    def bbs(self): return self.ctx.get_array(B.ARR_BBS)
+
+
+def _to_device_data(scene: dict, device) -> SplatData3D:
+    import torch
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(device).contiguous()
+    n = scene["means"].shape[0]
+    return SplatData3D(means=t(scene["means"]), scales=t(scene["scales"]), shs=t(np.reshape(scene["shs"], (n, -1))),
+                       quaternions=t(scene["quats"]), opacities=t(np.reshape(scene["opacities"], (n, 1))))
+
+
+def initData(nGaussians: int, seed: int = 0) -> dict:
+    """splat.jl:90-104: uniform [0,1) parameters (the reference draws a 9xN `shs`, inconsistent
+    with the 12 floats splatDraw reads; 12 are drawn here = SH degree 1)."""
+    rng = np.random.default_rng(seed)
+    r = lambda *s: rng.random(s, dtype=np.float32)
+    return dict(means=r(nGaussians, 3), quats=r(nGaussians, 4), scales=r(nGaussians, 3), shs=r(nGaussians, 4, 3),
+                opacities=r(nGaussians))
+
+
+def getRenderer(rendererType, imgSize, threads, blocks, source=None, *, device: int = 0, **kw) -> GaussianRenderer3D:
+    """renderer.jl:164-186.  `source`: a PLY path (splat.jl:106-119), an int nGaussians
+    (splat.jl:90-104) or a dict of arrays (means, scales, quats, opacities, shs[n,K,3])."""
+    import torch
+    if isinstance(rendererType, str):
+        rendererType = RendererType[rendererType.lstrip(":")]
+    if rendererType != RendererType.GAUSSIAN_3D:
+        raise NotImplementedError(f"{rendererType}: only GAUSSIAN_3D exists on this path (the reference's 2-D "
+                                  "constructors reference undefined names, renderer.jl:38-82; OPTIMAL_PROJECTION_3D has no body)")
+    if tuple(threads) != (16, 16):
+        raise ValueError("threads must be (16, 16) (tile size of the reference's example, main.jl:9)")
+    W, H = int(imgSize[0]), int(imgSize[1])
+    if blocks is not None and tuple(blocks) != ((W + 15) // 16, (H + 15) // 16):
+        raise ValueError("blocks must be ceil(imgSize/threads)")
+    if not torch.cuda.is_available():
+        raise RuntimeError("gaussiansplat_amd needs a HIP device (no CPU fallback)")
+    if isinstance(source, str):
+        from .ply import load_ply
+        scene = load_ply(source)
+    elif isinstance(source, int):
+        scene = initData(source)
+    elif isinstance(source, dict):
+        scene = source
+    else:
+        raise TypeError("source must be a PLY path, an int or a dict of arrays")
+    shs = np.asarray(scene["shs"])
+    K = shs.reshape(shs.shape[0], -1).shape[1] // 3
+    deg = {1: 0, 4: 1, 9: 2, 16: 3}[K]
+    data = _to_device_data(scene, torch.device("cuda", device))
+    return GaussianRenderer3D(data, (W, H), deg, device=device, **kw)
+
+
+def preprocess(renderer: GaussianRenderer3D, camera: Camera | None = None):
+    """forward.jl:35-111.  The reference hard-codes defaultCamera() (forward.jl:53); a camera may
+    be passed instead.  Returns `tps` lazily (the reference returns the clip-space positions only to
+    hand them to forward())."""
+    cam = camera or renderer.camera or default_camera()
+    renderer.camera = cam
+    H, W = renderer.transmittance.shape
+    T = compute_transform(cam)
+    P = compute_projection(cam, W, H)
+    renderer.ctx.set_camera(T, P, float(np.float32(cam.fx)), float(np.float32(cam.fy)), float(np.float32(cam.near)),
+                            float(np.float32(cam.far)), cam.eye, cam.lookAt, W, H)
+    renderer._begin()
+    renderer.ctx.preprocess()
+    return _LazyTps(renderer)
+
+
+class _LazyTps:
+    def __init__(self, r): self._r = r
+    def numpy(self): return self._r.ctx.get_array(B.ARR_TPS)
+
+
+def compactIdxs(renderer: GaussianRenderer3D, threads=(16, 16), blocks=None):
+    """forward.jl:118-161: builds the per-tile splat lists (tile|depth keys, radix sort, ranges)."""
+    gx, gy = blocks if blocks is not None else (0, 0)
+    renderer.ctx.bin(int(gx), int(gy))
+
+
+def forward(renderer: GaussianRenderer3D, tps=None, threads=(16, 16), blocks=None):
+    """forward.jl:163-198: writes renderer.imageData and renderer.transmittance in place."""
+    renderer.ctx.forward_device(renderer.imageData.data_ptr(), renderer.transmittance.data_ptr())
+    renderer._end()
+
+
+def backward(renderer: GaussianRenderer3D, ΔC):
+    """backward.jl:3-38: ΔC has the shape of imageData; accumulates into renderer.splatGrads."""
+    import torch
+    dC = ΔC if isinstance(ΔC, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(ΔC, np.float32))
+    dC = dC.to(renderer.imageData.device, torch.float32).contiguous()
+    assert dC.shape == renderer.imageData.shape
+    renderer._dC_keepalive = dC
+    renderer._begin()
+    renderer.ctx.backward(dC.data_ptr(), renderer._grads)
+    renderer._end()
+
+
+def resetGrads(renderer_or_grads):
+    """splat.jl:158-173."""
+    import torch
+    if isinstance(renderer_or_grads, GaussianRenderer3D):
+        r = renderer_or_grads
+        r._begin()
+        with torch.cuda.stream(r.stream):
+            r.splatGrads.flat.zero_()
+        r._end()
+    else:
+        renderer_or_grads.flat.zero_()

@@ -1,0 +1,185 @@
+/*
+ * gsplat.h -- C ABI of libgsplat_hip.so, the MI355X (gfx950) differentiable Gaussian-splat
+ * rasterizer that sits behind arhik/GaussianSplat's (empty) backend.jl.
+ *
+ * The reference defines no FFI: src/backend.jl:1 is empty and the de-facto surface is five
+ * Julia functions over a mutable renderer struct.  Each entry point below names the
+ * reference function it replaces (paths relative to /root/reference):
+ *
+ *   gs_create / gs_destroy    getRenderer(...)                    src/renderer.jl:119-149,164-186
+ *   gs_set_model              initData + `|> CuArray` uploads     src/splat.jl:106-119, src/forward.jl:63-69,169-170
+ *   gs_set_camera             defaultCamera/computeTransform/...  src/forward.jl:53-62, src/camera.jl:88-111
+ *   gs_preprocess             preprocess(renderer)                src/forward.jl:35-111
+ *   gs_bin                    compactIdxs(renderer,threads,blocks) src/forward.jl:118-161
+ *   gs_forward                forward(renderer,tps,threads,blocks) src/forward.jl:163-198
+ *   gs_backward               backward(renderer, dC)              src/backward.jl:3-38
+ *   gs_reset_grads            resetGrads(renderer.splatGrads)     src/splat.jl:158-173
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no exceptions; every function returns 0 (GS_OK) or a
+ *     negative gs_status; gs_last_error(ctx) gives the message of the last failure.
+ *   - array layouts are the reference's column-major ones so a Julia `pointer(A)` can be
+ *     passed unpermuted: parameters [component, gaussian] (component fastest), images
+ *     [x, y, channel] (x fastest, channel planes), T and P 4x4 column-major.
+ *   - `mem` says where a caller buffer lives: GS_MEM_HOST (copied over PCIe) or
+ *     GS_MEM_DEVICE (a HIP device pointer on the ctx's device; used in place).
+ *   - the caller owns every buffer it passes; the library owns the ctx scratch (grow-only,
+ *     no per-frame allocation once sizes are stable).
+ *   - one ctx = one GPU = one stream; a ctx is not thread-safe, different ctxs are.
+ *   - all work is enqueued on the ctx stream; functions that return data to HOST buffers
+ *     synchronise that stream before returning, device-buffer variants do not.
+ *   - there is NO CPU fallback: without a HIP device gs_create fails with GS_ERR_NO_DEVICE.
+ */
+#ifndef GSPLAT_H
+#define GSPLAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+typedef enum {
+    GS_OK = 0,
+    GS_ERR_INVALID = -1,      /* bad argument / call order                                  */
+    GS_ERR_NO_DEVICE = -2,    /* no usable HIP device                                       */
+    GS_ERR_HIP = -3,          /* a HIP runtime call failed (see gs_last_error)              */
+    GS_ERR_OOM = -4,          /* device allocation failed                                   */
+    GS_ERR_UNSUPPORTED = -5   /* e.g. tile size != 16, sh_degree > 3                        */
+} gs_status;
+
+typedef enum { GS_MEM_HOST = 0, GS_MEM_DEVICE = 1 } gs_mem;
+
+/* Order of every per-tile splat list (what the radix sort realises).
+ *   INDEX       literal reference behaviour: compact.jl:3-21 places a gaussian at slot
+ *               inclusive-scan(hits) over the GAUSSIAN INDEX axis, so sortIdxs has no effect.
+ *   DEPTH_DESC  the order forward.jl:103 computes (sortperm(-tps[3,:]), far -> near) and the
+ *               TODO at forward.jl:123-131 intends; ties by gaussian index (stable).
+ *   DEPTH_ASC   near -> far (extension).                                                      */
+typedef enum { GS_ORDER_INDEX = 0, GS_ORDER_DEPTH_DESC = 1, GS_ORDER_DEPTH_ASC = 2 } gs_order;
+
+typedef struct {
+    int32_t struct_size;      /* = sizeof(gs_config); ABI guard                              */
+    int32_t tile_size;        /* threads=(16,16) of examples/main.jl:9; only 16 is supported */
+    int32_t order;            /* gs_order; default GS_ORDER_DEPTH_DESC                       */
+    float   t_min;            /* transmittance early-out: a pixel stops taking splats once
+                                 its T < t_min.  0 = literal reference (splat.jl:224-261 has
+                                 no early-out).  Default 1e-5 (pixel error <= t_min*max|rgb|) */
+    int32_t deterministic;    /* 1: per-gaussian gradients reduced in a fixed order (bitwise
+                                 reproducible); 0: float atomics                              */
+    int32_t export_debug;     /* 1: gs_preprocess also materialises the reference's scratch
+                                 arrays (ts, tps, mu', cov3ds, cov2ds, invCov2ds, bbs) for
+                                 gs_get_array; costs 124 extra bytes/gaussian of HBM writes   */
+    int32_t profile_stages;   /* 1: record hipEvents around every stage (gs_get_stage_times) */
+    int32_t reserved[9];
+} gs_config;
+
+typedef struct gs_ctx gs_ctx;
+
+/* Fill cfg with the defaults above. */
+void gs_default_config(gs_config *cfg);
+
+int gs_abi_version(void);
+
+/* getRenderer: create a renderer context on HIP device `device`. */
+int gs_create(gs_ctx **out, int device, const gs_config *cfg);
+int gs_destroy(gs_ctx *ctx);
+const char *gs_last_error(const gs_ctx *ctx);   /* ctx may be NULL: last gs_create error */
+
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream. */
+int gs_set_stream(gs_ctx *ctx, void *hip_stream);
+int gs_synchronize(gs_ctx *ctx);
+
+/* Model (SplatData3D, splat.jl:36-43).  means 3xN, scales 3xN (log), quats 4xN (w,x,y,z, not
+ * normalised by the kernels), opacities 1xN (logit), shs (3*K)xN with K=(sh_degree+1)^2 and
+ * element [c + 3k] = channel c of coefficient k (splat.jl:117 for degree 1).
+ * GS_MEM_HOST: copied once and kept resident.  GS_MEM_DEVICE: borrowed (the caller keeps them
+ * alive and may update them in place between frames, e.g. an optimiser step). */
+int gs_set_model(gs_ctx *ctx, int64_t n, int sh_degree,
+                 const float *means, const float *scales, const float *quats,
+                 const float *opacities, const float *shs, int mem);
+
+/* Camera + image size (forward.jl:41,53-62).  T, P: 16 floats each, column-major. */
+int gs_set_camera(gs_ctx *ctx, const float T[16], const float P[16], float fx, float fy,
+                  float near_, float far_, const float eye[3], const float lookAt[3],
+                  int32_t W, int32_t H);
+
+/* preprocess(renderer): projection, 2-D covariance + inverse, bounding box, SH colour,
+ * sigmoid, depth key, tile rectangle. */
+int gs_preprocess(gs_ctx *ctx);
+
+/* compactIdxs(renderer, threads, blocks): per-tile splat lists = tile|depth keys, stable
+ * radix sort, tile ranges.  gx, gy = the reference's `blocks`; pass 0,0 for ceil(W/16),
+ * ceil(H/16). */
+int gs_bin(gs_ctx *ctx, int32_t gx, int32_t gy);
+
+/* forward(renderer, tps, threads, blocks): per-tile alpha composite.  image: W*H*3 floats
+ * (planar), transmittance: W*H floats.  Either may be NULL. */
+int gs_forward(gs_ctx *ctx, float *image, float *transmittance, int mem);
+
+typedef struct {              /* SplatGrads3D, splat.jl:45-52; any pointer may be NULL       */
+    float *d_means;           /* 3 x N                                                        */
+    float *d_scales;          /* 3 x N                                                        */
+    float *d_quats;           /* 4 x N                                                        */
+    float *d_opacities;       /* 1 x N                                                        */
+    float *d_shs;             /* 3K x N                                                       */
+} gs_grads;
+
+/* backward(renderer, dC): dC is W*H*3 (same layout as the image).  Gradients ACCUMULATE (+=)
+ * into `grads` (DEVICE pointers), exactly as the reference's grads persist until resetGrads.
+ * Requires gs_forward on the same frame. */
+int gs_backward(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads);
+
+/* resetGrads: zero the arrays of `grads` (DEVICE pointers) on the ctx stream. */
+int gs_reset_grads(gs_ctx *ctx, const gs_grads *grads);
+
+/* ---- introspection (parity tests, profiling) ------------------------------------------- */
+
+typedef enum {
+    GS_ARR_TS = 0,            /* 4 x N  f32   view-space position            (export_debug) */
+    GS_ARR_TPS = 1,           /* 4 x N  f32   clip-space position            (export_debug) */
+    GS_ARR_MU = 2,            /* 2 x N  f32   renderer.positions             (export_debug) */
+    GS_ARR_COV3D = 3,         /* 9 x N  f32   renderer.cov3ds                (export_debug) */
+    GS_ARR_COV2D = 4,         /* 4 x N  f32   renderer.cov2ds                (export_debug) */
+    GS_ARR_INVCOV = 5,        /* 4 x N  f32   renderer.invCov2ds             (export_debug) */
+    GS_ARR_BBS = 6,           /* 4 x N  f32   renderer.bbs [xmin ymin xmax ymax] (export_debug) */
+    GS_ARR_RGB = 7,           /* 3 x N  f32   sh2color result                                */
+    GS_ARR_SIG = 8,           /* 1 x N  f32   cusigmoid(opacity)                             */
+    GS_ARR_DEPTH_KEY = 9,     /* 1 x N  u32   radix key of clip z for the ctx order          */
+    GS_ARR_TILE_RECT = 10,    /* 4 x N  u16   x0 x1 y0 y1, 1-based inclusive; x0=0: no tile  */
+    GS_ARR_SORT_IDXS = 11,    /* 1 x N  u32   renderer.sortIdxs (0-based)                    */
+    GS_ARR_TILE_RANGES = 12,  /* 2 x gx*gy u32 [start,end) into the sorted instance list     */
+    GS_ARR_SORTED_IDS = 13,   /* 1 x I  u32   gaussian id per sorted instance (0-based)      */
+    GS_ARR_SORTED_KEYS = 14,  /* 1 x I  u64   tile<<32 | depth key (or | id in INDEX order)  */
+    GS_ARR_GRAD2D = 15        /* 10 x N f32   d{rgb3,sig,mu2,inv4} after gs_backward          */
+} gs_array;
+
+int64_t gs_num_gaussians(const gs_ctx *ctx);
+int64_t gs_num_instances(const gs_ctx *ctx);      /* I of the last gs_bin */
+
+/* Copy an internal array to a HOST buffer of `bytes` bytes (synchronises). */
+int gs_get_array(gs_ctx *ctx, int which, void *host_dst, int64_t bytes);
+
+typedef enum {
+    GS_STAGE_PREPROCESS = 0, GS_STAGE_DEPTH_SORT, GS_STAGE_COUNT_SCAN, GS_STAGE_EMIT,
+    GS_STAGE_TILE_SORT, GS_STAGE_RANGES, GS_STAGE_COMPOSITE_FWD, GS_STAGE_COMPOSITE_BWD,
+    GS_STAGE_PREPROCESS_BWD, GS_STAGE_COUNT
+} gs_stage;
+
+/* Milliseconds of the last execution of each stage (profile_stages=1); synchronises. */
+int gs_get_stage_times(gs_ctx *ctx, float ms[GS_STAGE_COUNT]);
+
+/* Accumulated hipEvent time (ms) and launch count per stage since the last reset
+ * (profile_stages=1); synchronises.  reset != 0 clears the accumulators afterwards. */
+int gs_get_stage_stats(gs_ctx *ctx, double sum_ms[GS_STAGE_COUNT], int64_t count[GS_STAGE_COUNT], int reset);
+
+/* Work counters of the last frame: list entries actually walked by the composite kernels
+ * (== gs_num_instances when t_min == 0; fewer with the transmittance early-out). */
+int gs_get_work_counters(gs_ctx *ctx, int64_t *walked_fwd, int64_t *walked_bwd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_H */

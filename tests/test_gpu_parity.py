@@ -1,0 +1,118 @@
+"""HIP path vs CPU oracle through the C ABI (run on the MI355X box: pytest -m gpu).
+
+Bars (BASELINE north_star): tile rectangles, depth keys, sort order, tile ranges and sorted
+ids BIT-EXACT; pixels |d| <= 1e-4 + 1e-4|x|; gradients rel-L2 <= 1e-3 against the fp64 adjoint.
+"""
+import numpy as np
+import pytest
+
+from common import hip_context, rel_l2, scene_and_cameras
+
+pytestmark = pytest.mark.gpu
+
+PIX_ATOL, PIX_RTOL = 1e-4, 1e-4
+GRAD_REL_L2 = 1e-3
+
+# (n, W, H, sh_degree, seed): C1 of BASELINE.json, ragged sizes (n % 32 != 0, H % 16 != 0), SH degrees
+CASES = [
+    (10_000, 256, 256, 0, 1235),
+    (3_001, 200, 120, 1, 7),
+    (2_500, 136, 104, 2, 8),
+    (4_097, 176, 90, 3, 9),
+]
+
+
+def _oracle_rects(O, bbs, gx, gy):
+    import ctypes as C
+    L = O.lib()
+    out = np.zeros((bbs.shape[0], 4), np.uint16)
+    rc = (C.c_int32 * 4)()
+    for g in range(bbs.shape[0]):
+        bb = np.ascontiguousarray(bbs[g], np.float32)
+        if L.gso_tile_rect(bb.ctypes.data_as(C.POINTER(C.c_float)), 16, gx, gy, rc):
+            out[g] = (rc[0], rc[1], rc[2], rc[3])
+    return out
+
+
+@pytest.mark.parametrize("n,W,H,deg,seed", CASES)
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_preprocess_and_binning_bit_exact(oracle, n, W, H, deg, seed, order):
+    from gaussiansplat_amd import backend as B
+    O = oracle
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, export_debug=True, t_min=0.0)
+    ctx.preprocess()
+    for name, which in (("ts", B.ARR_TS), ("tps", B.ARR_TPS), ("mu", B.ARR_MU), ("cov3d", B.ARR_COV3D), ("cov2d", B.ARR_COV2D),
+                        ("invcov", B.ARR_INVCOV), ("bbs", B.ARR_BBS), ("rgb", B.ARR_RGB), ("sig", B.ARR_SIG)):
+        got = ctx.get_array(which)
+        assert np.array_equal(got, pre[name].reshape(got.shape), equal_nan=True), f"{name} not bit-exact"
+    # depth keys + tile rectangles
+    import ctypes as C
+    keys = np.array([O.lib().gso_depth_key(C.c_float(z), order) for z in pre["tps"][:, 2]], np.uint32)
+    assert np.array_equal(ctx.get_array(B.ARR_DEPTH_KEY), keys)
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RECT), _oracle_rects(O, pre["bbs"], gx, gy))
+    # lists
+    ctx.bin()
+    ranges, ids, okeys = O.bin_lists(pre["bbs"], pre["tps"], order, 16, gx, gy)
+    assert ctx.num_instances == len(ids)
+    assert np.array_equal(ctx.get_array(B.ARR_SORT_IDXS), O.depth_order(pre["tps"], order))
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ranges)
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ids)
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), okeys)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,W,H,deg,seed", CASES)
+@pytest.mark.parametrize("order,t_min", [(1, 0.0), (0, 0.0), (2, 0.0), (1, 1e-5)])
+def test_forward_pixels(oracle, n, W, H, deg, seed, order, t_min):
+    O = oracle
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=order, t_min=t_min)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=t_min)
+    ctx.preprocess(); ctx.bin()
+    img, tr = ctx.forward_host()
+    assert np.all(np.abs(img - ref["image"]) <= PIX_ATOL + PIX_RTOL * np.abs(ref["image"])), np.abs(img - ref["image"]).max()
+    assert np.all(np.abs(tr - ref["trans"]) <= PIX_ATOL + PIX_RTOL * np.abs(ref["trans"]))
+    if t_min > 0:   # the early-out result must also be within the stated tolerance of the LITERAL reference
+        lit = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=order, t_min=0.0)
+        assert np.all(np.abs(img - lit["image"]) <= PIX_ATOL + PIX_RTOL * np.abs(lit["image"]))
+        assert np.all(np.abs(tr - lit["trans"]) <= PIX_ATOL + PIX_RTOL * np.abs(lit["trans"]))
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,W,H,deg,seed", CASES)
+@pytest.mark.parametrize("order,t_min", [(1, 0.0), (0, 0.0), (1, 1e-5)])
+def test_backward_gradients(oracle, n, W, H, deg, seed, order, t_min):
+    import torch
+    from gaussiansplat_amd import backend as B
+    from gaussiansplat_amd import synthetic
+    O = oracle
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=order, t_min=t_min)
+    dC = synthetic.make_dC(W, H, seed)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC,
+                      t_min=t_min)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=t_min)
+    ctx.preprocess(); ctx.bin(); ctx.forward_host()
+    K3 = 3 * (deg + 1) ** 2
+    flat = torch.zeros(n * (11 + K3), dtype=torch.float32, device="cuda")
+    o = 0
+    views = {}
+    for name, w in (("means", 3), ("scales", 3), ("quats", 4), ("opacities", 1), ("shs", K3)):
+        views[name] = flat[o:o + n * w]; o += n * w
+    grads = B.GsGrads(*(views[k].data_ptr() for k in ("means", "scales", "quats", "opacities", "shs")))
+    torch.cuda.synchronize()
+    for rep in range(2):                       # gradients ACCUMULATE (reference contract): 2 calls = 2x
+        ctx.backward(dC, grads)
+    ctx.synchronize()
+    g2d = ctx.get_array(B.ARR_GRAD2D)
+    assert rel_l2(g2d, gref["g2d"]) <= GRAD_REL_L2, ("g2d", rel_l2(g2d, gref["g2d"]))
+    for name in views:
+        got = views[name].cpu().numpy().astype(np.float64) / 2.0
+        want = gref[name].reshape(-1)
+        assert rel_l2(got, want) <= GRAD_REL_L2, (name, rel_l2(got, want))
+    ctx.reset_grads(grads); ctx.synchronize()
+    assert float(flat.abs().max()) == 0.0
+    ctx.close()
