@@ -490,9 +490,15 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
             }
             return GS_OK;
         }
-        case GS_ARR_GRAD2D:
+        case GS_ARR_GRAD2D: {
             if (!c->did_bwd) return fail(c, GS_ERR_INVALID, "gs_get_array: gs_backward first");
-            src = c->g2d.p; need = sizeof(float) * 10 * n; break;
+            if ((size_t)bytes != sizeof(float) * 10 * n) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
+            if (n) HIPCHK(c, hipMemcpyAsync(dst, c->g2d.p, sizeof(float) * 10 * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            float *o = static_cast<float *>(dst);
+            for (size_t g = 0; g < n; ++g) o[10 * g + 8] = o[10 * g + 7];   // d inv[2] == d inv[1] (stored once)
+            return GS_OK;
+        }
         default: return fail(c, GS_ERR_INVALID, "gs_get_array: unknown array");
     }
     if ((size_t)bytes != need) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");

@@ -121,24 +121,61 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(GsCompositeArgs a) {
     }
 }
 
-// ---------------------------------------------------------------- wave64 sum -> lane 63 (DPP)
+// ---------------------------------------------------------------- wave64 reductions
+// Nine per-splat sums are needed.  Reducing them one by one costs 6 DPP adds each; instead
+// eight of them go through a reduce-scatter butterfly built on gfx950's lane-swap
+// instructions: v_permlane32_swap pairs two registers (one add sums BOTH across the wave
+// halves, leaving value A in lanes 0-31 and B in lanes 32-63), v_permlane16_swap does the
+// same across 16-lane rows, and four row_shr DPP adds finish inside the rows.  Result: lane
+// 15 of row r holds the wave total of value ORDER[r] -- 20 VALU ops for 8 values.
+typedef unsigned int gs_u2 __attribute__((ext_vector_type(2)));
+
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
     const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
     return v + __int_as_float(t);
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
     v = dpp_add<0x111, 0xF, 0xF>(v);      // row_shr:1
     v = dpp_add<0x112, 0xF, 0xF>(v);      // row_shr:2
     v = dpp_add<0x114, 0xF, 0xF>(v);      // row_shr:4
     v = dpp_add<0x118, 0xF, 0xF>(v);      // row_shr:8   -> lane 15 of each row = row sum
+    return v;
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = row_sum_to_lane15(v);
     v = dpp_add<0x142, 0xA, 0xF>(v);      // row_bcast:15 into rows 1,3
     v = dpp_add<0x143, 0xC, 0xF>(v);      // row_bcast:31 into rows 2,3 -> lane 63 = total
     return v;
 }
+// lanes 0-31: a(l)+a(l+32) ; lanes 32-63: b(l-32)+b(l)
+__device__ __forceinline__ float fold32(float a, float b) {
+    const gs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// rows 0,2: a.row(r)+a.row(r+1) ; rows 1,3: b.row(r-1)+b.row(r)
+__device__ __forceinline__ float fold16(float a, float b) {
+    const gs_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// -> lane 15 of rows 0..3 = totals of (v0, v2, v1, v3) in `lo`, of (v4, v6, v5, v7) in `hi`
+__device__ __forceinline__ void reduce8(const float (&v)[8], float &lo, float &hi) {
+    const float b0 = fold32(v[0], v[1]), b1 = fold32(v[2], v[3]), b2 = fold32(v[4], v[5]), b3 = fold32(v[6], v[7]);
+    lo = row_sum_to_lane15(fold16(b0, b1));
+    hi = row_sum_to_lane15(fold16(b2, b3));
+}
 
-__device__ __forceinline__ float bcast63(float v) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+// g2d row of a gaussian: [dr dg db dsig dmx dmy d00 d01 (d10 = d01, filled by the reader) d11]
+// lane 15 of row r adds lo -> LO_COMP[r] ; lane 14 of row r adds hi -> HI_COMP[r] ; lane 61 adds the 9th
+__device__ __forceinline__ int out_component(int lane) {
+    const int row = lane >> 4, pos = lane & 15;
+    // lo rows hold (v0,v2,v1,v3) = (dr, db, dg, dsig) ; hi rows hold (v4,v6,v5,v7) = (dmx, d00, dmy, d01)
+    const int lo_comp = row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
+    const int hi_comp = row == 0 ? 4 : row == 1 ? 6 : row == 2 ? 5 : 7;
+    if (pos == 15) return lo_comp;
+    if (pos == 14) return hi_comp;
+    if (lane == 61) return 9;
+    return -1;
 }
 
 template <bool EARLY>
@@ -154,14 +191,17 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(GsCompositeArgs a) {
     const float fx = (float)px;
     const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
     const size_t plane = (size_t)a.W * a.H;
+    const int ocomp = out_component(lane);
+    const bool take_hi = (lane & 15) == 14, take_9 = lane == 61;
 
-    float dCr[4], dCg[4], dCb[4], T[4], S[4];
+    float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
     uint32_t walked = 0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int py = py0 + 4 * p;
         const bool in = (px <= a.W && py <= a.H);
         const size_t o = in ? (size_t)(px - 1) + (size_t)a.W * (py - 1) : 0;
+        fy[p] = (float)py;
         dCr[p] = in ? a.dC[o] : 0.0f;
         dCg[p] = in ? a.dC[o + plane] : 0.0f;
         dCb[p] = in ? a.dC[o + 2 * plane] : 0.0f;
@@ -191,18 +231,23 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(GsCompositeArgs a) {
             const float A0 = (NEG_HALF_LOG2E * P.i0) * dX * dX;
             const float B0 = (NEG_HALF_LOG2E * (P.i1 + P.i2)) * dX;
             const float Cq = NEG_HALF_LOG2E * P.i3;
-            float ar = 0.0f, ag = 0.0f, ab = 0.0f, asig = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+            float e[4], dY[4];
             bool any = false;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int py = py0 + 4 * p;
-                const float dY = (float)py - P.my;
-                float e = fast_exp2(fmaf(dY, fmaf(Cq, dY, B0), A0));
+                dY[p] = fy[p] - P.my;
+                const float ex = fast_exp2(fmaf(dY[p], fmaf(Cq, dY[p], B0), A0));
                 bool hit = hitx && (py >= ymin) && (py <= ymax);
                 if (EARLY) hit = hit && !(T[p] < a.t_min);
                 any = any || hit;
-                e = hit ? e : 0.0f;
-                const float alpha = P.sig * e;
+                e[p] = hit ? ex : 0.0f;
+            }
+            if (__ballot(any) == 0ull) continue;                        // nobody in the tile touched it
+            float ar = 0.0f, ag = 0.0f, ab = 0.0f, asig = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float alpha = P.sig * e[p];
                 const float w = alpha * T[p];
                 const float cdot = fmaf(P.r, dCr[p], fmaf(P.g, dCg[p], P.b * dCb[p]));
                 ar = fmaf(w, dCr[p], ar);
@@ -212,35 +257,31 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(GsCompositeArgs a) {
                 const float om = 1.0f - alpha;
                 const float inv = om > 0.0f ? fast_rcp(om) : 0.0f;
                 const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));   // dL/dalpha
-                asig = fmaf(e, dalpha, asig);                           // alpha = sig * e
+                asig = fmaf(e[p], dalpha, asig);                        // alpha = sig * e
                 const float dd = -(alpha * dalpha);                     // dL/ddist
                 q0 += dd;
-                q1 = fmaf(dd, dY, q1);
-                q2 = fmaf(dd * dY, dY, q2);
+                q1 = fmaf(dd, dY[p], q1);
+                q2 = fmaf(dd * dY[p], dY[p], q2);
                 T[p] = T[p] - w;
             }
-            if (__ballot(any) == 0ull) continue;                        // nobody in the tile touched it
-            // per-lane moments (dX differs per lane), then one wave reduction per quantity
-            const float qx = dX * q0, qxx = dX * qx, qxy = dX * q1;
-            const float Rr = wave_sum_to_lane63(ar), Rg = wave_sum_to_lane63(ag), Rb = wave_sum_to_lane63(ab);
-            const float Rs = wave_sum_to_lane63(asig);
-            const float Rx = wave_sum_to_lane63(qx), Ry = wave_sum_to_lane63(q1);
-            const float Rxx = wave_sum_to_lane63(qxx), Rxy = wave_sum_to_lane63(qxy), Ryy = wave_sum_to_lane63(q2);
-            // totals sit in lane 63: broadcast, finish the 10 outputs, and issue ONE atomic
-            // wave-instruction whose lanes 0..9 cover the gaussian's contiguous 40-byte row
-            const float tr = bcast63(Rr), tg = bcast63(Rg), tb = bcast63(Rb), tsg = bcast63(Rs);
-            const float tx = bcast63(Rx), ty = bcast63(Ry), txx = bcast63(Rxx), txy = bcast63(Rxy), tyy = bcast63(Ryy);
+            // per-lane outputs (dX differs per lane; everything below is linear in the partials)
             const float mc = 0.5f * (P.i1 + P.i2);
-            float v = tr;
-            v = lane == 1 ? tg : v;
-            v = lane == 2 ? tb : v;
-            v = lane == 3 ? tsg : v;
-            v = lane == 4 ? -(P.i0 * tx + mc * ty) : v;                 // d mu_x  (delta = pixel - mu)
-            v = lane == 5 ? -(mc * tx + P.i3 * ty) : v;                 // d mu_y
-            v = lane == 6 ? 0.5f * txx : v;                             // d inv[0]
-            v = (lane == 7 || lane == 8) ? 0.5f * txy : v;              // d inv[1], d inv[2]
-            v = lane == 9 ? 0.5f * tyy : v;                             // d inv[3]
-            if (lane < 10) atomicAdd(a.g2d + (size_t)sid[k] * 10 + lane, v);
+            const float qx = dX * q0;
+            float v[8];
+            v[0] = ar; v[1] = ag; v[2] = ab; v[3] = asig;
+            v[4] = -fmaf(P.i0, qx, mc * q1);                            // d mu_x (delta = pixel - mu)
+            v[5] = -fmaf(mc, qx, P.i3 * q1);                            // d mu_y
+            v[6] = 0.5f * dX * qx;                                      // d inv[0]
+            v[7] = 0.5f * dX * q1;                                      // d inv[1] = d inv[2]
+            float lo, hi;
+            reduce8(v, lo, hi);
+            const float t9 = wave_sum_to_lane63(0.5f * q2);             // d inv[3]
+            // hi's totals move one lane down (lane 14), the ninth two lanes down (lane 61): one
+            // atomic wave-instruction then covers the gaussian's 40-byte row with 9 active lanes
+            const float hi_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x101, 0xF, 0xF, true));  // row_shl:1
+            const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));  // row_shl:2
+            const float outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
+            if (ocomp >= 0) atomicAdd(a.g2d + (size_t)sid[k] * 10 + ocomp, outv);
         }
         walked += (uint32_t)cnt;
         if (EARLY) {

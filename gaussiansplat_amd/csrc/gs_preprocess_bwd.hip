@@ -11,6 +11,9 @@
 //
 // One thread per gaussian, no atomics (each thread owns its rows).  HBM-bound: reads
 // 4*(11+3K)+40 B, writes 4*(11+3K) B per gaussian (read-modify-write for the += contract).
+// The SH rows (3K floats = 192 B at degree 3, thread-strided in HBM) are staged through an
+// LDS tile [256][3K+1]: coalesced block loads, conflict-free per-thread rows (odd stride),
+// gradients written back into the same tile and added to d_shs with coalesced accesses.
 #include "gs_common.h"
 
 #define SH_C0 0.28209479177387814f
@@ -21,14 +24,22 @@ __constant__ float bC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
                              -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
 template <int DEG>
-__global__ __launch_bounds__(256) void gs_preprocess_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
+__global__ __launch_bounds__(256, 3) void gs_preprocess_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
     constexpr int K = (DEG + 1) * (DEG + 1);
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n) return;
+    constexpr int ROW = 3 * K + 1;
+    extern __shared__ __attribute__((aligned(16))) float tile[];       // [256][ROW]
+    const int64_t gb = (int64_t)blockIdx.x * blockDim.x;
+    const int nb = (int)min((int64_t)blockDim.x, a.n - gb);
+    for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x)
+        tile[(idx / (3 * K)) * ROW + idx % (3 * K)] = a.shs[gb * 3 * K + idx];
+    __syncthreads();
+    const int64_t g = gb + threadIdx.x;
+    if (g < a.n) {
     const float *g2 = a.g2d + 10 * g;
     const float grgb[3] = {g2[0], g2[1], g2[2]};
     const float gsig = g2[3], gmx = g2[4], gmy = g2[5];
-    const float G[2][2] = {{g2[6], g2[8]}, {g2[7], g2[9]}};            // G[r][c] = dL/dM[r][c], column-major storage
+    // G[r][c] = dL/dM[r][c]; the composite kernel stores the symmetric off-diagonal once (slot 7)
+    const float G[2][2] = {{g2[6], g2[7]}, {g2[7], g2[9]}};
     const float *T = cam.T, *P = cam.P;
 
     // ---- forward recompute (same formulas as gs_preprocess.hip)
@@ -38,6 +49,55 @@ __global__ __launch_bounds__(256) void gs_preprocess_bwd_kernel(GsPreprocessBwdA
     for (int i = 0; i < 4; ++i) t[i] = T[i] * m1 + T[i + 4] * m2 + T[i + 8] * m3 + T[i + 12];
 #pragma unroll
     for (int i = 0; i < 4; ++i) p[i] = P[i] * t[0] + P[i + 4] * t[1] + P[i + 8] * t[2] + P[i + 12] * t[3];
+    float dt[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0};
+    // ---- rgb(sh, dir(p))
+    const float v0 = p[0] - (cam.lookAt[0] - cam.eye[0]);
+    const float v1 = p[1] - (cam.lookAt[1] - cam.eye[1]);
+    const float v2 = p[2] - (cam.lookAt[2] - cam.eye[2]);
+    const float inrm = rsqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+    const float dxn = v0 * inrm, dyn = v1 * inrm, dzn = v2 * inrm;
+    // basis values (kept), then cs[k] = sum_c grgb[c]*sh[c,k]; the derivative of every basis
+    // polynomial is applied inline (no per-coefficient gradient table: keeps VGPRs low)
+    const float X = dxn, Y = dyn, Z = dzn;
+    float bs[K], cs[K];
+    bs[0] = SH_C0;
+    if constexpr (DEG >= 1) { bs[1] = -Y * SH_C1; bs[2] = Z * SH_C1; bs[3] = -X * SH_C1; }
+    if constexpr (DEG >= 2) {
+        const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+        bs[4] = bC2[0] * xy; bs[5] = bC2[1] * yz; bs[6] = bC2[2] * (2 * zz - xx - yy); bs[7] = bC2[3] * xz; bs[8] = bC2[4] * (xx - yy);
+        if constexpr (DEG >= 3) {
+            bs[9] = bC3[0] * Y * (3 * xx - yy); bs[10] = bC3[1] * xy * Z; bs[11] = bC3[2] * Y * (4 * zz - xx - yy);
+            bs[12] = bC3[3] * Z * (2 * zz - 3 * xx - 3 * yy); bs[13] = bC3[4] * X * (4 * zz - xx - yy);
+            bs[14] = bC3[5] * Z * (xx - yy); bs[15] = bC3[6] * X * (xx - 3 * yy);
+        }
+    }
+    float *sh = tile + threadIdx.x * ROW;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        cs[k] = grgb[0] * sh[3 * k] + grgb[1] * sh[3 * k + 1] + grgb[2] * sh[3 * k + 2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sh[c + 3 * k] = bs[k] * grgb[c];   // the tile now carries d L / d sh
+    }
+    float ddir[3] = {0.0f, 0.0f, 0.0f};
+    if constexpr (DEG >= 1) { ddir[0] += -SH_C1 * cs[3]; ddir[1] += -SH_C1 * cs[1]; ddir[2] += SH_C1 * cs[2]; }
+    if constexpr (DEG >= 2) {
+        ddir[0] += bC2[0] * Y * cs[4] - 2 * bC2[2] * X * cs[6] + bC2[3] * Z * cs[7] + 2 * bC2[4] * X * cs[8];
+        ddir[1] += bC2[0] * X * cs[4] + bC2[1] * Z * cs[5] - 2 * bC2[2] * Y * cs[6] - 2 * bC2[4] * Y * cs[8];
+        ddir[2] += bC2[1] * Y * cs[5] + 4 * bC2[2] * Z * cs[6] + bC2[3] * X * cs[7];
+    }
+    if constexpr (DEG >= 3) {
+        const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+        ddir[0] += 6 * bC3[0] * xy * cs[9] + bC3[1] * yz * cs[10] - 2 * bC3[2] * xy * cs[11] - 6 * bC3[3] * xz * cs[12]
+                   + bC3[4] * (4 * zz - 3 * xx - yy) * cs[13] + 2 * bC3[5] * xz * cs[14] + bC3[6] * (3 * xx - 3 * yy) * cs[15];
+        ddir[1] += bC3[0] * (3 * xx - 3 * yy) * cs[9] + bC3[1] * xz * cs[10] + bC3[2] * (4 * zz - xx - 3 * yy) * cs[11]
+                   - 6 * bC3[3] * yz * cs[12] - 2 * bC3[4] * xy * cs[13] - 2 * bC3[5] * yz * cs[14] - 6 * bC3[6] * xy * cs[15];
+        ddir[2] += bC3[1] * xy * cs[10] + 8 * bC3[2] * yz * cs[11] + bC3[3] * (6 * zz - 3 * xx - 3 * yy) * cs[12]
+                   + 8 * bC3[4] * xz * cs[13] + bC3[5] * (xx - yy) * cs[14];
+    }
+    const float dd = dxn * ddir[0] + dyn * ddir[1] + dzn * ddir[2];
+    dp[0] += (ddir[0] - dxn * dd) * inrm;
+    dp[1] += (ddir[1] - dyn * dd) * inrm;
+    dp[2] += (ddir[2] - dzn * dd) * inrm;
     const float tx = t[0], ty = t[1], tz = t[2], fx = cam.fx, fy = cam.fy;
     const float itz = 1.0f / tz, itz2 = itz * itz;
     const float J[2][3] = {{fx * itz, 0.0f, -fx * tx * itz2}, {0.0f, fy * itz, -fy * ty * itz2}};
@@ -127,7 +187,6 @@ __global__ __launch_bounds__(256) void gs_preprocess_bwd_kernel(GsPreprocessBwdA
     dy += 2 * z * dR[1][2]; dz += 2 * y * dR[1][2]; dw += -2 * x * dR[1][2]; dx += -2 * w * dR[1][2];
     dx += -4 * x * dR[2][2]; dy += -4 * y * dR[2][2];
     // ---- J(t)
-    float dt[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0};
     const float itz3 = itz2 * itz;
     dt[0] += dJ[0][2] * (-fx * itz2);
     dt[1] += dJ[1][2] * (-fy * itz2);
@@ -138,56 +197,6 @@ __global__ __launch_bounds__(256) void gs_preprocess_bwd_kernel(GsPreprocessBwdA
     dp[0] += gmx * 0.5f * Wd * ip3;
     dp[1] += gmy * 0.5f * Hd * ip3;
     dp[3] += -(gmx * 0.5f * Wd * p[0] + gmy * 0.5f * Hd * p[1]) * ip3 * ip3;
-    // ---- rgb(sh, dir(p))
-    const float v0 = p[0] - (cam.lookAt[0] - cam.eye[0]);
-    const float v1 = p[1] - (cam.lookAt[1] - cam.eye[1]);
-    const float v2 = p[2] - (cam.lookAt[2] - cam.eye[2]);
-    const float inrm = rsqrtf(v0 * v0 + v1 * v1 + v2 * v2);
-    const float dxn = v0 * inrm, dyn = v1 * inrm, dzn = v2 * inrm;
-    float bs[K], db[K][3];
-#pragma unroll
-    for (int k = 0; k < K; ++k) db[k][0] = db[k][1] = db[k][2] = 0.0f;
-    bs[0] = SH_C0;
-    if constexpr (DEG >= 1) {
-        bs[1] = -dyn * SH_C1; db[1][1] = -SH_C1;
-        bs[2] = dzn * SH_C1;  db[2][2] = SH_C1;
-        bs[3] = -dxn * SH_C1; db[3][0] = -SH_C1;
-    }
-    if constexpr (DEG >= 2) {
-        const float X = dxn, Y = dyn, Z = dzn;
-        const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
-        bs[4] = bC2[0] * xy;                 db[4][0] = bC2[0] * Y;  db[4][1] = bC2[0] * X;
-        bs[5] = bC2[1] * yz;                 db[5][1] = bC2[1] * Z;  db[5][2] = bC2[1] * Y;
-        bs[6] = bC2[2] * (2 * zz - xx - yy); db[6][0] = -2 * bC2[2] * X; db[6][1] = -2 * bC2[2] * Y; db[6][2] = 4 * bC2[2] * Z;
-        bs[7] = bC2[3] * xz;                 db[7][0] = bC2[3] * Z;  db[7][2] = bC2[3] * X;
-        bs[8] = bC2[4] * (xx - yy);          db[8][0] = 2 * bC2[4] * X; db[8][1] = -2 * bC2[4] * Y;
-        if constexpr (DEG >= 3) {
-            bs[9]  = bC3[0] * Y * (3 * xx - yy);           db[9][0] = 6 * bC3[0] * xy;  db[9][1] = bC3[0] * (3 * xx - 3 * yy);
-            bs[10] = bC3[1] * xy * Z;                      db[10][0] = bC3[1] * yz; db[10][1] = bC3[1] * xz; db[10][2] = bC3[1] * xy;
-            bs[11] = bC3[2] * Y * (4 * zz - xx - yy);      db[11][0] = -2 * bC3[2] * xy; db[11][1] = bC3[2] * (4 * zz - xx - 3 * yy); db[11][2] = 8 * bC3[2] * yz;
-            bs[12] = bC3[3] * Z * (2 * zz - 3 * xx - 3 * yy); db[12][0] = -6 * bC3[3] * xz; db[12][1] = -6 * bC3[3] * yz; db[12][2] = bC3[3] * (6 * zz - 3 * xx - 3 * yy);
-            bs[13] = bC3[4] * X * (4 * zz - xx - yy);      db[13][0] = bC3[4] * (4 * zz - 3 * xx - yy); db[13][1] = -2 * bC3[4] * xy; db[13][2] = 8 * bC3[4] * xz;
-            bs[14] = bC3[5] * Z * (xx - yy);               db[14][0] = 2 * bC3[5] * xz; db[14][1] = -2 * bC3[5] * yz; db[14][2] = bC3[5] * (xx - yy);
-            bs[15] = bC3[6] * X * (xx - 3 * yy);           db[15][0] = bC3[6] * (3 * xx - 3 * yy); db[15][1] = -6 * bC3[6] * xy;
-        }
-    }
-    const float *sh = a.shs + (int64_t)3 * K * g;
-    float ddir[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        float cs = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            cs += grgb[c] * sh[c + 3 * k];
-            if (a.d_shs) a.d_shs[(int64_t)3 * K * g + c + 3 * k] += bs[k] * grgb[c];
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) ddir[q] += cs * db[k][q];
-    }
-    const float dd = dxn * ddir[0] + dyn * ddir[1] + dzn * ddir[2];
-    dp[0] += (ddir[0] - dxn * dd) * inrm;
-    dp[1] += (ddir[1] - dyn * dd) * inrm;
-    dp[2] += (ddir[2] - dzn * dd) * inrm;
     // ---- p = P t ; t = T [m;1]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -210,16 +219,23 @@ __global__ __launch_bounds__(256) void gs_preprocess_bwd_kernel(GsPreprocessBwdA
         const float sg = ez / (1.0f + ez);
         a.d_opac[g] += gsig * sg * (1.0f - sg);
     }
+    }   // g < n
+    __syncthreads();
+    if (a.d_shs)
+        for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x)
+            a.d_shs[gb * 3 * K + idx] += tile[(idx / (3 * K)) * ROW + idx % (3 * K)];
 }
 
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     const dim3 block(256), grid((unsigned)((a.n + 255) / 256));
+    const int K = (a.sh_degree + 1) * (a.sh_degree + 1);
+    const size_t lds = sizeof(float) * 256 * (3 * K + 1);
     switch (a.sh_degree) {
-        case 0: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<0>, grid, block, 0, s, a, cam); break;
-        case 1: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<1>, grid, block, 0, s, a, cam); break;
-        case 2: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<2>, grid, block, 0, s, a, cam); break;
-        case 3: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<3>, grid, block, 0, s, a, cam); break;
+        case 0: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<0>, grid, block, lds, s, a, cam); break;
+        case 1: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<1>, grid, block, lds, s, a, cam); break;
+        case 2: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<2>, grid, block, lds, s, a, cam); break;
+        case 3: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<3>, grid, block, lds, s, a, cam); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
