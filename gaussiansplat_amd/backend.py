@@ -25,7 +25,7 @@ STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges
 # every symbol include/gsplat.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
            "gs_synchronize", "gs_set_model", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
-           "gs_backward", "gs_reset_grads", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
+           "gs_backward", "gs_reset_grads", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters")
 
 
@@ -80,6 +80,8 @@ def load():
     L.gs_forward.argtypes = [vp, vp, vp, C.c_int]
     L.gs_backward.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads)]
     L.gs_reset_grads.argtypes = [vp, C.POINTER(GsGrads)]
+    L.gs_grads_alloc.argtypes = [vp, C.POINTER(GsGrads)]
+    L.gs_grads_read.argtypes = [vp, C.POINTER(GsGrads), vp, vp, vp, vp, vp]
     L.gs_num_gaussians.argtypes = [vp]; L.gs_num_gaussians.restype = C.c_int64
     L.gs_num_instances.argtypes = [vp]; L.gs_num_instances.restype = C.c_int64
     L.gs_get_array.argtypes = [vp, C.c_int, vp, C.c_int64]
@@ -173,6 +175,20 @@ class Context:
             self._chk(self.L.gs_backward(self.h, C.c_void_p(a.ctypes.data), GS_MEM_HOST, C.byref(grads)))
         else:
             self._chk(self.L.gs_backward(self.h, C.c_void_p(int(dC_ptr_or_array)), GS_MEM_DEVICE, C.byref(grads)))
+
+    def grads_alloc(self) -> GsGrads:
+        """Library-owned flat gradient buffer (for hosts without a device allocator, e.g. plain Julia)."""
+        g = GsGrads()
+        self._chk(self.L.gs_grads_alloc(self.h, C.byref(g)))
+        return g
+
+    def grads_read(self, grads: GsGrads, sh_degree: int) -> dict:
+        n, k3 = self.num_gaussians, 3 * (sh_degree + 1) ** 2
+        out = dict(means=np.empty((n, 3), np.float32), scales=np.empty((n, 3), np.float32), quats=np.empty((n, 4), np.float32),
+                   opacities=np.empty((n,), np.float32), shs=np.empty((n, k3), np.float32))
+        self._chk(self.L.gs_grads_read(self.h, C.byref(grads), *(C.c_void_p(out[k].ctypes.data) for k in
+                                                                   ("means", "scales", "quats", "opacities", "shs"))))
+        return out
 
     def reset_grads(self, grads: GsGrads):
         self._chk(self.L.gs_reset_grads(self.h, C.byref(grads)))

@@ -68,6 +68,7 @@ struct gs_ctx {
     double ev_sum[GS_STAGE_COUNT] = {};
     int64_t ev_cnt[GS_STAGE_COUNT] = {};
     DevBuf counters;                         // 2 x u64: entries walked fwd / bwd
+    DevBuf grads_flat;                       // gs_grads_alloc
 };
 
 namespace {
@@ -170,7 +171,7 @@ int gs_destroy(gs_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
-                      &c->counters};
+                      &c->counters, &c->grads_flat};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->model) b.release();
     for (auto &b : c->dbg) b.release();
@@ -418,6 +419,33 @@ int gs_reset_grads(gs_ctx *c, const gs_grads *g) {
     if (g->d_quats) HIPCHK(c, hipMemsetAsync(g->d_quats, 0, sizeof(float) * 4 * n, c->stream));
     if (g->d_opacities) HIPCHK(c, hipMemsetAsync(g->d_opacities, 0, sizeof(float) * n, c->stream));
     if (g->d_shs) HIPCHK(c, hipMemsetAsync(g->d_shs, 0, sizeof(float) * 3 * K * n, c->stream));
+    return GS_OK;
+}
+
+int gs_grads_alloc(gs_ctx *c, gs_grads *out) {
+    if (!c || !out) return GS_ERR_INVALID;
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t n = (size_t)c->n;
+    const size_t K3 = (size_t)3 * (c->sh_degree + 1) * (c->sh_degree + 1);
+    const size_t total = n * (11 + K3);
+    HIPCHK(c, c->grads_flat.ensure(sizeof(float) * (total ? total : 1)));
+    HIPCHK(c, hipMemsetAsync(c->grads_flat.p, 0, sizeof(float) * total, c->stream));
+    float *f = c->grads_flat.as<float>();
+    out->d_means = f; out->d_scales = f + 3 * n; out->d_quats = f + 6 * n; out->d_opacities = f + 10 * n; out->d_shs = f + 11 * n;
+    return GS_OK;
+}
+
+int gs_grads_read(gs_ctx *c, const gs_grads *g, float *h_means, float *h_scales, float *h_quats, float *h_opacities, float *h_shs) {
+    if (!c || !g) return GS_ERR_INVALID;
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t n = (size_t)c->n;
+    const size_t K3 = (size_t)3 * (c->sh_degree + 1) * (c->sh_degree + 1);
+    const float *src[5] = {g->d_means, g->d_scales, g->d_quats, g->d_opacities, g->d_shs};
+    float *dst[5] = {h_means, h_scales, h_quats, h_opacities, h_shs};
+    const size_t w[5] = {3, 3, 4, 1, K3};
+    for (int i = 0; i < 5; ++i)
+        if (dst[i] && src[i] && n) HIPCHK(c, hipMemcpyAsync(dst[i], src[i], sizeof(float) * w[i] * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return GS_OK;
 }
 

@@ -135,6 +135,14 @@ int gs_backward(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads);
 /* resetGrads: zero the arrays of `grads` (DEVICE pointers) on the ctx stream. */
 int gs_reset_grads(gs_ctx *ctx, const gs_grads *grads);
 
+/* initGrads (splat.jl:137-156) for hosts without their own device allocator: allocates ONE flat
+ * zeroed device buffer [d_means 3N | d_scales 3N | d_quats 4N | d_opac N | d_shs 3K*N] owned by
+ * the ctx (freed by gs_destroy or the next gs_grads_alloc) and points `out` into it.
+ * gs_grads_read copies gradient arrays back to HOST buffers (any may be NULL); synchronises. */
+int gs_grads_alloc(gs_ctx *ctx, gs_grads *out);
+int gs_grads_read(gs_ctx *ctx, const gs_grads *grads, float *h_means, float *h_scales, float *h_quats,
+                  float *h_opacities, float *h_shs);
+
 /* ---- introspection (parity tests, profiling) ------------------------------------------- */
 
 typedef enum {

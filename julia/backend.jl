@@ -1,0 +1,119 @@
+# backend.jl -- drop-in body for the reference's EMPTY src/backend.jl (/root/reference/src/backend.jl:1).
+#
+# Thin ccall glue over libgsplat_hip.so (include/gsplat.h).  NOT executed in the build container
+# (no Julia toolchain there); the Python ctypes binding gaussiansplat_amd/backend.py binds the same
+# symbols 1:1 and is what the tests drive.  Arrays keep the reference's column-major layouts, so
+# `pointer(A)` is passed unpermuted: means 3xN, scales 3xN, quaternions 4xN, opacities 1xN,
+# shs (3K)xN, image WxHx3, T/P 4x4.
+#
+# A maintainer adds `include("backend.jl")` to src/GaussianSplat.jl and replaces the CUDA.jl bodies
+# of preprocess / compactIdxs / forward / backward (src/forward.jl:35-198, src/backward.jl:3-38)
+# by the `hip_*` functions below.
+
+module HipBackend
+
+const libgs = get(ENV, "GSPLAT_HIP_LIB", "libgsplat_hip.so")
+
+const GS_MEM_HOST = Cint(0)
+const GS_MEM_DEVICE = Cint(1)
+@enum GsOrder::Cint GS_ORDER_INDEX = 0 GS_ORDER_DEPTH_DESC = 1 GS_ORDER_DEPTH_ASC = 2
+
+mutable struct GsConfig                      # must mirror gs_config (64 bytes)
+    struct_size::Int32
+    tile_size::Int32
+    order::Int32
+    t_min::Float32
+    deterministic::Int32
+    export_debug::Int32
+    profile_stages::Int32
+    reserved::NTuple{9, Int32}
+end
+
+struct GsGrads                               # gs_grads: device pointers, may be C_NULL
+    d_means::Ptr{Float32}
+    d_scales::Ptr{Float32}
+    d_quats::Ptr{Float32}
+    d_opacities::Ptr{Float32}
+    d_shs::Ptr{Float32}
+end
+
+mutable struct HipRenderer
+    ctx::Ptr{Cvoid}
+    n::Int
+    shDegree::Int
+    W::Int
+    H::Int
+end
+
+function check(r::HipRenderer, rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:gs_last_error, libgs), Cstring, (Ptr{Cvoid},), r.ctx))
+    error("libgsplat_hip error $rc: $msg")
+end
+
+function defaultConfig()
+    cfg = GsConfig(0, 0, 0, 0f0, 0, 0, 0, ntuple(_ -> Int32(0), 9))
+    ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
+    return cfg
+end
+
+# getRenderer(...)  (src/renderer.jl:119-149): host arrays are copied once and stay resident
+function hip_getRenderer(means::Matrix{Float32}, scales::Matrix{Float32}, quaternions::Matrix{Float32},
+                         opacities::Matrix{Float32}, shs::Matrix{Float32}, imgSize; device = 0, cfg = defaultConfig())
+    ctxref = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:gs_create, libgs), Cint, (Ref{Ptr{Cvoid}}, Cint, Ref{GsConfig}), ctxref, device, cfg)
+    rc == 0 || error("gs_create failed: " * unsafe_string(ccall((:gs_last_error, libgs), Cstring, (Ptr{Cvoid},), C_NULL)))
+    n = size(means, 2)
+    K = div(size(shs, 1), 3)
+    deg = isqrt(K) - 1
+    r = HipRenderer(ctxref[], n, deg, imgSize[1], imgSize[2])
+    check(r, ccall((:gs_set_model, libgs), Cint,
+                   (Ptr{Cvoid}, Int64, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cint),
+                   r.ctx, n, deg, means, scales, quaternions, opacities, shs, GS_MEM_HOST))
+    finalizer(x -> ccall((:gs_destroy, libgs), Cint, (Ptr{Cvoid},), x.ctx), r)
+    return r
+end
+
+# preprocess(renderer)  (src/forward.jl:35-111); T, P from computeTransform/computeProjection (.linear)
+function hip_preprocess(r::HipRenderer, camera, T::AbstractMatrix, P::AbstractMatrix)
+    Tm = Matrix{Float32}(T); Pm = Matrix{Float32}(P)
+    eye = Vector{Float32}(camera.eye); lookAt = Vector{Float32}(camera.lookAt)
+    check(r, ccall((:gs_set_camera, libgs), Cint,
+                   (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Float32}, Ptr{Float32}, Int32, Int32),
+                   r.ctx, Tm, Pm, camera.fx, camera.fy, camera.near, camera.far, eye, lookAt, r.W, r.H))
+    check(r, ccall((:gs_preprocess, libgs), Cint, (Ptr{Cvoid},), r.ctx))
+end
+
+# compactIdxs(renderer, threads, blocks)  (src/forward.jl:118-161)
+hip_compactIdxs(r::HipRenderer, threads, blocks) =
+    check(r, ccall((:gs_bin, libgs), Cint, (Ptr{Cvoid}, Int32, Int32), r.ctx, blocks[1], blocks[2]))
+
+# forward(renderer, tps, threads, blocks)  (src/forward.jl:163-198): fills imageData (W x H x 3), transmittance (W x H)
+function hip_forward!(r::HipRenderer, imageData::Array{Float32, 3}, transmittance::Array{Float32, 2})
+    check(r, ccall((:gs_forward, libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Cint),
+                   r.ctx, imageData, transmittance, GS_MEM_HOST))
+end
+
+# initGrads (src/splat.jl:137-156): one flat zeroed device buffer owned by the library
+function hip_initGrads(r::HipRenderer)
+    g = Ref(GsGrads(C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
+    check(r, ccall((:gs_grads_alloc, libgs), Cint, (Ptr{Cvoid}, Ref{GsGrads}), r.ctx, g))
+    return g[]
+end
+
+# copy the accumulated gradients into host arrays shaped like the parameters
+function hip_readGrads!(r::HipRenderer, grads::GsGrads, Δmeans, Δscales, Δquaternions, Δopacities, Δshs)
+    check(r, ccall((:gs_grads_read, libgs), Cint,
+                   (Ptr{Cvoid}, Ref{GsGrads}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+                   r.ctx, grads, Δmeans, Δscales, Δquaternions, Δopacities, Δshs))
+end
+
+# backward(renderer, ΔC)  (src/backward.jl:3-38): accumulates into DEVICE gradient arrays
+hip_backward!(r::HipRenderer, ΔC::Array{Float32, 3}, grads::GsGrads) =
+    check(r, ccall((:gs_backward, libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}, Cint, Ref{GsGrads}), r.ctx, ΔC, GS_MEM_HOST, grads))
+
+# resetGrads(renderer.splatGrads)  (src/splat.jl:158-173)
+hip_resetGrads!(r::HipRenderer, grads::GsGrads) =
+    check(r, ccall((:gs_reset_grads, libgs), Cint, (Ptr{Cvoid}, Ref{GsGrads}), r.ctx, grads))
+
+end # module

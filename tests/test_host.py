@@ -1,0 +1,50 @@
+"""Host-side mirror of the reference interface: camera, synthetic scenes, loaders (CPU only)."""
+import json
+
+import numpy as np
+
+from gaussiansplat_amd import camera as gcam
+from gaussiansplat_amd import synthetic
+
+
+def test_default_camera_matches_reference_literals():
+    c = gcam.default_camera()                          # camera.jl:24-47
+    assert list(c.eye) == [1.0, 3.0, 30.0] and list(c.lookAt) == [0, 0, 0] and list(c.up) == [0, 1, 0]
+    assert (c.fx, c.fy, c.near, c.far) == (3200.0, 3200.0, 0.1, 100.0)
+
+
+def test_get_camera_from_cameras_json(tmp_path):
+    rot = [[1, 0, 0], [0, 1, 0], [0, 0, 1]]
+    entry = dict(id=3, img_name="im0", width=640, height=480, position=[1.0, 2.0, 3.0], rotation=rot, fx=500.0, fy=510.0)
+    p = tmp_path / "cameras.json"
+    p.write_text(json.dumps([entry]))
+    c = gcam.get_camera(str(p), 1)                     # 1-based like the reference (camera.jl:119)
+    assert np.allclose(c.eye, [-1, -2, -3]) and np.allclose(c.lookAt, [0, 0, -1])   # camera.jl:130-131
+    assert (c.fx, c.fy, c.near, c.far, c.id, c.data) == (500.0, 510.0, 0.010, 100.0, 3, "im0")
+
+
+def test_synthetic_scene_is_deterministic_and_shaped():
+    a = synthetic.make_scene(1000, 256, 256, 3, seed=1234)
+    b = synthetic.make_scene(1000, 256, 256, 3, seed=1234)
+    for k in a:
+        assert np.array_equal(a[k], b[k]) and a[k].dtype == np.float32
+    assert a["shs"].shape == (1000, 16, 3) and a["quats"].shape == (1000, 4)
+    assert np.allclose(np.linalg.norm(a["quats"], axis=1), 1, atol=1e-6)
+    assert (a["scales"] >= -4.5).all() and (a["scales"] <= -2.5).all()
+    assert (a["opacities"] >= -2).all() and (a["opacities"] <= 4).all()
+    c0 = synthetic.scene_camera(1920, 0); c2 = synthetic.scene_camera(1920, 2)
+    assert c0.fx == 3200.0 and np.allclose(c0.eye, [1, 3, 30])
+    assert np.isclose(np.linalg.norm(c2.eye), np.linalg.norm(c0.eye), rtol=1e-6) and np.isclose(c2.eye[1], 3.0)
+
+
+def test_ply_round_trip_reference_field_mapping(tmp_path):
+    from gaussiansplat_amd import ply
+    sc = synthetic.make_scene(257, 128, 128, 3, seed=5)
+    p = str(tmp_path / "scene.ply")
+    ply.save_ply(p, sc)
+    d1 = ply.load_ply(p)                                  # reference mapping: f_dc + f_rest[0:9] -> 12 floats
+    assert d1["shs"].shape == (257, 4, 3)
+    assert np.array_equal(d1["shs"].reshape(257, -1), sc["shs"].reshape(257, -1)[:, :12])
+    d3 = ply.load_ply(p, sh_degree=3)
+    for k in ("means", "scales", "quats", "opacities", "shs"):
+        assert np.array_equal(d3[k], sc[k]), k
