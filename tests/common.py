@@ -20,7 +20,7 @@ def hip_context(sc, cam, T, P, W, H, deg, **kw):
     from gaussiansplat_amd import backend as B
     ctx = B.Context(**kw)
     n = sc["means"].shape[0]
-    ctx.set_model_host(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"].reshape(n, -1), deg)
+    ctx.set_model_host(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"].reshape(n, 3 * (deg + 1) ** 2), deg)
     ctx.set_camera(T, P, float(np.float32(cam.fx)), float(np.float32(cam.fy)), float(np.float32(cam.near)),
                    float(np.float32(cam.far)), cam.eye, cam.lookAt, W, H)
     return ctx

@@ -1,0 +1,81 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle is too slow there)."""
+import numpy as np
+import pytest
+
+from common import hip_context, scene_and_cameras
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c3():
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg = synthetic.CONFIGS["C3"]
+    return (n, W, H, deg) + scene_and_cameras(n, W, H, deg, 1236)
+
+
+@pytest.mark.parametrize("order", [1, 0])
+def test_c3_binning_invariants(c3, order):
+    from gaussiansplat_amd import backend as B
+    n, W, H, deg, sc, cam, T, P, ocam = c3
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0)
+    ctx.preprocess(); ctx.bin()
+    I = ctx.num_instances
+    rect = ctx.get_array(B.ARR_TILE_RECT).astype(np.int64)
+    area = np.where(rect[:, 0] == 0, 0, (rect[:, 1] - rect[:, 0] + 1) * (rect[:, 3] - rect[:, 2] + 1))
+    assert I == int(area.sum()) and I > 10 * n                          # checksum of the per-gaussian counts
+    keys = ctx.get_array(B.ARR_SORTED_KEYS)
+    assert np.all(keys[1:] >= keys[:-1])                                  # sortedness of tile|depth (or tile|index)
+    ids = ctx.get_array(B.ARR_SORTED_IDS)
+    ranges = ctx.get_array(B.ARR_TILE_RANGES).astype(np.int64)
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    assert tiles.max() < gx * gy
+    cnt = np.bincount(tiles, minlength=gx * gy)
+    assert np.array_equal(ranges[:, 1] - ranges[:, 0], cnt)               # ranges == histogram of the sorted keys
+    assert np.array_equal(ranges[cnt > 0, 0], np.concatenate([[0], np.cumsum(cnt)])[:-1][cnt > 0])
+    assert np.array_equal(np.bincount(ids, minlength=n), area)            # every gaussian appears once per tile of its rect
+    perm = ctx.get_array(B.ARR_SORT_IDXS)
+    assert np.array_equal(np.sort(perm), np.arange(n, dtype=np.uint32))   # a permutation
+    dk = ctx.get_array(B.ARR_DEPTH_KEY)
+    if order != 0:
+        assert np.all(np.diff(dk[perm].astype(np.int64)) >= 0)            # depth order, stable: ties by index
+        tie = np.diff(dk[perm].astype(np.int64)) == 0
+        assert np.all(np.diff(perm.astype(np.int64))[tie] > 0)
+    ctx.close()
+
+
+def test_c3_forward_deterministic_backward_linear(c3):
+    import torch
+    from gaussiansplat_amd import backend as B, synthetic
+    n, W, H, deg, sc, cam, T, P, ocam = c3
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5)
+    ctx.preprocess(); ctx.bin()
+    img1, tr1 = ctx.forward_host()
+    ctx.preprocess(); ctx.bin()
+    img2, tr2 = ctx.forward_host()
+    assert np.array_equal(img1, img2) and np.array_equal(tr1, tr2)        # idempotent, bitwise
+    assert np.isfinite(img1).all() and tr1.min() >= 0 and tr1.max() <= 1
+    lit = hip_context(sc, cam, T, P, W, H, deg, t_min=0.0)
+    lit.preprocess(); lit.bin()
+    img0, tr0 = lit.forward_host()
+    assert np.all(np.abs(img1 - img0) <= 1e-4 + 1e-4 * np.abs(img0))      # early-out within tolerance of the literal result
+    assert np.all(np.abs(tr1 - tr0) <= 1e-4)
+    lit.close()
+    # adjoint is linear in dC: g(2 dC) == 2 g(dC) up to atomic-order rounding
+    K3 = 3 * (deg + 1) ** 2
+    dC = synthetic.make_dC(W, H, 3)
+    outs = []
+    for scale in (1.0, 2.0):
+        flat = torch.zeros(n * (11 + K3), dtype=torch.float32, device="cuda")
+        ptrs, o = [], 0
+        for w in (3, 3, 4, 1, K3):
+            ptrs.append(flat[o:o + n * w].data_ptr()); o += n * w
+        torch.cuda.synchronize()
+        ctx.backward((scale * dC).astype(np.float32), B.GsGrads(*ptrs)); ctx.synchronize()
+        outs.append(flat.cpu().numpy().astype(np.float64))
+    assert np.isfinite(outs[0]).all()
+    assert np.linalg.norm(outs[1] - 2 * outs[0]) <= 1e-4 * np.linalg.norm(outs[1])
+    wf, wb = ctx.work_counters()
+    assert 0 < wf <= ctx.num_instances + 64 * 8160 and wb == wf
+    ctx.close()
