@@ -26,7 +26,7 @@ STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges
 SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
            "gs_synchronize", "gs_set_model", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
            "gs_backward", "gs_reset_grads", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
-           "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters")
+           "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_debug_time_composite")
 
 
 class GsConfig(C.Structure):
@@ -88,6 +88,7 @@ def load():
     L.gs_get_stage_times.argtypes = [vp, fp]
     L.gs_get_stage_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.gs_get_work_counters.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.gs_debug_time_composite.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -229,6 +230,11 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         self._chk(self.L.gs_get_work_counters(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def time_composite(self, which: int, variant: int, reps: int = 10) -> float:
+        ms = C.c_float()
+        self._chk(self.L.gs_debug_time_composite(self.h, which, variant, reps, C.byref(ms)))
+        return float(ms.value)
 
     def stage_times(self) -> dict:
         ms = (C.c_float * len(STAGES))()

@@ -61,6 +61,8 @@ struct gs_ctx {
     uint32_t *perm_ptr = nullptr;
     int64_t n_inst = 0;
     uint32_t *pinned = nullptr;
+    const float *last_dC = nullptr;          // device dC of the last gs_backward (debug timing)
+    int variant_fwd = 0, variant_bwd = 0;
 
     hipEvent_t ev[GS_STAGE_COUNT][2] = {};
     bool ev_valid[GS_STAGE_COUNT] = {};      // a start/stop pair has been recorded
@@ -355,6 +357,7 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     HIPCHK(c, c->counters.ensure(16));
     a.walked = c->counters.as<unsigned long long>();
+    a.variant = c->variant_fwd;
     {
         StageTimer t(c, GS_STAGE_COMPOSITE_FWD);
         HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16, c->stream));
@@ -388,6 +391,8 @@ int gs_backward(gs_ctx *c, const float *dC, int mem, const gs_grads *grads) {
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     a.dC = dC_dev; a.g2d = c->g2d.as<float>();
     a.walked = c->counters.as<unsigned long long>() + 1;
+    a.variant = c->variant_bwd;
+    c->last_dC = dC_dev;
     {
         StageTimer t(c, GS_STAGE_COMPOSITE_BWD);
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, sizeof(float) * 10 * n1, c->stream));
@@ -557,6 +562,31 @@ int gs_get_stage_stats(gs_ctx *c, double sum_ms[GS_STAGE_COUNT], int64_t count[G
         sum_ms[s] = c->ev_sum[s]; count[s] = c->ev_cnt[s];
         if (reset) { c->ev_sum[s] = 0.0; c->ev_cnt[s] = 0; }
     }
+    return GS_OK;
+}
+
+int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *mean_ms) {
+    if (!c || !mean_ms || reps <= 0) return GS_ERR_INVALID;
+    if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_debug_time_composite: gs_forward first");
+    if (which == 1 && !c->did_bwd) return fail(c, GS_ERR_INVALID, "gs_debug_time_composite: gs_backward first");
+    if (bind_device(c)) return GS_ERR_HIP;
+    GsCompositeArgs a{};
+    a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
+    a.ranges = c->ranges.as<uint32_t>(); a.inst = c->inst_sorted; a.payload = c->payload.as<GsPayload>();
+    a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
+    a.dC = c->last_dC; a.g2d = c->g2d.as<float>(); a.walked = nullptr; a.variant = variant;
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));   // warm
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; ++i)
+        HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    *mean_ms = ms / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return GS_OK;
 }
 

@@ -121,6 +121,230 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(GsCompositeArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- forward, variant 1
+// Same mapping, leaner inner loop:
+//  * everything lane-independent is computed ONCE per (tile, splat) by the staging lane and kept
+//    in the LDS record: k*inv entries (k = -1/2 log2 e), log2(sig) (folded into the exponent, so
+//    alpha = exp2(pw) directly) and the pixel box as (lo, count) pairs;
+//  * the box test is one unsigned compare per axis ((unsigned)(p - lo) < count), the x result is
+//    folded into the y count, so a pixel costs one v_sub + one v_cmp and no scalar and-chains;
+//  * early-out is evaluated per 64-entry batch: a pixel whose T fell below t_min is frozen
+//    (T recorded, working T = 0, so every later weight is exactly 0) -- no per-entry test.
+struct StagedSplat {            // wave-uniform view of one LDS record
+    float mx, my, l2s, ki0, kB, ki3, r, g, b;
+    int xlo, ylo;
+    uint32_t xcnt, ycnt;
+};
+__device__ __forceinline__ void stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2) {
+    const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
+    const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
+    const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
+    const uint32_t xc = (uint32_t)max(0, xmax - xmin + 1), yc = (uint32_t)max(0, ymax - ymin + 1);
+    // log2(sig), capped one ulp below 0 so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic is PSD);
+    // only matters when sigmoid(o) rounds to exactly 1.0f (o > 16.6): relative change 6e-8
+    const float l2s = fminf(__builtin_amdgcn_logf(n0.z), -8.6e-8f);
+    q0 = make_float4(n0.x, n0.y, n0.z == n0.z ? l2s : n0.z, __uint_as_float(((uint32_t)xmin & 0xFFFFu) | (xc << 16)));
+    q1 = make_float4(NEG_HALF_LOG2E * n1.x, NEG_HALF_LOG2E * (n1.y + n1.z), NEG_HALF_LOG2E * n1.w, n0.z);
+    q2 = make_float4(n2.x, n2.y, n2.z, __uint_as_float(((uint32_t)ymin & 0xFFFFu) | (yc << 16)));
+}
+
+template <bool EARLY, int UNROLL, int MINW>
+__global__ __launch_bounds__(64, MINW) void composite_fwd_v1_kernel(GsCompositeArgs a) {
+    __shared__ float4 sp[CB * 3];
+    const int ntiles = a.gx * a.gy;
+    const int tile = tile_of_block(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x;
+    const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
+    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
+    const float fx = (float)px;
+    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
+
+    float Cr[4], Cg[4], Cb[4], T[4], Tdead[4], fy[4];
+    bool dead[4];
+    uint32_t walked = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        Cr[p] = Cg[p] = Cb[p] = 0.0f;
+        fy[p] = (float)(py0 + 4 * p);
+        const bool in = (px <= a.W && py0 + 4 * p <= a.H);
+        T[p] = in ? 1.0f : 0.0f;                                        // off-image pixels are inert
+        Tdead[p] = 0.0f; dead[p] = !in;
+    }
+    const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    uint32_t pos = s0 + lane;
+    if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+    for (uint32_t base = s0; base < s1; base += CB) {
+        const int cnt = (int)min((uint32_t)CB, s1 - base);
+        if (EARLY) {                                                    // freeze saturated pixels, vote
+            bool live = false;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (!dead[p] && T[p] < a.t_min) { dead[p] = true; Tdead[p] = T[p]; T[p] = 0.0f; }
+                live = live || !dead[p];
+            }
+            if (__ballot(live) == 0ull) break;                          // whole tile saturated
+        }
+        float4 q0, q1, q2;
+        stage_record(q0, q1, q2, n0, n1, n2);
+        __syncthreads();                                                // one wave: orders LDS reads/writes only
+        sp[3 * lane] = q0; sp[3 * lane + 1] = q1; sp[3 * lane + 2] = q2;
+        __syncthreads();
+        pos = base + CB + lane;                                         // next batch in flight during the loop below
+        if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+#pragma unroll UNROLL
+        for (int k = 0; k < cnt; ++k) {
+            const float4 q0k = sp[3 * k], q1k = sp[3 * k + 1], q2k = sp[3 * k + 2];
+            const uint32_t xw = __float_as_uint(q0k.w), yw = __float_as_uint(q2k.w);
+            const bool hitx = (uint32_t)(px - (int)(short)(xw & 0xFFFFu)) < (xw >> 16);
+            const uint32_t ycnt = hitx ? (yw >> 16) : 0u;
+            const int ylo = (int)(short)(yw & 0xFFFFu);
+            const float dX = fx - q0k.x;
+            const float A0 = fmaf(q1k.x * dX, dX, q0k.z);               // k i0 dX^2 + log2(sig)
+            const float B0 = q1k.y * dX;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float dY = fy[p] - q0k.y;
+                const float al = fast_exp2(fmaf(dY, fmaf(q1k.z, dY, B0), A0));
+                const bool hit = (uint32_t)(py0 + 4 * p - ylo) < ycnt;
+                const float w = (hit ? al : 0.0f) * T[p];
+                Cr[p] = fmaf(q2k.x, w, Cr[p]);
+                Cg[p] = fmaf(q2k.y, w, Cg[p]);
+                Cb[p] = fmaf(q2k.z, w, Cb[p]);
+                T[p] = T[p] - w;
+            }
+        }
+        walked += (uint32_t)cnt;
+    }
+    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
+    if (px <= a.W) {
+        const size_t plane = (size_t)a.W * a.H;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int py = py0 + 4 * p;
+            if (py <= a.H) {
+                const size_t o = (size_t)(px - 1) + (size_t)a.W * (py - 1);
+                if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p]; }
+                if (a.trans) a.trans[o] = (EARLY && dead[p]) ? Tdead[p] : T[p];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- forward, variant 2
+// v1 with the pixel-box test turned into arithmetic: v_cmp / v_cndmask cost ~4 cycles each on
+// gfx950 (fma: 2), so the box is applied as an exponent penalty
+//     pw' = pw - BIG * |d - med3(d, lo, hi)|        (d = pixel - mu on that axis)
+// which is exactly 0 inside the box (med3 returns d itself) and drives exp2 to 0 outside.
+// lo/hi = box edge - mu -/+ 0.25 are lane independent and staged once per (tile, splat).
+#define GS_BIG 1.0e30f
+__device__ __forceinline__ void stage_record2(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2) {
+    const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
+    const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
+    const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
+    const bool empty = xmax < xmin || ymax < ymin;
+    const float l2s = fminf(__builtin_amdgcn_logf(n0.z), -8.6e-8f);
+    // an empty box (near/far-culled splat) gets lo = hi = +BIG: every pixel is "outside"
+    const float xlo = empty ? GS_BIG : ((float)xmin - n0.x) - 0.25f, xhi = empty ? GS_BIG : ((float)xmax - n0.x) + 0.25f;
+    const float ylo = empty ? GS_BIG : ((float)ymin - n0.y) - 0.25f, yhi = empty ? GS_BIG : ((float)ymax - n0.y) + 0.25f;
+    q0 = make_float4(n0.x, n0.y, n0.z == n0.z ? l2s : n0.z, xlo);
+    q1 = make_float4(NEG_HALF_LOG2E * n1.x, NEG_HALF_LOG2E * (n1.y + n1.z), NEG_HALF_LOG2E * n1.w, xhi);
+    q2 = make_float4(n2.x, n2.y, n2.z, ylo);
+    // yhi travels in a 4th slot
+    (void)yhi;
+}
+
+template <bool EARLY, int UNROLL, int MINW>
+__global__ __launch_bounds__(64, MINW) void composite_fwd_v2_kernel(GsCompositeArgs a) {
+    __shared__ float4 sp[CB * 3];
+    __shared__ float syhi[CB];
+    const int ntiles = a.gx * a.gy;
+    const int tile = tile_of_block(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x;
+    const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
+    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
+    const float fx = (float)px;
+    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
+
+    float Cr[4], Cg[4], Cb[4], T[4], Tdead[4], fy[4];
+    bool dead[4];
+    uint32_t walked = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        Cr[p] = Cg[p] = Cb[p] = 0.0f;
+        fy[p] = (float)(py0 + 4 * p);
+        const bool in = (px <= a.W && py0 + 4 * p <= a.H);
+        T[p] = in ? 1.0f : 0.0f;
+        Tdead[p] = 0.0f; dead[p] = !in;
+    }
+    const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    uint32_t pos = s0 + lane;
+    if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+    for (uint32_t base = s0; base < s1; base += CB) {
+        const int cnt = (int)min((uint32_t)CB, s1 - base);
+        if (EARLY) {
+            bool live = false;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (!dead[p] && T[p] < a.t_min) { dead[p] = true; Tdead[p] = T[p]; T[p] = 0.0f; }
+                live = live || !dead[p];
+            }
+            if (__ballot(live) == 0ull) break;
+        }
+        float4 q0, q1, q2;
+        stage_record2(q0, q1, q2, n0, n1, n2);
+        {
+            const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
+            const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
+            const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
+            const bool empty = xmax < xmin || ymax < ymin;
+            __syncthreads();
+            sp[3 * lane] = q0; sp[3 * lane + 1] = q1; sp[3 * lane + 2] = q2;
+            syhi[lane] = empty ? GS_BIG : ((float)ymax - n0.y) + 0.25f;
+            __syncthreads();
+        }
+        pos = base + CB + lane;
+        if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+#pragma unroll UNROLL
+        for (int k = 0; k < cnt; ++k) {
+            const float4 q0k = sp[3 * k], q1k = sp[3 * k + 1], q2k = sp[3 * k + 2];
+            const float yhi = syhi[k];
+            const float dX = fx - q0k.x;
+            const float ex = dX - __builtin_amdgcn_fmed3f(dX, q0k.w, q1k.w);          // 0 inside the box columns
+            const float A0 = fmaf(-GS_BIG, fabsf(ex), fmaf(q1k.x * dX, dX, q0k.z));  // k i0 dX^2 + log2 sig - penalty
+            const float B0 = q1k.y * dX;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float dY = fy[p] - q0k.y;
+                const float ey = dY - __builtin_amdgcn_fmed3f(dY, q2k.w, yhi);
+                const float pw = fmaf(dY, fmaf(q1k.z, dY, B0), A0);
+                const float w = fast_exp2(fmaf(-GS_BIG, fabsf(ey), pw)) * T[p];
+                Cr[p] = fmaf(q2k.x, w, Cr[p]);
+                Cg[p] = fmaf(q2k.y, w, Cg[p]);
+                Cb[p] = fmaf(q2k.z, w, Cb[p]);
+                T[p] = T[p] - w;
+            }
+        }
+        walked += (uint32_t)cnt;
+    }
+    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
+    if (px <= a.W) {
+        const size_t plane = (size_t)a.W * a.H;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int py = py0 + 4 * p;
+            if (py <= a.H) {
+                const size_t o = (size_t)(px - 1) + (size_t)a.W * (py - 1);
+                if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p]; }
+                if (a.trans) a.trans[o] = (EARLY && dead[p]) ? Tdead[p] : T[p];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- wave64 reductions
 // Nine per-splat sums are needed.  Reducing them one by one costs 6 DPP adds each; instead
 // eight of them go through a reduce-scatter butterfly built on gfx950's lane-swap
@@ -292,10 +516,270 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(GsCompositeArgs a) {
     if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
 }
 
+// ---------------------------------------------------------------- backward, variant 1
+// Same tricks as composite_fwd_v1_kernel (lane-independent terms precomputed at staging, one
+// unsigned compare per pixel, per-batch freeze of saturated pixels: T = S = 0 makes every later
+// contribution exactly zero).  alpha = exp2(pw + log2 sig) is strictly < 1 (see stage_record), so
+// 1/(1-alpha) needs no guard; d sig = -(1/sig) * sum(dd) needs no accumulator of its own.
+template <bool EARLY, int UNROLL, int MINW>
+__global__ __launch_bounds__(64, MINW) void composite_bwd_v1_kernel(GsCompositeArgs a) {
+    __shared__ float4 sp[CB * 4];                                       // 4 KiB
+    const int ntiles = a.gx * a.gy;
+    const int tile = tile_of_block(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x;
+    const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
+    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
+    const float fx = (float)px;
+    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
+    const size_t plane = (size_t)a.W * a.H;
+    const int ocomp = out_component(lane);
+    const bool take_hi = (lane & 15) == 14, take_9 = lane == 61;
+
+    float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
+    bool dead[4];
+    uint32_t walked = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int py = py0 + 4 * p;
+        const bool in = (px <= a.W && py <= a.H);
+        const size_t o = in ? (size_t)(px - 1) + (size_t)a.W * (py - 1) : 0;
+        fy[p] = (float)py;
+        dCr[p] = in ? a.dC[o] : 0.0f;
+        dCg[p] = in ? a.dC[o + plane] : 0.0f;
+        dCb[p] = in ? a.dC[o + 2 * plane] : 0.0f;
+        T[p] = in ? 1.0f : 0.0f;
+        S[p] = in ? (a.image[o] * dCr[p] + a.image[o + plane] * dCg[p] + a.image[o + 2 * plane] * dCb[p]) : 0.0f;
+        dead[p] = !in;
+    }
+    const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    uint32_t nid = 0;
+    uint32_t pos = s0 + lane;
+    if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+    for (uint32_t base = s0; base < s1; base += CB) {
+        const int cnt = (int)min((uint32_t)CB, s1 - base);
+        if (EARLY) {
+            bool live = false;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (!dead[p] && T[p] < a.t_min) { dead[p] = true; T[p] = 0.0f; S[p] = 0.0f; }
+                live = live || !dead[p];
+            }
+            if (__ballot(live) == 0ull) break;
+        }
+        float4 q0, q1, q2;
+        stage_record(q0, q1, q2, n0, n1, n2);
+        const float sg = n0.z;
+        q1.w = sg > 0.0f ? fast_rcp(sg) : 0.0f;                         // 1/sig (sig == 0: d opacity is 0 anyway)
+        __syncthreads();
+        sp[4 * lane] = q0; sp[4 * lane + 1] = q1; sp[4 * lane + 2] = q2;
+        sp[4 * lane + 3] = make_float4(n1.x, 0.5f * (n1.y + n1.z), n1.w, __uint_as_float(nid));
+        __syncthreads();
+        pos = base + CB + lane;
+        if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+#pragma unroll UNROLL
+        for (int k = 0; k < cnt; ++k) {
+            const float4 q0k = sp[4 * k], q1k = sp[4 * k + 1], q2k = sp[4 * k + 2];
+            const uint32_t xw = __float_as_uint(q0k.w), yw = __float_as_uint(q2k.w);
+            const bool hitx = (uint32_t)(px - (int)(short)(xw & 0xFFFFu)) < (xw >> 16);
+            const uint32_t ycnt = hitx ? (yw >> 16) : 0u;
+            const int ylo = (int)(short)(yw & 0xFFFFu);
+            const float dX = fx - q0k.x;
+            const float A0 = fmaf(q1k.x * dX, dX, q0k.z);
+            const float B0 = q1k.y * dX;
+            float al[4], dY[4];
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                dY[p] = fy[p] - q0k.y;
+                const float ex = fast_exp2(fmaf(dY[p], fmaf(q1k.z, dY[p], B0), A0));
+                const bool hit = (uint32_t)(py0 + 4 * p - ylo) < ycnt;
+                any = any || hit;
+                al[p] = hit ? ex : 0.0f;
+            }
+            if (__ballot(any) == 0ull) continue;                        // nobody in the tile touched it
+            float ar = 0.0f, ag = 0.0f, ab = 0.0f, q0s = 0.0f, q1s = 0.0f, q2s = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float w = al[p] * T[p];
+                const float cdot = fmaf(q2k.x, dCr[p], fmaf(q2k.y, dCg[p], q2k.z * dCb[p]));
+                ar = fmaf(w, dCr[p], ar);
+                ag = fmaf(w, dCg[p], ag);
+                ab = fmaf(w, dCb[p], ab);
+                S[p] = fmaf(-cdot, w, S[p]);                            // colour behind this splat
+                const float inv = fast_rcp(1.0f - al[p]);
+                const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));   // dL/dalpha
+                const float dd = -(al[p] * dalpha);                     // dL/ddist ; dL/dsig = -(1/sig) sum dd
+                q0s += dd;
+                q1s = fmaf(dd, dY[p], q1s);
+                q2s = fmaf(dd * dY[p], dY[p], q2s);
+                T[p] = T[p] - w;
+            }
+            const float4 q3k = sp[4 * k + 3];                           // i0, mc, i3, id
+            const float qx = dX * q0s;
+            float v[8];
+            v[0] = ar; v[1] = ag; v[2] = ab; v[3] = -(q1k.w * q0s);
+            v[4] = -fmaf(q3k.x, qx, q3k.y * q1s);                       // d mu_x (delta = pixel - mu)
+            v[5] = -fmaf(q3k.y, qx, q3k.z * q1s);                       // d mu_y
+            v[6] = 0.5f * dX * qx;                                      // d inv[0]
+            v[7] = 0.5f * dX * q1s;                                     // d inv[1] = d inv[2]
+            float lo, hi;
+            reduce8(v, lo, hi);
+            const float t9 = wave_sum_to_lane63(0.5f * q2s);            // d inv[3]
+            const float hi_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x101, 0xF, 0xF, true));  // row_shl:1
+            const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));  // row_shl:2
+            const float outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
+            if (ocomp >= 0) atomicAdd(a.g2d + (size_t)__float_as_uint(q3k.w) * 10 + ocomp, outv);
+        }
+        walked += (uint32_t)cnt;
+    }
+    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
+}
+
+// ---------------------------------------------------------------- backward, variant 2
+// composite_bwd_v1_kernel with the arithmetic pixel-box penalty of composite_fwd_v2_kernel.
+template <bool EARLY, int MINW>
+__global__ __launch_bounds__(64, MINW) void composite_bwd_v2_kernel(GsCompositeArgs a) {
+    __shared__ float4 sp[CB * 4];
+    __shared__ float syhi[CB];
+    const int ntiles = a.gx * a.gy;
+    const int tile = tile_of_block(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int lane = threadIdx.x;
+    const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
+    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
+    const float fx = (float)px;
+    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
+    const size_t plane = (size_t)a.W * a.H;
+    const int ocomp = out_component(lane);
+    const bool take_hi = (lane & 15) == 14, take_9 = lane == 61;
+
+    float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
+    bool dead[4];
+    uint32_t walked = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int py = py0 + 4 * p;
+        const bool in = (px <= a.W && py <= a.H);
+        const size_t o = in ? (size_t)(px - 1) + (size_t)a.W * (py - 1) : 0;
+        fy[p] = (float)py;
+        dCr[p] = in ? a.dC[o] : 0.0f;
+        dCg[p] = in ? a.dC[o + plane] : 0.0f;
+        dCb[p] = in ? a.dC[o + 2 * plane] : 0.0f;
+        T[p] = in ? 1.0f : 0.0f;
+        S[p] = in ? (a.image[o] * dCr[p] + a.image[o + plane] * dCg[p] + a.image[o + 2 * plane] * dCb[p]) : 0.0f;
+        dead[p] = !in;
+    }
+    const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    uint32_t nid = 0;
+    uint32_t pos = s0 + lane;
+    if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+    for (uint32_t base = s0; base < s1; base += CB) {
+        const int cnt = (int)min((uint32_t)CB, s1 - base);
+        if (EARLY) {
+            bool live = false;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (!dead[p] && T[p] < a.t_min) { dead[p] = true; T[p] = 0.0f; S[p] = 0.0f; }
+                live = live || !dead[p];
+            }
+            if (__ballot(live) == 0ull) break;
+        }
+        float4 q0, q1, q2;
+        stage_record2(q0, q1, q2, n0, n1, n2);
+        {
+            const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
+            const bool empty = (int)(short)(bbx >> 16) < (int)(short)(bbx & 0xFFFFu) || (int)(short)(bby >> 16) < (int)(short)(bby & 0xFFFFu);
+            const float sg = n0.z;
+            __syncthreads();
+            sp[4 * lane] = q0; sp[4 * lane + 1] = q1; sp[4 * lane + 2] = q2;
+            // i0, mc, i3 and 1/sig ; id and yhi in the side array
+            sp[4 * lane + 3] = make_float4(n1.x, 0.5f * (n1.y + n1.z), n1.w, sg > 0.0f ? fast_rcp(sg) : 0.0f);
+            syhi[lane] = empty ? GS_BIG : ((float)(int)(short)(bby >> 16) - n0.y) + 0.25f;
+            __syncthreads();
+        }
+        const uint32_t my_id = nid;                                      // id of entry `lane` of this batch
+        pos = base + CB + lane;
+        if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+        for (int k = 0; k < cnt; ++k) {
+            const float4 q0k = sp[4 * k], q1k = sp[4 * k + 1], q2k = sp[4 * k + 2];
+            const float yhi = syhi[k];
+            const float dX = fx - q0k.x;
+            const float ex = dX - __builtin_amdgcn_fmed3f(dX, q0k.w, q1k.w);
+            const float A0 = fmaf(-GS_BIG, fabsf(ex), fmaf(q1k.x * dX, dX, q0k.z));
+            const float B0 = q1k.y * dX;
+            float al[4], dY[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                dY[p] = fy[p] - q0k.y;
+                const float ey = dY[p] - __builtin_amdgcn_fmed3f(dY[p], q2k.w, yhi);
+                al[p] = fast_exp2(fmaf(-GS_BIG, fabsf(ey), fmaf(dY[p], fmaf(q1k.z, dY[p], B0), A0)));
+            }
+            if (__ballot(((al[0] + al[1]) + (al[2] + al[3])) != 0.0f) == 0ull) continue;   // nobody in the tile touched it
+            float ar = 0.0f, ag = 0.0f, ab = 0.0f, q0s = 0.0f, q1s = 0.0f, q2s = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float w = al[p] * T[p];
+                const float cdot = fmaf(q2k.x, dCr[p], fmaf(q2k.y, dCg[p], q2k.z * dCb[p]));
+                ar = fmaf(w, dCr[p], ar);
+                ag = fmaf(w, dCg[p], ag);
+                ab = fmaf(w, dCb[p], ab);
+                S[p] = fmaf(-cdot, w, S[p]);
+                const float inv = fast_rcp(1.0f - al[p]);
+                const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));
+                const float dd = -(al[p] * dalpha);
+                q0s += dd;
+                q1s = fmaf(dd, dY[p], q1s);
+                q2s = fmaf(dd * dY[p], dY[p], q2s);
+                T[p] = T[p] - w;
+            }
+            const float4 q3k = sp[4 * k + 3];                           // i0, mc, i3, 1/sig
+            const float qx = dX * q0s;
+            float v[8];
+            v[0] = ar; v[1] = ag; v[2] = ab; v[3] = -(q3k.w * q0s);
+            v[4] = -fmaf(q3k.x, qx, q3k.y * q1s);
+            v[5] = -fmaf(q3k.y, qx, q3k.z * q1s);
+            v[6] = 0.5f * dX * qx;
+            v[7] = 0.5f * dX * q1s;
+            float lo, hi;
+            reduce8(v, lo, hi);
+            const float t9 = wave_sum_to_lane63(0.5f * q2s);
+            const float hi_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x101, 0xF, 0xF, true));
+            const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));
+            const float outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)my_id, k);
+            if (ocomp >= 0) atomicAdd(a.g2d + (size_t)gid * 10 + ocomp, outv);
+        }
+        walked += (uint32_t)cnt;
+    }
+    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
+}
+
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s) {
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
     const int grid = ((ntiles + 7) / 8) * 8;
+#define GS_V1(U, M) \
+    do { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_fwd_v1_kernel<true, U, M>), dim3(grid), dim3(64), 0, s, a); \
+         else hipLaunchKernelGGL((composite_fwd_v1_kernel<false, U, M>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); } while (0)
+    if (a.variant == 0) {                       // default: measured best on MI355X (tools/abtest.py)
+        if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_fwd_v2_kernel<true, 2, 1>), dim3(grid), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((composite_fwd_v2_kernel<false, 2, 8>), dim3(grid), dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
+#define GS_V2(U, M) \
+    do { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_fwd_v2_kernel<true, U, M>), dim3(grid), dim3(64), 0, s, a); \
+         else hipLaunchKernelGGL((composite_fwd_v2_kernel<false, U, M>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); } while (0)
+    if (a.variant == 10) GS_V2(2, 1);
+    if (a.variant == 11) GS_V2(2, 8);
+    if (a.variant == 12) GS_V2(1, 8);
+    if (a.variant == 1) GS_V1(2, 1);
+    if (a.variant == 2) GS_V1(1, 1);
+    if (a.variant == 3) GS_V1(2, 8);
+    if (a.variant == 4) GS_V1(1, 8);
+    if (a.variant == 5) GS_V1(4, 1);
     if (a.t_min > 0.0f) hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(grid), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(grid), dim3(64), 0, s, a);
     return hipGetLastError();
@@ -305,6 +789,20 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s) {
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
     const int grid = ((ntiles + 7) / 8) * 8;
+#define GS_B1(U, M) \
+    do { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_bwd_v1_kernel<true, U, M>), dim3(grid), dim3(64), 0, s, a); \
+         else hipLaunchKernelGGL((composite_bwd_v1_kernel<false, U, M>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); } while (0)
+    if (a.variant == 10) { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_bwd_v2_kernel<true, 1>), dim3(grid), dim3(64), 0, s, a);
+                           else hipLaunchKernelGGL((composite_bwd_v2_kernel<false, 1>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); }
+    if (a.variant == 11) { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_bwd_v2_kernel<true, 8>), dim3(grid), dim3(64), 0, s, a);
+                           else hipLaunchKernelGGL((composite_bwd_v2_kernel<false, 8>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); }
+    if (a.variant == 0) { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_bwd_v2_kernel<true, 1>), dim3(grid), dim3(64), 0, s, a);
+                          else hipLaunchKernelGGL((composite_bwd_v2_kernel<false, 8>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); }
+    if (a.variant == 1) GS_B1(1, 1);
+    if (a.variant == 2) GS_B1(2, 1);
+    if (a.variant == 3) GS_B1(1, 6);
+    if (a.variant == 4) GS_B1(1, 8);
+    if (a.variant == 5) GS_B1(2, 5);
     if (a.t_min > 0.0f) hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(grid), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(grid), dim3(64), 0, s, a);
     return hipGetLastError();

@@ -187,6 +187,11 @@ int gs_get_stage_stats(gs_ctx *ctx, double sum_ms[GS_STAGE_COUNT], int64_t count
  * (== gs_num_instances when t_min == 0; fewer with the transmittance early-out). */
 int gs_get_work_counters(gs_ctx *ctx, int64_t *walked_fwd, int64_t *walked_bwd);
 
+/* Profiling aid: re-launch the composite forward (which=0) or backward (which=1) kernel of the
+ * current frame `reps` times with kernel variant `variant` and return the mean hipEvent time.
+ * Backward gradients of these launches go to the internal 2-D gradient scratch only. */
+int gs_debug_time_composite(gs_ctx *ctx, int which, int variant, int reps, float *mean_ms);
+
 #ifdef __cplusplus
 }
 #endif

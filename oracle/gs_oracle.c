@@ -449,7 +449,7 @@ void gso_composite_forward(const gso_camera *cam, int tile, int gx, int gy,
                 float C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Tr = 1.0f;        /* :210-213 */
                 float fi = (float)i, fj = (float)j;
                 for (uint32_t k = s0; k < s1; ++k) {                     /* :224 */
-                    if (t_min > 0.0f && Tr < t_min) break;               /* extension: early-out */
+                    if (t_min > 0.0f && ((k - s0) % GSO_EARLY_BATCH) == 0 && Tr < t_min) break;   /* extension: early-out */
                     uint32_t b = ids[k];
                     float cz = tps[4 * (int64_t)b + 2];
                     if (cz < cam->near_ || cz > cam->far_) continue;     /* :227 */
@@ -697,7 +697,7 @@ void gso_backward(int64_t n, int sh_degree,
                     size_t m = 0;
                     float fi = (float)i, fj = (float)j;
                     for (uint32_t k = s0; k < s1; ++k) {
-                        if (t_min > 0.0f && Tr < (double)t_min) break;
+                        if (t_min > 0.0f && ((k - s0) % GSO_EARLY_BATCH) == 0 && Tr < (double)t_min) break;
                         uint32_t b = ids[k];
                         float cz = tps[4 * (int64_t)b + 2];
                         if (cz < cam->near_ || cz > cam->far_) continue;

@@ -83,7 +83,10 @@ int64_t gso_bin(int64_t n, const float *bbs, const float *tps, const uint32_t *p
 int64_t gso_bin_dense_literal(int64_t n, const float *bbs, int tile, int gx, int gy,
                               uint32_t *hitIdxs, int64_t maxBin);
 
-/* splat.jl:195-269.  t_min == 0 is the literal reference (no early-out). */
+/* splat.jl:195-269.  t_min == 0 is the literal reference (no early-out).  t_min > 0 (build
+ * extension): a pixel stops taking splats at the first list position that is a multiple of
+ * GSO_EARLY_BATCH (counted from the start of its tile's list) at which its T < t_min. */
+#define GSO_EARLY_BATCH 64
 void gso_composite_forward(const gso_camera *cam, int tile, int gx, int gy,
                            const uint32_t *ranges, const uint32_t *ids,
                            const float *mu, const float *invcov, const float *bbs,

@@ -18,6 +18,7 @@ f32 = np.float32
 f64 = np.float64
 
 ORDER_INDEX, ORDER_DEPTH_DESC, ORDER_DEPTH_ASC = 0, 1, 2
+EARLY_BATCH = 64
 
 
 def expf_spec(x):
@@ -309,9 +310,12 @@ def composite_forward(pre, ranges, ids, near, far, W, H, tile, gx, gy, t_min=0.0
             fj = np.broadcast_to(j.astype(f32)[:, None], (len(j), len(i)))
             C = np.zeros((3, len(j), len(i)), f32)
             Tr = np.ones((len(j), len(i)), f32)
+            dead = np.zeros_like(Tr, bool)
             for k in range(int(ranges[t, 0]), int(ranges[t, 1])):
                 b = int(ids[k])
-                live = np.ones_like(Tr, bool) if t_min <= 0 else ~(Tr < t_min)   # early-out extension
+                if t_min > 0 and (k - int(ranges[t, 0])) % EARLY_BATCH == 0:     # early-out extension: checked per batch
+                    dead |= (Tr < t_min)
+                live = ~dead
                 cz = tps[b, 2]
                 if (cz < near) or (cz > far):                                    # splat.jl:227
                     continue

@@ -75,14 +75,16 @@ def render(params, deg, T, P, fx, fy, eye, lookAt, near, far, W, H, ranges, ids,
         fi, fj = i[None, :].expand(len(j), len(i)), j[:, None].expand(len(j), len(i))
         C = torch.zeros(3, len(j), len(i), dtype=torch.float64)
         Tr = torch.ones(len(j), len(i), dtype=torch.float64)
+        dead = torch.zeros(len(j), len(i), dtype=torch.bool)
         for k in range(s0, s1):
             b = int(ids[k])
+            if t_min > 0 and (k - s0) % 64 == 0:
+                dead = dead | (Tr.detach() < t_min)
             if clipz32[b] < near or clipz32[b] > far:
                 continue
             bb = bbs32[b]
             hit = (fi >= float(bb[0])) & (fi <= float(bb[2])) & (fj >= float(bb[1])) & (fj <= float(bb[3]))
-            if t_min > 0:
-                hit = hit & ~(Tr.detach() < t_min)
+            hit = hit & ~dead
             if not bool(hit.any()):
                 continue
             dX, dY = fi - mux[b], fj - muy[b]

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""A/B timing of composite kernel variants on the C3 workload (GPU box)."""
+import sys, os, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from common import hip_context, scene_and_cameras
+from gaussiansplat_amd import synthetic, backend as B
+import torch
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+variants_f = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"])]
+variants_b = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0"])]
+n, W, H, deg = synthetic.CONFIGS[cfg]
+sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1234 + list(synthetic.CONFIGS).index(cfg))
+dC = synthetic.make_dC(W, H, 1)
+K3 = 3 * (deg + 1) ** 2
+out = {}
+for t_min in (0.0, 1e-5):
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=t_min)
+    ctx.preprocess(); ctx.bin(); img0, tr0 = ctx.forward_host()
+    g = ctx.grads_alloc(); ctx.backward(dC, g); ctx.synchronize()
+    for rnd in range(2):
+        for v in variants_f:
+            out[f"fwd t_min={t_min:g} v{v} r{rnd}"] = ctx.time_composite(0, v, 5)
+        for v in variants_b:
+            out[f"bwd t_min={t_min:g} v{v} r{rnd}"] = ctx.time_composite(1, v, 3)
+    ctx.close()
+for k, v in out.items():
+    print(f"{k:36s} {v:8.3f} ms")
