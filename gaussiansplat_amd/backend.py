@@ -25,7 +25,7 @@ STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges
 # every symbol include/gsplat.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
            "gs_synchronize", "gs_set_model", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
-           "gs_backward", "gs_reset_grads", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
+           "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_debug_time_composite")
 
 
@@ -79,6 +79,7 @@ def load():
     L.gs_bin.argtypes = [vp, C.c_int32, C.c_int32]
     L.gs_forward.argtypes = [vp, vp, vp, C.c_int]
     L.gs_backward.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads)]
+    L.gs_backward_ex.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads), C.c_int]
     L.gs_reset_grads.argtypes = [vp, C.POINTER(GsGrads)]
     L.gs_grads_alloc.argtypes = [vp, C.POINTER(GsGrads)]
     L.gs_grads_read.argtypes = [vp, C.POINTER(GsGrads), vp, vp, vp, vp, vp]
@@ -170,12 +171,13 @@ class Context:
     def forward_device(self, image_ptr: int = 0, trans_ptr: int = 0):
         self._chk(self.L.gs_forward(self.h, C.c_void_p(image_ptr), C.c_void_p(trans_ptr), GS_MEM_DEVICE))
 
-    def backward(self, dC_ptr_or_array, grads: GsGrads):
+    def backward(self, dC_ptr_or_array, grads: GsGrads, overwrite: bool = False):
+        flags = 1 if overwrite else 0          # GS_BWD_OVERWRITE
         if isinstance(dC_ptr_or_array, np.ndarray):
             a = np.ascontiguousarray(dC_ptr_or_array, np.float32)
-            self._chk(self.L.gs_backward(self.h, C.c_void_p(a.ctypes.data), GS_MEM_HOST, C.byref(grads)))
+            self._chk(self.L.gs_backward_ex(self.h, C.c_void_p(a.ctypes.data), GS_MEM_HOST, C.byref(grads), flags))
         else:
-            self._chk(self.L.gs_backward(self.h, C.c_void_p(int(dC_ptr_or_array)), GS_MEM_DEVICE, C.byref(grads)))
+            self._chk(self.L.gs_backward_ex(self.h, C.c_void_p(int(dC_ptr_or_array)), GS_MEM_DEVICE, C.byref(grads), flags))
 
     def grads_alloc(self) -> GsGrads:
         """Library-owned flat gradient buffer (for hosts without a device allocator, e.g. plain Julia)."""

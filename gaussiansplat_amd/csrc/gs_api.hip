@@ -71,6 +71,7 @@ struct gs_ctx {
     int64_t ev_cnt[GS_STAGE_COUNT] = {};
     DevBuf counters;                         // 2 x u64: entries walked fwd / bwd
     DevBuf grads_flat;                       // gs_grads_alloc
+    DevBuf dpc;                              // 4 x n scratch between the two backward kernels
 };
 
 namespace {
@@ -173,7 +174,7 @@ int gs_destroy(gs_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
-                      &c->counters, &c->grads_flat};
+                      &c->counters, &c->grads_flat, &c->dpc};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->model) b.release();
     for (auto &b : c->dbg) b.release();
@@ -371,7 +372,9 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     return GS_OK;
 }
 
-int gs_backward(gs_ctx *c, const float *dC, int mem, const gs_grads *grads) {
+int gs_backward(gs_ctx *c, const float *dC, int mem, const gs_grads *grads) { return gs_backward_ex(c, dC, mem, grads, 0); }
+
+int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, int flags) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_backward: gs_forward first");
     if (!dC || !grads) return fail(c, GS_ERR_INVALID, "gs_backward: NULL argument");
@@ -403,6 +406,9 @@ int gs_backward(gs_ctx *c, const float *dC, int mem, const gs_grads *grads) {
     b.n = c->n; b.sh_degree = c->sh_degree;
     b.means = c->means; b.scales = c->scales; b.quats = c->quats; b.opac = c->opac; b.shs = c->shs;
     b.g2d = c->g2d.as<float>();
+    HIPCHK(c, c->dpc.ensure(sizeof(float) * 4 * n1));
+    b.dpc = c->dpc.as<float>();
+    b.overwrite = (flags & GS_BWD_OVERWRITE) ? 1 : 0;
     b.d_means = grads->d_means; b.d_scales = grads->d_scales; b.d_quats = grads->d_quats;
     b.d_opac = grads->d_opacities; b.d_shs = grads->d_shs;
     {

@@ -90,6 +90,8 @@ struct GsPreprocessBwdArgs {
     int sh_degree;
     const float *means, *scales, *quats, *opac, *shs;
     const float *g2d;
-    float *d_means, *d_scales, *d_quats, *d_opac, *d_shs;   // accumulate (+=); may be null
+    float *d_means, *d_scales, *d_quats, *d_opac, *d_shs;   // accumulate (+=) or overwrite; may be null
+    float *dpc;           // scratch 4 x n: d L / d tps[1:3] through the colour
+    int overwrite;        // 1: store instead of accumulate
 };
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s);

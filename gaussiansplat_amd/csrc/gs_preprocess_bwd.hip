@@ -9,11 +9,16 @@
 // splat.jl:175-193), including its quirks: R22 = 1 - 2(x^2 - z^2), the gaussian's own R in
 // J*R, +0.3 on all four covariance entries, clip-space view direction for SH.
 //
-// One thread per gaussian, no atomics (each thread owns its rows).  HBM-bound: reads
-// 4*(11+3K)+40 B, writes 4*(11+3K) B per gaussian (read-modify-write for the += contract).
-// The SH rows (3K floats = 192 B at degree 3, thread-strided in HBM) are staged through an
-// LDS tile [256][3K+1]: coalesced block loads, conflict-free per-thread rows (odd stride),
-// gradients written back into the same tile and added to d_shs with coalesced accesses.
+// Two kernels, one thread per gaussian, no atomics (each thread owns its rows); HBM-bound:
+//   gs_sh_bwd_kernel    d rgb -> d shs, plus d rgb / d(clip position) handed to the second kernel
+//                       (16 B/gaussian).  The SH rows (3K floats = 192 B at degree 3, thread-strided in
+//                       HBM) go through an LDS tile [256][3K+1]: coalesced block loads, conflict-free
+//                       per-thread rows (odd stride), gradients written back into the same tile and
+//                       stored/added to d_shs with coalesced accesses.
+//   gs_geom_bwd_kernel  d{mu', invCov2d, sig} -> d{means, scales, quaternions, opacities}.
+// Splitting keeps both under 128 VGPRs (the fused version needed 168 + spills).
+// `overwrite` stores instead of accumulating: used for the first backward after resetGrads, so
+// the reset needs no 4(11+3K)-byte/gaussian zero fill and this pass no read of the old gradients.
 #include "gs_common.h"
 
 #define SH_C0 0.28209479177387814f
@@ -23,8 +28,8 @@ __constant__ float bC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.315391
 __constant__ float bC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                              -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
-template <int DEG>
-__global__ __launch_bounds__(256, 3) void gs_preprocess_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
+template <int DEG, bool OVERWRITE>
+__global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
     constexpr int K = (DEG + 1) * (DEG + 1);
     constexpr int ROW = 3 * K + 1;
     extern __shared__ __attribute__((aligned(16))) float tile[];       // [256][ROW]
@@ -35,8 +40,73 @@ __global__ __launch_bounds__(256, 3) void gs_preprocess_bwd_kernel(GsPreprocessB
     __syncthreads();
     const int64_t g = gb + threadIdx.x;
     if (g < a.n) {
+        const float *g2 = a.g2d + 10 * g;
+        const float grgb[3] = {g2[0], g2[1], g2[2]};
+        const float *T = cam.T, *P = cam.P;
+        const float m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
+        float t[4], p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = T[i] * m1 + T[i + 4] * m2 + T[i + 8] * m3 + T[i + 12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = P[i] * t[0] + P[i + 4] * t[1] + P[i + 8] * t[2] + P[i + 12] * t[3];
+        // ---- rgb(sh, dir(p)), splat.jl:180-193
+        const float v0 = p[0] - (cam.lookAt[0] - cam.eye[0]);
+        const float v1 = p[1] - (cam.lookAt[1] - cam.eye[1]);
+        const float v2 = p[2] - (cam.lookAt[2] - cam.eye[2]);
+        const float inrm = rsqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+        const float X = v0 * inrm, Y = v1 * inrm, Z = v2 * inrm;
+        float bs[K], cs[K];
+        bs[0] = SH_C0;
+        if constexpr (DEG >= 1) { bs[1] = -Y * SH_C1; bs[2] = Z * SH_C1; bs[3] = -X * SH_C1; }
+        if constexpr (DEG >= 2) {
+            const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+            bs[4] = bC2[0] * xy; bs[5] = bC2[1] * yz; bs[6] = bC2[2] * (2 * zz - xx - yy); bs[7] = bC2[3] * xz; bs[8] = bC2[4] * (xx - yy);
+            if constexpr (DEG >= 3) {
+                bs[9] = bC3[0] * Y * (3 * xx - yy); bs[10] = bC3[1] * xy * Z; bs[11] = bC3[2] * Y * (4 * zz - xx - yy);
+                bs[12] = bC3[3] * Z * (2 * zz - 3 * xx - 3 * yy); bs[13] = bC3[4] * X * (4 * zz - xx - yy);
+                bs[14] = bC3[5] * Z * (xx - yy); bs[15] = bC3[6] * X * (xx - 3 * yy);
+            }
+        }
+        float *sh = tile + threadIdx.x * ROW;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            cs[k] = grgb[0] * sh[3 * k] + grgb[1] * sh[3 * k + 1] + grgb[2] * sh[3 * k + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sh[c + 3 * k] = bs[k] * grgb[c];   // the tile now carries d L / d sh
+        }
+        float ddir[3] = {0.0f, 0.0f, 0.0f};
+        if constexpr (DEG >= 1) { ddir[0] += -SH_C1 * cs[3]; ddir[1] += -SH_C1 * cs[1]; ddir[2] += SH_C1 * cs[2]; }
+        if constexpr (DEG >= 2) {
+            ddir[0] += bC2[0] * Y * cs[4] - 2 * bC2[2] * X * cs[6] + bC2[3] * Z * cs[7] + 2 * bC2[4] * X * cs[8];
+            ddir[1] += bC2[0] * X * cs[4] + bC2[1] * Z * cs[5] - 2 * bC2[2] * Y * cs[6] - 2 * bC2[4] * Y * cs[8];
+            ddir[2] += bC2[1] * Y * cs[5] + 4 * bC2[2] * Z * cs[6] + bC2[3] * X * cs[7];
+        }
+        if constexpr (DEG >= 3) {
+            const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+            ddir[0] += 6 * bC3[0] * xy * cs[9] + bC3[1] * yz * cs[10] - 2 * bC3[2] * xy * cs[11] - 6 * bC3[3] * xz * cs[12]
+                       + bC3[4] * (4 * zz - 3 * xx - yy) * cs[13] + 2 * bC3[5] * xz * cs[14] + bC3[6] * (3 * xx - 3 * yy) * cs[15];
+            ddir[1] += bC3[0] * (3 * xx - 3 * yy) * cs[9] + bC3[1] * xz * cs[10] + bC3[2] * (4 * zz - xx - 3 * yy) * cs[11]
+                       - 6 * bC3[3] * yz * cs[12] - 2 * bC3[4] * xy * cs[13] - 2 * bC3[5] * yz * cs[14] - 6 * bC3[6] * xy * cs[15];
+            ddir[2] += bC3[1] * xy * cs[10] + 8 * bC3[2] * yz * cs[11] + bC3[3] * (6 * zz - 3 * xx - 3 * yy) * cs[12]
+                       + 8 * bC3[4] * xz * cs[13] + bC3[5] * (xx - yy) * cs[14];
+        }
+        const float dd = X * ddir[0] + Y * ddir[1] + Z * ddir[2];
+        // d L / d tps[1:3] through the colour (dir = normalize(tps[1:3] - (lookAt - eye)))
+        reinterpret_cast<float4 *>(a.dpc)[g] = make_float4((ddir[0] - X * dd) * inrm, (ddir[1] - Y * dd) * inrm, (ddir[2] - Z * dd) * inrm, 0.0f);
+    }
+    __syncthreads();
+    if (a.d_shs)
+        for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x) {
+            const float v = tile[(idx / (3 * K)) * ROW + idx % (3 * K)];
+            if (OVERWRITE) a.d_shs[gb * 3 * K + idx] = v; else a.d_shs[gb * 3 * K + idx] += v;
+        }
+}
+
+template <bool OVERWRITE>
+__global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n) return;
     const float *g2 = a.g2d + 10 * g;
-    const float grgb[3] = {g2[0], g2[1], g2[2]};
     const float gsig = g2[3], gmx = g2[4], gmy = g2[5];
     // G[r][c] = dL/dM[r][c]; the composite kernel stores the symmetric off-diagonal once (slot 7)
     const float G[2][2] = {{g2[6], g2[7]}, {g2[7], g2[9]}};
@@ -49,55 +119,8 @@ __global__ __launch_bounds__(256, 3) void gs_preprocess_bwd_kernel(GsPreprocessB
     for (int i = 0; i < 4; ++i) t[i] = T[i] * m1 + T[i + 4] * m2 + T[i + 8] * m3 + T[i + 12];
 #pragma unroll
     for (int i = 0; i < 4; ++i) p[i] = P[i] * t[0] + P[i + 4] * t[1] + P[i + 8] * t[2] + P[i + 12] * t[3];
-    float dt[4] = {0, 0, 0, 0}, dp[4] = {0, 0, 0, 0};
-    // ---- rgb(sh, dir(p))
-    const float v0 = p[0] - (cam.lookAt[0] - cam.eye[0]);
-    const float v1 = p[1] - (cam.lookAt[1] - cam.eye[1]);
-    const float v2 = p[2] - (cam.lookAt[2] - cam.eye[2]);
-    const float inrm = rsqrtf(v0 * v0 + v1 * v1 + v2 * v2);
-    const float dxn = v0 * inrm, dyn = v1 * inrm, dzn = v2 * inrm;
-    // basis values (kept), then cs[k] = sum_c grgb[c]*sh[c,k]; the derivative of every basis
-    // polynomial is applied inline (no per-coefficient gradient table: keeps VGPRs low)
-    const float X = dxn, Y = dyn, Z = dzn;
-    float bs[K], cs[K];
-    bs[0] = SH_C0;
-    if constexpr (DEG >= 1) { bs[1] = -Y * SH_C1; bs[2] = Z * SH_C1; bs[3] = -X * SH_C1; }
-    if constexpr (DEG >= 2) {
-        const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
-        bs[4] = bC2[0] * xy; bs[5] = bC2[1] * yz; bs[6] = bC2[2] * (2 * zz - xx - yy); bs[7] = bC2[3] * xz; bs[8] = bC2[4] * (xx - yy);
-        if constexpr (DEG >= 3) {
-            bs[9] = bC3[0] * Y * (3 * xx - yy); bs[10] = bC3[1] * xy * Z; bs[11] = bC3[2] * Y * (4 * zz - xx - yy);
-            bs[12] = bC3[3] * Z * (2 * zz - 3 * xx - 3 * yy); bs[13] = bC3[4] * X * (4 * zz - xx - yy);
-            bs[14] = bC3[5] * Z * (xx - yy); bs[15] = bC3[6] * X * (xx - 3 * yy);
-        }
-    }
-    float *sh = tile + threadIdx.x * ROW;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        cs[k] = grgb[0] * sh[3 * k] + grgb[1] * sh[3 * k + 1] + grgb[2] * sh[3 * k + 2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) sh[c + 3 * k] = bs[k] * grgb[c];   // the tile now carries d L / d sh
-    }
-    float ddir[3] = {0.0f, 0.0f, 0.0f};
-    if constexpr (DEG >= 1) { ddir[0] += -SH_C1 * cs[3]; ddir[1] += -SH_C1 * cs[1]; ddir[2] += SH_C1 * cs[2]; }
-    if constexpr (DEG >= 2) {
-        ddir[0] += bC2[0] * Y * cs[4] - 2 * bC2[2] * X * cs[6] + bC2[3] * Z * cs[7] + 2 * bC2[4] * X * cs[8];
-        ddir[1] += bC2[0] * X * cs[4] + bC2[1] * Z * cs[5] - 2 * bC2[2] * Y * cs[6] - 2 * bC2[4] * Y * cs[8];
-        ddir[2] += bC2[1] * Y * cs[5] + 4 * bC2[2] * Z * cs[6] + bC2[3] * X * cs[7];
-    }
-    if constexpr (DEG >= 3) {
-        const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
-        ddir[0] += 6 * bC3[0] * xy * cs[9] + bC3[1] * yz * cs[10] - 2 * bC3[2] * xy * cs[11] - 6 * bC3[3] * xz * cs[12]
-                   + bC3[4] * (4 * zz - 3 * xx - yy) * cs[13] + 2 * bC3[5] * xz * cs[14] + bC3[6] * (3 * xx - 3 * yy) * cs[15];
-        ddir[1] += bC3[0] * (3 * xx - 3 * yy) * cs[9] + bC3[1] * xz * cs[10] + bC3[2] * (4 * zz - xx - 3 * yy) * cs[11]
-                   - 6 * bC3[3] * yz * cs[12] - 2 * bC3[4] * xy * cs[13] - 2 * bC3[5] * yz * cs[14] - 6 * bC3[6] * xy * cs[15];
-        ddir[2] += bC3[1] * xy * cs[10] + 8 * bC3[2] * yz * cs[11] + bC3[3] * (6 * zz - 3 * xx - 3 * yy) * cs[12]
-                   + 8 * bC3[4] * xz * cs[13] + bC3[5] * (xx - yy) * cs[14];
-    }
-    const float dd = dxn * ddir[0] + dyn * ddir[1] + dzn * ddir[2];
-    dp[0] += (ddir[0] - dxn * dd) * inrm;
-    dp[1] += (ddir[1] - dyn * dd) * inrm;
-    dp[2] += (ddir[2] - dzn * dd) * inrm;
+    const float4 dpc = reinterpret_cast<const float4 *>(a.dpc)[g];
+    float dt[4] = {0, 0, 0, 0}, dp[4] = {dpc.x, dpc.y, dpc.z, 0.0f};
     const float tx = t[0], ty = t[1], tz = t[2], fx = cam.fx, fy = cam.fy;
     const float itz = 1.0f / tz, itz2 = itz * itz;
     const float J[2][3] = {{fx * itz, 0.0f, -fx * tx * itz2}, {0.0f, fy * itz, -fy * ty * itz2}};
@@ -204,26 +227,27 @@ __global__ __launch_bounds__(256, 3) void gs_preprocess_bwd_kernel(GsPreprocessB
         for (int i = 0; i < 4; ++i) dt[j] += P[i + 4 * j] * dp[i];
     if (a.d_means) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            a.d_means[3 * g + j] += T[4 * j] * dt[0] + T[1 + 4 * j] * dt[1] + T[2 + 4 * j] * dt[2] + T[3 + 4 * j] * dt[3];
+        for (int j = 0; j < 3; ++j) {
+            const float v = T[4 * j] * dt[0] + T[1 + 4 * j] * dt[1] + T[2 + 4 * j] * dt[2] + T[3 + 4 * j] * dt[3];
+            if (OVERWRITE) a.d_means[3 * g + j] = v; else a.d_means[3 * g + j] += v;
+        }
     }
     if (a.d_scales) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) a.d_scales[3 * g + j] += de[j] * e[j];
+        for (int j = 0; j < 3; ++j) { if (OVERWRITE) a.d_scales[3 * g + j] = de[j] * e[j]; else a.d_scales[3 * g + j] += de[j] * e[j]; }
     }
     if (a.d_quats) {
-        a.d_quats[4 * g] += dw; a.d_quats[4 * g + 1] += dx; a.d_quats[4 * g + 2] += dy; a.d_quats[4 * g + 3] += dz;
+        float4 *q = reinterpret_cast<float4 *>(a.d_quats) + g;
+        float4 o = OVERWRITE ? make_float4(0.f, 0.f, 0.f, 0.f) : *q;
+        o.x += dw; o.y += dx; o.z += dy; o.w += dz;
+        *q = o;
     }
     if (a.d_opac) {
         const float ez = __expf(a.opac[g]);
         const float sg = ez / (1.0f + ez);
-        a.d_opac[g] += gsig * sg * (1.0f - sg);
+        const float v = gsig * sg * (1.0f - sg);
+        if (OVERWRITE) a.d_opac[g] = v; else a.d_opac[g] += v;
     }
-    }   // g < n
-    __syncthreads();
-    if (a.d_shs)
-        for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x)
-            a.d_shs[gb * 3 * K + idx] += tile[(idx / (3 * K)) * ROW + idx % (3 * K)];
 }
 
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s) {
@@ -231,12 +255,16 @@ hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera
     const dim3 block(256), grid((unsigned)((a.n + 255) / 256));
     const int K = (a.sh_degree + 1) * (a.sh_degree + 1);
     const size_t lds = sizeof(float) * 256 * (3 * K + 1);
+#define GS_SH(D) do { if (a.overwrite) hipLaunchKernelGGL((gs_sh_bwd_kernel<D, true>), grid, block, lds, s, a, cam); \
+                      else hipLaunchKernelGGL((gs_sh_bwd_kernel<D, false>), grid, block, lds, s, a, cam); } while (0)
     switch (a.sh_degree) {
-        case 0: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<0>, grid, block, lds, s, a, cam); break;
-        case 1: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<1>, grid, block, lds, s, a, cam); break;
-        case 2: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<2>, grid, block, lds, s, a, cam); break;
-        case 3: hipLaunchKernelGGL(gs_preprocess_bwd_kernel<3>, grid, block, lds, s, a, cam); break;
+        case 0: GS_SH(0); break;
+        case 1: GS_SH(1); break;
+        case 2: GS_SH(2); break;
+        case 3: GS_SH(3); break;
         default: return hipErrorInvalidValue;
     }
+    if (a.overwrite) hipLaunchKernelGGL(gs_geom_bwd_kernel<true>, grid, block, 0, s, a, cam);
+    else hipLaunchKernelGGL(gs_geom_bwd_kernel<false>, grid, block, 0, s, a, cam);
     return hipGetLastError();
 }

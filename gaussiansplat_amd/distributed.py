@@ -52,7 +52,10 @@ class HipViewRenderer:
 
     def __init__(self, renderer):
         self.r = renderer
-        self.flat = renderer.splatGrads.flat
+
+    @property
+    def flat(self):
+        return self.r.splatGrads.flat
 
     def reset(self) -> None:
         from . import renderer as R

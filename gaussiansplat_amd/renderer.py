@@ -76,7 +76,8 @@ class GaussianRenderer3D:               # renderer.jl:205-219
                  t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False):
         import torch
         self.splatData = splatData
-        self.splatGrads = initGrads(splatData)
+        self._splatGrads = initGrads(splatData)
+        self._grads_lazy_zero = False       # resetGrads() pending: the next backward overwrites
         W, H = int(imgSize[0]), int(imgSize[1])
         dev = splatData.means.device
         self.imageData = torch.zeros((3, H, W), dtype=torch.float32, device=dev)      # CUDA.zeros(imgSize...)
@@ -92,9 +93,22 @@ class GaussianRenderer3D:               # renderer.jl:205-219
         self.ctx.set_model_device(self.nGaussians, sh_degree,
                                   [t.data_ptr() for t in (splatData.means, splatData.scales, splatData.quaternions,
                                                           splatData.opacities, splatData.shs)])
-        g = self.splatGrads
+        g = self._splatGrads
         self._grads = B.GsGrads(g.Δmeans.data_ptr(), g.Δscales.data_ptr(), g.Δquaternions.data_ptr(),
                                 g.Δopacities.data_ptr(), g.Δshs.data_ptr())
+
+    @property
+    def splatGrads(self) -> SplatGrads3D:
+        """renderer.splatGrads (renderer.jl:207).  resetGrads is lazy: the zero fill is skipped when the
+        next backward overwrites anyway, and materialised here if somebody looks first."""
+        if self._grads_lazy_zero:
+            import torch
+            self._begin()
+            with torch.cuda.stream(self.stream):
+                self._splatGrads.flat.zero_()
+            self._end()
+            self._grads_lazy_zero = False
+        return self._splatGrads
 
     def _begin(self):
         import torch
@@ -209,7 +223,8 @@ def backward(renderer: GaussianRenderer3D, ΔC):
     assert dC.shape == renderer.imageData.shape
     renderer._dC_keepalive = dC
     renderer._begin()
-    renderer.ctx.backward(dC.data_ptr(), renderer._grads)
+    renderer.ctx.backward(dC.data_ptr(), renderer._grads, overwrite=renderer._grads_lazy_zero)
+    renderer._grads_lazy_zero = False
     renderer._end()
 
 
@@ -217,10 +232,6 @@ def resetGrads(renderer_or_grads):
     """splat.jl:158-173."""
     import torch
     if isinstance(renderer_or_grads, GaussianRenderer3D):
-        r = renderer_or_grads
-        r._begin()
-        with torch.cuda.stream(r.stream):
-            r.splatGrads.flat.zero_()
-        r._end()
+        renderer_or_grads._grads_lazy_zero = True      # zero fill deferred: see GaussianRenderer3D.splatGrads
     else:
         renderer_or_grads.flat.zero_()

@@ -132,6 +132,12 @@ typedef struct {              /* SplatGrads3D, splat.jl:45-52; any pointer may b
  * Requires gs_forward on the same frame. */
 int gs_backward(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads);
 
+/* gs_backward with flags.  GS_BWD_OVERWRITE: store the gradients instead of accumulating -- for
+ * the first backward after a reset, so the caller can skip the zero fill and this pass skips
+ * the read of the old values (the result equals reset + accumulate). */
+#define GS_BWD_OVERWRITE 1
+int gs_backward_ex(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads, int flags);
+
 /* resetGrads: zero the arrays of `grads` (DEVICE pointers) on the ctx stream. */
 int gs_reset_grads(gs_ctx *ctx, const gs_grads *grads);
 
