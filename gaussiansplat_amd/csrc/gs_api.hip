@@ -148,6 +148,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (c0.tile_size != GS_TILE) return fail(nullptr, GS_ERR_UNSUPPORTED, "gs_create: only tile_size 16 is supported (reference threads=(16,16))");
     if (c0.order < GS_ORDER_INDEX || c0.order > GS_ORDER_DEPTH_ASC) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad order");
     if (!(c0.t_min >= 0.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: t_min must be >= 0");
+    if (c0.deterministic) return fail(nullptr, GS_ERR_UNSUPPORTED, "gs_create: deterministic gradient reduction is not implemented yet (float atomics only)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -330,7 +331,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
         StageTimer t(c, GS_STAGE_TILE_SORT);
         int tile_bits = 1;
         while ((1LL << tile_bits) < ntiles) ++tile_bits;
-        const int hi = 32 + ((tile_bits + 7) / 8) * 8;
+        const int hi = 32 + tile_bits;                 // only the bits the tile ids use
         int in_b = 0;
         HIPCHK(c, gs_radix_sort_u64(c->inst_a.as<uint64_t>(), c->inst_b.as<uint64_t>(), c->n_inst, 32, hi, c->table.as<uint32_t>(),
                                     c->digit_total.as<uint32_t>(), &in_b, c->stream));

@@ -27,7 +27,7 @@ size_t gs_sort_table_entries(int64_t n_max) {
 }
 
 // ---------------------------------------------------------------- radix pass: histogram
-__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, int64_t n, int shift,
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, int64_t n, int shift, uint32_t mask,
                                                               uint32_t *__restrict__ block_hist, int nblocks) {
     __shared__ uint32_t h[RS_RADIX];
     h[threadIdx.x] = 0;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__r
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
         const int64_t idx = base + (int64_t)i * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & (RS_RADIX - 1)], 1u);
+        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
     block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];   // [digit][block]
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
 // the set of lanes holding the same digit) and a per-wave running LDS counter; keys are then
 // placed digit-contiguously in LDS and written out in runs.
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                                 int64_t n, int shift, const uint32_t *__restrict__ block_hist,
-                                                                 int nblocks) {
+                                                                 int64_t n, int shift, uint32_t mask,
+                                                                 const uint32_t *__restrict__ block_hist, int nblocks) {
     __shared__ uint64_t skeys[RS_CHUNK];                 // 32 KiB
     __shared__ uint32_t wcnt[RS_WAVES][RS_RADIX];        // running count per (wave, digit)
     __shared__ uint32_t lpre[RS_RADIX];                  // exclusive prefix over digits in this chunk
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
         const int li = w * (GS_WAVE * RS_ITEMS) + r * GS_WAVE + lane;    // index inside the chunk
         const bool valid = li < cnt;
         key[r] = valid ? in[base + li] : ~0ull;
-        const uint32_t dg = (uint32_t)(key[r] >> shift) & (RS_RADIX - 1);
+        const uint32_t dg = valid ? ((uint32_t)(key[r] >> shift) & mask) : (RS_RADIX - 1);
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     for (int r = 0; r < RS_ITEMS; ++r) {
         const int li = w * (GS_WAVE * RS_ITEMS) + r * GS_WAVE + lane;
         if (li < cnt) {
-            const uint32_t dg = (uint32_t)(key[r] >> shift) & (RS_RADIX - 1);
+            const uint32_t dg = (uint32_t)(key[r] >> shift) & mask;
             skeys[lpre[dg] + wcnt[w][dg] + rank[r]] = key[r];
         }
     }
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
         const int li = r * RS_THREADS + tid;
         if (li < cnt) {
             const uint64_t k = skeys[li];
-            const uint32_t dg = (uint32_t)(k >> shift) & (RS_RADIX - 1);
+            const uint32_t dg = (uint32_t)(k >> shift) & mask;
             out[(size_t)gbase[dg] + (uint32_t)(li - (int)lpre[dg])] = k;
         }
     }
@@ -186,11 +186,17 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
     if (n <= 0) return hipSuccess;
     const int nblocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
     uint64_t *src = a, *dst = b;
-    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, n, shift, block_hist, nblocks);
+    // equal-width digits of at most 8 bits: fewer bins per pass = longer contiguous runs in the scatter
+    const int total = bit_hi - bit_lo;
+    const int passes = (total + 7) / 8;
+    const int width = (total + passes - 1) / passes;
+    for (int shift = bit_lo; shift < bit_hi; shift += width) {
+        const int bits = (bit_hi - shift) < width ? (bit_hi - shift) : width;
+        const uint32_t mask = (1u << bits) - 1u;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, n, shift, mask, block_hist, nblocks);
         hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, block_hist, nblocks);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks);
         uint64_t *t = src; src = dst; dst = t;
         *result_in_b ^= 1;
     }

@@ -116,3 +116,36 @@ def test_backward_gradients(oracle, n, W, H, deg, seed, order, t_min):
     ctx.reset_grads(grads); ctx.synchronize()
     assert float(flat.abs().max()) == 0.0
     ctx.close()
+
+
+@pytest.mark.parametrize("t_min", [0.2, 1e-3, 1e-5])
+def test_early_out_dense_scene_matches_oracle_rule(oracle, t_min):
+    """Lists of several hundred entries per tile, so the per-batch freeze really triggers: the HIP
+    path must follow the oracle's rule (pixels AND gradients), and stay within t_min*max|rgb| of literal."""
+    import torch
+    from gaussiansplat_amd import backend as B
+    from gaussiansplat_amd import synthetic
+    O = oracle
+    n, W, H, deg = 4000, 80, 56, 2
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 17)
+    sc["scales"] = sc["scales"] + np.float32(1.2)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=t_min)
+    assert int((ref["ranges"][:, 1] - ref["ranges"][:, 0]).max()) > 4 * 64
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=t_min)
+    ctx.preprocess(); ctx.bin()
+    img, tr = ctx.forward_host()
+    assert np.all(np.abs(img - ref["image"]) <= PIX_ATOL + PIX_RTOL * np.abs(ref["image"]))
+    assert np.all(np.abs(tr - ref["trans"]) <= PIX_ATOL + PIX_RTOL * np.abs(ref["trans"]))
+    if t_min >= 1e-3:                                                   # the rule really froze pixels in this scene
+        lit = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=0.0)
+        assert not np.array_equal(lit["trans"], ref["trans"])
+        assert np.abs(img - lit["image"]).max() <= 4.0 * t_min
+    dC = synthetic.make_dC(W, H, 17)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC,
+                      t_min=t_min)
+    g = ctx.grads_alloc()
+    ctx.backward(dC, g)
+    got = ctx.grads_read(g, deg)
+    for k in ("means", "scales", "quats", "opacities", "shs"):
+        assert rel_l2(got[k].reshape(-1), gref[k].reshape(-1)) <= GRAD_REL_L2, (k, rel_l2(got[k].reshape(-1), gref[k].reshape(-1)))
+    ctx.close()

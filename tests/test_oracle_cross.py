@@ -31,6 +31,28 @@ def test_c_vs_numpy_bit_exact(oracle, n, W, H, deg, seed):
             assert np.array_equal(img, img2, equal_nan=True) and np.array_equal(tr, tr2, equal_nan=True)
 
 
+def test_early_out_rule_triggers_and_restatements_agree(oracle):
+    """Dense scene (lists >> 64): pixels are frozen at 64-entry batch boundaries once T < t_min."""
+    O = oracle
+    n, W, H, deg = 4000, 64, 48, 1
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 9)
+    sc["scales"] += 1.2                                            # bigger footprints -> long lists
+    pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam)
+    pre2 = NP.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, T, P, cam.fx, cam.fy,
+                         cam.eye, cam.lookAt, W, H)
+    gx, gy = W // 16, H // 16
+    r, i, k = O.bin_lists(pre["bbs"], pre["tps"], 1, 16, gx, gy)
+    assert int((r[:, 1] - r[:, 0]).min()) > 3 * 64
+    lit, lit_t = O.composite_forward(pre, r, i, ocam, 16, gx, gy, t_min=0.0)
+    for t_min in (0.2, 1e-3):
+        img, tr = O.composite_forward(pre, r, i, ocam, 16, gx, gy, t_min=t_min)
+        img2, tr2 = NP.composite_forward(pre2, r, i, cam.near, cam.far, W, H, 16, gx, gy, t_min=t_min)
+        assert np.array_equal(img, img2) and np.array_equal(tr, tr2)
+        assert not np.array_equal(tr, lit_t)                        # the rule did cut something
+        assert np.abs(img - lit).max() <= t_min * 4.0               # what is cut is bounded by t_min * max|rgb|
+        assert (tr[tr != lit_t] < t_min).all()                      # frozen pixels stopped below the threshold
+
+
 def test_expf_spec_matches_and_is_accurate(oracle):
     xs = np.concatenate([np.linspace(-100, 100, 4001), [0.0, -0.0, 88.72283, 88.7229, -87.33654, -87.3366, np.nan, np.inf, -np.inf]]).astype(np.float32)
     c = np.array([oracle.expf(float(x)) for x in xs], np.float32)
