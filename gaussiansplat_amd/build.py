@@ -23,6 +23,7 @@ SOURCES = {
     "gs_preprocess.hip": ["-ffp-contract=off"],
     "gs_preprocess_bwd.hip": [],
     "gs_sort.hip": [],
+    "gs_bin2.hip": [],
     "gs_composite.hip": [],
     "gs_api.hip": [],
 }

@@ -57,7 +57,7 @@ struct gs_ctx {
     DevBuf payload, depth_key, rect, pairs_a, pairs_b, perm, offsets, block_sums;
     DevBuf inst_a, inst_b, table, digit_total, ranges, image, trans, g2d, stage_in;
     DevBuf dbg[7];
-    uint64_t *inst_sorted = nullptr;
+    DevBuf ids, words, cs, diff;             // sorted gaussian ids; pass-1 words; chunk owners; 2-D difference array
     uint32_t *perm_ptr = nullptr;
     int64_t n_inst = 0;
     uint32_t *pinned = nullptr;
@@ -175,7 +175,7 @@ int gs_destroy(gs_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
-                      &c->counters, &c->grads_flat, &c->dpc};
+                      &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->model) b.release();
     for (auto &b : c->dbg) b.release();
@@ -318,28 +318,57 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     harvest_events(c);
     c->n_inst = (int64_t)c->pinned[0];
     const size_t ni1 = c->n_inst ? (size_t)c->n_inst : 1;
-    HIPCHK(c, c->inst_a.ensure(sizeof(uint64_t) * ni1));
-    HIPCHK(c, c->inst_b.ensure(sizeof(uint64_t) * ni1));
     HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
     HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 256));
     HIPCHK(c, c->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)(ntiles ? ntiles : 1)));
-    {
-        StageTimer t(c, GS_STAGE_EMIT);
-        HIPCHK(c, gs_launch_emit(c->rect.as<uint16_t>(), perm, c->offsets.as<uint32_t>(), c->inst_a.as<uint64_t>(), c->n, c->gx, c->stream));
-    }
-    {
-        StageTimer t(c, GS_STAGE_TILE_SORT);
-        int tile_bits = 1;
-        while ((1LL << tile_bits) < ntiles) ++tile_bits;
-        const int hi = 32 + tile_bits;                 // only the bits the tile ids use
-        int in_b = 0;
-        HIPCHK(c, gs_radix_sort_u64(c->inst_a.as<uint64_t>(), c->inst_b.as<uint64_t>(), c->n_inst, 32, hi, c->table.as<uint32_t>(),
-                                    c->digit_total.as<uint32_t>(), &in_b, c->stream));
-        c->inst_sorted = in_b ? c->inst_b.as<uint64_t>() : c->inst_a.as<uint64_t>();
-    }
-    {
-        StageTimer t(c, GS_STAGE_RANGES);
-        HIPCHK(c, gs_launch_ranges(c->inst_sorted, c->n_inst, c->ranges.as<uint32_t>(), ntiles, c->stream));
+    HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * ni1));
+    int tile_bits = 1;
+    while ((1LL << tile_bits) < ntiles) ++tile_bits;
+    int gid_bits = 1;
+    while ((1LL << gid_bits) < c->n) ++gid_bits;
+    const int passes = (tile_bits + 7) / 8;
+    const int lo_bits = passes <= 1 ? tile_bits : (tile_bits + 1) / 2, hi_bits = tile_bits - lo_bits;
+    const bool fast = c->cfg.bin_path == 0 && passes <= 2 && hi_bits + gid_bits <= 32 && gs_tile_ranges_supported(c->gx, c->gy);
+    if (fast) {
+        // ---- generate-in-pass binning on 32-bit words (gs_bin2.hip)
+        const size_t nchunks = ((size_t)c->n_inst + 4095) / 4096;
+        HIPCHK(c, c->cs.ensure(sizeof(uint32_t) * (nchunks + 2)));
+        HIPCHK(c, c->diff.ensure(sizeof(int) * gs_tile_ranges_scratch_ints(c->gx, c->gy)));
+        if (hi_bits > 0) HIPCHK(c, c->words.ensure(sizeof(uint32_t) * ni1));
+        {
+            StageTimer t(c, GS_STAGE_RANGES);
+            HIPCHK(c, gs_launch_tile_ranges(c->rect.as<uint16_t>(), c->n, c->diff.as<int>(), c->gx, c->gy, c->ranges.as<uint32_t>(), c->stream));
+        }
+        {
+            StageTimer t(c, GS_STAGE_TILE_SORT);
+            GsBin2Args b{};
+            b.n = c->n; b.n_inst = c->n_inst; b.gx = c->gx; b.lo_bits = lo_bits; b.hi_bits = hi_bits; b.gid_bits = gid_bits;
+            b.offsets = c->offsets.as<uint32_t>(); b.perm = perm; b.rect = c->rect.as<uint16_t>();
+            b.cs = c->cs.as<uint32_t>(); b.block_hist = c->table.as<uint32_t>(); b.digit_total = c->digit_total.as<uint32_t>();
+            b.buf_a = c->words.as<uint32_t>(); b.ids_out = c->ids.as<uint32_t>();
+            HIPCHK(c, gs_bin2_build_lists(b, c->stream));
+        }
+    } else {
+        // ---- explicit 64-bit tile|id instances, two radix passes (fallback; identical lists)
+        HIPCHK(c, c->inst_a.ensure(sizeof(uint64_t) * ni1));
+        HIPCHK(c, c->inst_b.ensure(sizeof(uint64_t) * ni1));
+        {
+            StageTimer t(c, GS_STAGE_EMIT);
+            HIPCHK(c, gs_launch_emit(c->rect.as<uint16_t>(), perm, c->offsets.as<uint32_t>(), c->inst_a.as<uint64_t>(), c->n, c->gx, c->stream));
+        }
+        uint64_t *sorted = nullptr;
+        {
+            StageTimer t(c, GS_STAGE_TILE_SORT);
+            int in_b = 0;
+            HIPCHK(c, gs_radix_sort_u64(c->inst_a.as<uint64_t>(), c->inst_b.as<uint64_t>(), c->n_inst, 32, 32 + tile_bits,
+                                        c->table.as<uint32_t>(), c->digit_total.as<uint32_t>(), &in_b, c->stream));
+            sorted = in_b ? c->inst_b.as<uint64_t>() : c->inst_a.as<uint64_t>();
+        }
+        {
+            StageTimer t(c, GS_STAGE_RANGES);
+            HIPCHK(c, gs_launch_ranges(sorted, c->n_inst, c->ranges.as<uint32_t>(), ntiles, c->stream));
+            HIPCHK(c, gs_launch_split_ids(sorted, c->ids.as<uint32_t>(), c->n_inst, c->stream));
+        }
     }
     c->did_bin = true; c->did_fwd = c->did_bwd = false;
     return GS_OK;
@@ -355,7 +384,7 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     HIPCHK(c, c->trans.ensure(sizeof(float) * px));
     GsCompositeArgs a{};
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
-    a.ranges = c->ranges.as<uint32_t>(); a.inst = c->inst_sorted; a.payload = c->payload.as<GsPayload>();
+    a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     HIPCHK(c, c->counters.ensure(16));
     a.walked = c->counters.as<unsigned long long>();
@@ -391,7 +420,7 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     HIPCHK(c, c->g2d.ensure(sizeof(float) * 10 * n1));
     GsCompositeArgs a{};
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
-    a.ranges = c->ranges.as<uint32_t>(); a.inst = c->inst_sorted; a.payload = c->payload.as<GsPayload>();
+    a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     a.dC = dC_dev; a.g2d = c->g2d.as<float>();
     a.walked = c->counters.as<unsigned long long>() + 1;
@@ -509,24 +538,22 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
         }
         case GS_ARR_TILE_RANGES: src = c->ranges.p; need = sizeof(uint32_t) * 2 * (size_t)c->gx * c->gy; break;
         case GS_ARR_SORTED_IDS: case GS_ARR_SORTED_KEYS: {
-            const size_t ni = (size_t)c->n_inst;
+            const size_t ni = (size_t)c->n_inst, nt = (size_t)c->gx * c->gy;
             const size_t w = which == GS_ARR_SORTED_IDS ? sizeof(uint32_t) : sizeof(uint64_t);
             if ((size_t)bytes != w * ni) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
-            std::vector<uint64_t> h(ni ? ni : 1);
-            std::vector<uint32_t> dk(n ? n : 1);
-            HIPCHK(c, hipMemcpyAsync(h.data(), c->inst_sorted, sizeof(uint64_t) * ni, hipMemcpyDeviceToHost, c->stream));
+            std::vector<uint32_t> h(ni ? ni : 1), dk(n ? n : 1), rg(2 * (nt ? nt : 1));
+            HIPCHK(c, hipMemcpyAsync(h.data(), c->ids.p, sizeof(uint32_t) * ni, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(dk.data(), c->depth_key.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(rg.data(), c->ranges.p, sizeof(uint32_t) * 2 * nt, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (which == GS_ARR_SORTED_IDS) {
-                uint32_t *o = static_cast<uint32_t *>(dst);
-                for (size_t p = 0; p < ni; ++p) o[p] = (uint32_t)h[p];
-            } else {
+                std::memcpy(dst, h.data(), sizeof(uint32_t) * ni);
+            } else {                                   // tile<<32 | depth key (or | id): the key the list order realises
                 uint64_t *o = static_cast<uint64_t *>(dst);
                 const bool by_index = c->cfg.order == GS_ORDER_INDEX;
-                for (size_t p = 0; p < ni; ++p) {
-                    const uint32_t g = (uint32_t)h[p];
-                    o[p] = (h[p] & 0xFFFFFFFF00000000ull) | (by_index ? g : dk[g]);
-                }
+                for (size_t t = 0; t < nt; ++t)
+                    for (size_t p = rg[2 * t]; p < rg[2 * t + 1] && p < ni; ++p)
+                        o[p] = ((uint64_t)t << 32) | (by_index ? h[p] : dk[h[p]]);
             }
             return GS_OK;
         }
@@ -579,7 +606,7 @@ int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *
     if (bind_device(c)) return GS_ERR_HIP;
     GsCompositeArgs a{};
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
-    a.ranges = c->ranges.as<uint32_t>(); a.inst = c->inst_sorted; a.payload = c->payload.as<GsPayload>();
+    a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     a.dC = c->last_dC; a.g2d = c->g2d.as<float>(); a.walked = nullptr; a.variant = variant;
     hipEvent_t e0, e1;

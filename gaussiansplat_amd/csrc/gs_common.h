@@ -67,12 +67,31 @@ hipError_t gs_launch_emit(const uint16_t *rect, const uint32_t *perm, const uint
 hipError_t gs_launch_ranges(const uint64_t *inst, int64_t n_inst, uint32_t *ranges, int64_t n_tiles,
                             hipStream_t s);
 hipError_t gs_launch_split_ids(const uint64_t *inst, uint32_t *ids, int64_t n_inst, hipStream_t s);
+// digit totals + exclusive scan of a [256][nblocks] per-block histogram table (one radix pass)
+hipError_t gs_launch_radix_scan(uint32_t *block_hist, int nblocks, uint32_t *digit_total, hipStream_t s);
+
+// low-traffic binning (gs_bin2.hip)
+size_t gs_tile_ranges_scratch_ints(int gx, int gy);
+bool gs_tile_ranges_supported(int gx, int gy);          // difference array must fit in LDS
+hipError_t gs_launch_tile_ranges(const uint16_t *rect, int64_t n, int *scratch, int gx, int gy, uint32_t *ranges, hipStream_t s);
+struct GsBin2Args {
+    int64_t n, n_inst;
+    int gx;
+    int lo_bits, hi_bits, gid_bits;   // tile id = hi:lo ; hi_bits + gid_bits <= 32
+    const uint32_t *offsets, *perm;
+    const uint16_t *rect;
+    uint32_t *cs;                     // nchunks + 1
+    uint32_t *block_hist, *digit_total;
+    uint32_t *buf_a;                  // n_inst words (pass-1 output)
+    uint32_t *ids_out;                // n_inst gaussian ids in (tile, list order)
+};
+hipError_t gs_bin2_build_lists(const GsBin2Args &b, hipStream_t s);
 
 struct GsCompositeArgs {
     int W, H, gx, gy;
     float t_min;
     const uint32_t *ranges;    // 2 x tiles
-    const uint64_t *inst;      // sorted instances (tile<<32 | gaussian id)
+    const uint32_t *ids;       // gaussian id per sorted instance
     const GsPayload *payload;
     float *image;              // W*H*3 planar
     float *trans;              // W*H

@@ -67,14 +67,14 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(GsCompositeArgs a) {
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t pos = s0 + lane;
-    if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+    if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
     for (uint32_t base = s0; base < s1; base += CB) {
         const int cnt = (int)min((uint32_t)CB, s1 - base);
         __syncthreads();                                                // one wave: orders LDS reads/writes only
         sp[3 * lane] = n0; sp[3 * lane + 1] = n1; sp[3 * lane + 2] = n2;
         __syncthreads();
         pos = base + CB + lane;                                         // next batch in flight during the loop below
-        if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
         for (int k = 0; k < cnt; ++k) {
             const GsPayload P = unpack_payload(sp[3 * k], sp[3 * k + 1], sp[3 * k + 2]);
             const int xmin = (int)(short)(P.bbx & 0xFFFFu), xmax = (int)(short)(P.bbx >> 16);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_v1_kernel(GsCompositeA
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t pos = s0 + lane;
-    if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+    if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
     for (uint32_t base = s0; base < s1; base += CB) {
         const int cnt = (int)min((uint32_t)CB, s1 - base);
         if (EARLY) {                                                    // freeze saturated pixels, vote
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_v1_kernel(GsCompositeA
         sp[3 * lane] = q0; sp[3 * lane + 1] = q1; sp[3 * lane + 2] = q2;
         __syncthreads();
         pos = base + CB + lane;                                         // next batch in flight during the loop below
-        if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
 #pragma unroll UNROLL
         for (int k = 0; k < cnt; ++k) {
             const float4 q0k = sp[3 * k], q1k = sp[3 * k + 1], q2k = sp[3 * k + 2];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_v2_kernel(GsCompositeA
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t pos = s0 + lane;
-    if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+    if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
     for (uint32_t base = s0; base < s1; base += CB) {
         const int cnt = (int)min((uint32_t)CB, s1 - base);
         if (EARLY) {
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_v2_kernel(GsCompositeA
             __syncthreads();
         }
         pos = base + CB + lane;
-        if (pos < s1) { const size_t g = (uint32_t)a.inst[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
 #pragma unroll UNROLL
         for (int k = 0; k < cnt; ++k) {
             const float4 q0k = sp[3 * k], q1k = sp[3 * k + 1], q2k = sp[3 * k + 2];
@@ -438,14 +438,14 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(GsCompositeArgs a) {
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t nid = 0;
     uint32_t pos = s0 + lane;
-    if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+    if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
     for (uint32_t base = s0; base < s1; base += CB) {
         const int cnt = (int)min((uint32_t)CB, s1 - base);
         __syncthreads();
         sp[3 * lane] = n0; sp[3 * lane + 1] = n1; sp[3 * lane + 2] = n2; sid[lane] = nid;
         __syncthreads();
         pos = base + CB + lane;
-        if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+        if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
         for (int k = 0; k < cnt; ++k) {
             const GsPayload P = unpack_payload(sp[3 * k], sp[3 * k + 1], sp[3 * k + 2]);
             const int xmin = (int)(short)(P.bbx & 0xFFFFu), xmax = (int)(short)(P.bbx >> 16);
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_v1_kernel(GsCompositeA
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t nid = 0;
     uint32_t pos = s0 + lane;
-    if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+    if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
     for (uint32_t base = s0; base < s1; base += CB) {
         const int cnt = (int)min((uint32_t)CB, s1 - base);
         if (EARLY) {
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_v1_kernel(GsCompositeA
         sp[4 * lane + 3] = make_float4(n1.x, 0.5f * (n1.y + n1.z), n1.w, __uint_as_float(nid));
         __syncthreads();
         pos = base + CB + lane;
-        if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+        if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
 #pragma unroll UNROLL
         for (int k = 0; k < cnt; ++k) {
             const float4 q0k = sp[4 * k], q1k = sp[4 * k + 1], q2k = sp[4 * k + 2];
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_v2_kernel(GsCompositeA
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t nid = 0;
     uint32_t pos = s0 + lane;
-    if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+    if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
     for (uint32_t base = s0; base < s1; base += CB) {
         const int cnt = (int)min((uint32_t)CB, s1 - base);
         if (EARLY) {
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_v2_kernel(GsCompositeA
         }
         const uint32_t my_id = nid;                                      // id of entry `lane` of this batch
         pos = base + CB + lane;
-        if (pos < s1) { nid = (uint32_t)a.inst[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+        if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
         for (int k = 0; k < cnt; ++k) {
             const float4 q0k = sp[4 * k], q1k = sp[4 * k + 1], q2k = sp[4 * k + 2];
             const float yhi = syhi[k];

@@ -180,6 +180,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     }
 }
 
+hipError_t gs_launch_radix_scan(uint32_t *block_hist, int nblocks, uint32_t *digit_total, hipStream_t stream) {
+    hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
+    return hipGetLastError();
+}
+
 hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
                              uint32_t *block_hist, uint32_t *digit_total, int *result_in_b, hipStream_t stream) {
     *result_in_b = 0;

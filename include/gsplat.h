@@ -74,7 +74,9 @@ typedef struct {
                                  arrays (ts, tps, mu', cov3ds, cov2ds, invCov2ds, bbs) for
                                  gs_get_array; costs 124 extra bytes/gaussian of HBM writes   */
     int32_t profile_stages;   /* 1: record hipEvents around every stage (gs_get_stage_times) */
-    int32_t reserved[9];
+    int32_t bin_path;         /* 0: generate-in-pass binning on 32-bit words (default); 1: explicit
+                                 64-bit tile|id instances + two radix passes (fallback, same result) */
+    int32_t reserved[8];
 } gs_config;
 
 typedef struct gs_ctx gs_ctx;

@@ -14,12 +14,12 @@ def c3():
     return (n, W, H, deg) + scene_and_cameras(n, W, H, deg, 1236)
 
 
-@pytest.mark.parametrize("order", [1, 0])
-def test_c3_binning_invariants(c3, order):
+@pytest.mark.parametrize("order,bin_path", [(1, 0), (0, 0), (1, 1)])
+def test_c3_binning_invariants(c3, order, bin_path):
     from gaussiansplat_amd import backend as B
     n, W, H, deg, sc, cam, T, P, ocam = c3
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0, bin_path=bin_path)
     ctx.preprocess(); ctx.bin()
     I = ctx.num_instances
     rect = ctx.get_array(B.ARR_TILE_RECT).astype(np.int64)
