@@ -35,8 +35,21 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
     extern __shared__ __attribute__((aligned(16))) float tile[];       // [256][ROW]
     const int64_t gb = (int64_t)blockIdx.x * blockDim.x;
     const int nb = (int)min((int64_t)blockDim.x, a.n - gb);
-    for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x)
-        tile[(idx / (3 * K)) * ROW + idx % (3 * K)] = a.shs[gb * 3 * K + idx];
+    // 3K is a multiple of 4 only for K = 4, 16 ... : use 16-byte global accesses when it is
+    constexpr bool VEC = (3 * K) % 4 == 0;
+    const bool vec_in = VEC && (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0;
+    const bool vec_out = VEC && (reinterpret_cast<uintptr_t>(a.d_shs) & 15) == 0;   // e.g. a flat buffer slice at 44 n bytes
+    if (vec_in) {
+        const float4 *src = reinterpret_cast<const float4 *>(a.shs + gb * 3 * K);       // gb*3K*4 B is 16-B aligned (gb % 256 == 0)
+        for (int i4 = threadIdx.x; i4 < nb * (3 * K / 4); i4 += blockDim.x) {
+            const float4 v = src[i4];
+            float *d = tile + ((i4 * 4) / (3 * K)) * ROW + (i4 * 4) % (3 * K);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x)
+            tile[(idx / (3 * K)) * ROW + idx % (3 * K)] = a.shs[gb * 3 * K + idx];
+    }
     __syncthreads();
     const int64_t g = gb + threadIdx.x;
     if (g < a.n) {
@@ -95,11 +108,22 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
         reinterpret_cast<float4 *>(a.dpc)[g] = make_float4((ddir[0] - X * dd) * inrm, (ddir[1] - Y * dd) * inrm, (ddir[2] - Z * dd) * inrm, 0.0f);
     }
     __syncthreads();
-    if (a.d_shs)
-        for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x) {
-            const float v = tile[(idx / (3 * K)) * ROW + idx % (3 * K)];
-            if (OVERWRITE) a.d_shs[gb * 3 * K + idx] = v; else a.d_shs[gb * 3 * K + idx] += v;
+    if (a.d_shs) {
+        if (vec_out) {
+            float4 *dst = reinterpret_cast<float4 *>(a.d_shs + gb * 3 * K);
+            for (int i4 = threadIdx.x; i4 < nb * (3 * K / 4); i4 += blockDim.x) {
+                const float *t = tile + ((i4 * 4) / (3 * K)) * ROW + (i4 * 4) % (3 * K);
+                float4 v = make_float4(t[0], t[1], t[2], t[3]);
+                if (!OVERWRITE) { const float4 o = dst[i4]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                dst[i4] = v;
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x) {
+                const float v = tile[(idx / (3 * K)) * ROW + idx % (3 * K)];
+                if (OVERWRITE) a.d_shs[gb * 3 * K + idx] = v; else a.d_shs[gb * 3 * K + idx] += v;
+            }
         }
+    }
 }
 
 template <bool OVERWRITE>
