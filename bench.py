@@ -41,6 +41,21 @@ def algorithmic_bytes(stage: str, N: int, I: int, Iw_f: int, Iw_b: int, P: int, 
     }[stage]
 
 
+def measured_traffic(kernel_stage: str, config: str, t_min: float):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/r01c_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes on
+    this same command, FETCH_SIZE doubled per the gfx950 correction).  None if no matching profile."""
+    path = os.path.join(ROOT, "profiles", "r01c_hbm_traffic.json")
+    if config != "C3" or abs(t_min - 1e-5) > 1e-12 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        ks = json.load(fh)["kernels"]
+    for name, v in ks.items():
+        if kernel_stage in name and "true" in name:      # early-out instantiation
+            return v["hbm_bytes_fetch_x2"]
+    return None
+
+
 def cpu_baseline(t_min: float, order: int):
     """The oracle (CPU restatement of the reference arithmetic, OpenMP build) on a bounded sample:
     BASELINE config C2 (100k gaussians, 800x800, SH3), one fwd+bwd."""
@@ -157,8 +172,9 @@ def main():
                        "instances": I, "walked_fwd": wf, "walked_bwd": wb, "seed": seed},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": by, "avg_ms": stage_ms[dom],
-                         "note": "composite kernels are VALU-bound (DESIGN.md s5); HBM fraction reported as measured"},
+                         "traffic": measured_traffic(dom, args.config, args.t_min), "algorithmic_bytes": by, "avg_ms": stage_ms[dom],
+                         "note": "composite kernels are VALU-bound: SQ_ACTIVE_INST_VALU ~98% of kernel cycles "
+                                 "(profiles/r01c_pmc_valu.json, DESIGN.md s5); HBM fraction reported as measured"},
         }
     if not args.no_literal and args.t_min > 0:
         del r
