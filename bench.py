@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal (t_min=0) measurement")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -100,10 +101,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if os.environ.get("GS_BENCH_SINGLE_DEVICE") == "1":      # rehearsal: every rank on cuda:0 (use with --backend gloo)
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     n, W, H, deg = synthetic.CONFIGS[args.config]
     seed = 1234 + list(synthetic.CONFIGS).index(args.config)

@@ -25,7 +25,7 @@ STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges
 # every symbol include/gsplat.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
            "gs_synchronize", "gs_set_model", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
-           "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
+           "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_debug_time_composite")
 
 
@@ -81,6 +81,8 @@ def load():
     L.gs_backward.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads)]
     L.gs_backward_ex.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads), C.c_int]
     L.gs_reset_grads.argtypes = [vp, C.POINTER(GsGrads)]
+    L.gs_loss_l1_dssim.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, C.POINTER(C.c_double), C.c_int]
+    L.gs_sgd_step.argtypes = [vp, C.c_float, C.POINTER(GsGrads)]
     L.gs_grads_alloc.argtypes = [vp, C.POINTER(GsGrads)]
     L.gs_grads_read.argtypes = [vp, C.POINTER(GsGrads), vp, vp, vp, vp, vp]
     L.gs_num_gaussians.argtypes = [vp]; L.gs_num_gaussians.restype = C.c_int64
@@ -193,6 +195,25 @@ class Context:
         self._chk(self.L.gs_grads_read(self.h, C.byref(grads), *(C.c_void_p(out[k].ctypes.data) for k in
                                                                    ("means", "scales", "quats", "opacities", "shs"))))
         return out
+
+    def loss_host(self, img: np.ndarray, gt: np.ndarray, lam: float = 0.1):
+        """(loss, dC) for host images [C, H, W] (src/loss.jl:62-72 and its gradient)."""
+        img = np.ascontiguousarray(img, np.float32); gt = np.ascontiguousarray(gt, np.float32)
+        dC = np.empty_like(img)
+        out = C.c_double()
+        Cn, H, W = img.shape
+        self._chk(self.L.gs_loss_l1_dssim(self.h, C.c_void_p(img.ctypes.data), C.c_void_p(gt.ctypes.data), W, H, Cn, lam,
+                                          C.c_void_p(dC.ctypes.data), C.byref(out), GS_MEM_HOST))
+        return float(out.value), dC
+
+    def loss_device(self, img_ptr: int, gt_ptr: int, dC_ptr: int, W: int, H: int, Cn: int, lam: float = 0.1, want_loss: bool = True):
+        out = C.c_double()
+        self._chk(self.L.gs_loss_l1_dssim(self.h, C.c_void_p(img_ptr), C.c_void_p(gt_ptr), W, H, Cn, lam, C.c_void_p(dC_ptr),
+                                          C.byref(out) if want_loss else None, GS_MEM_DEVICE))
+        return float(out.value) if want_loss else None
+
+    def sgd_step(self, lr: float, grads: GsGrads):
+        self._chk(self.L.gs_sgd_step(self.h, lr, C.byref(grads)))
 
     def reset_grads(self, grads: GsGrads):
         self._chk(self.L.gs_reset_grads(self.h, C.byref(grads)))

@@ -25,6 +25,7 @@ SOURCES = {
     "gs_sort.hip": [],
     "gs_bin2.hip": [],
     "gs_composite.hip": [],
+    "gs_loss.hip": [],
     "gs_api.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

@@ -72,6 +72,7 @@ struct gs_ctx {
     DevBuf counters;                         // 2 x u64: entries walked fwd / bwd
     DevBuf grads_flat;                       // gs_grads_alloc
     DevBuf dpc;                              // 4 x n scratch between the two backward kernels
+    DevBuf loss_maps, loss_acc, loss_in[2], loss_dc;
 };
 
 namespace {
@@ -175,7 +176,8 @@ int gs_destroy(gs_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
-                      &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff};
+                      &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
+                      &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->model) b.release();
     for (auto &b : c->dbg) b.release();
@@ -447,6 +449,60 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     }
     if (mem == GS_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));   // dC host buffer no longer needed
     c->did_bwd = true;
+    return GS_OK;
+}
+
+int gs_loss_l1_dssim(gs_ctx *c, const float *img, const float *gt, int32_t W, int32_t H, int32_t C, float lam, float *dC,
+                     double *loss_out, int mem) {
+    if (!c || !img || !gt) return GS_ERR_INVALID;
+    if (W <= 0 || H <= 0 || C <= 0) return fail(c, GS_ERR_INVALID, "gs_loss_l1_dssim: bad image size");
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(c, GS_ERR_INVALID, "gs_loss_l1_dssim: bad mem");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t n = (size_t)W * H * C;
+    HIPCHK(c, c->loss_maps.ensure(sizeof(float) * 3 * n));
+    HIPCHK(c, c->loss_acc.ensure(2 * sizeof(double)));
+    const float *d_img = img, *d_gt = gt;
+    float *d_dc = dC;
+    if (mem == GS_MEM_HOST) {
+        HIPCHK(c, c->loss_in[0].ensure(sizeof(float) * n));
+        HIPCHK(c, c->loss_in[1].ensure(sizeof(float) * n));
+        HIPCHK(c, hipMemcpyAsync(c->loss_in[0].p, img, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->loss_in[1].p, gt, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        d_img = c->loss_in[0].as<float>(); d_gt = c->loss_in[1].as<float>();
+    }
+    if (mem == GS_MEM_HOST || !dC) { HIPCHK(c, c->loss_dc.ensure(sizeof(float) * n)); d_dc = c->loss_dc.as<float>(); }
+    // window of loss.jl:5-12: exp(-r)/sqrt(2 sigma^2), r = distance from (6,6), normalised (sigma cancels); Float64 -> Float32
+    float win[121];
+    {
+        double k[121], sum = 0.0;
+        for (int j = 0; j < 11; ++j)
+            for (int i = 0; i < 11; ++i) { k[j * 11 + i] = std::exp(-std::sqrt((double)((5 - j) * (5 - j) + (5 - i) * (5 - i)))); sum += k[j * 11 + i]; }
+        for (int i = 0; i < 121; ++i) win[i] = (float)(k[i] / sum);
+    }
+    HIPCHK(c, gs_loss_run(W, H, C, d_img, d_gt, c->loss_maps.as<float>(), c->loss_acc.as<double>(), d_dc, lam, win, c->stream));
+    if (mem == GS_MEM_HOST && dC) HIPCHK(c, hipMemcpyAsync(dC, d_dc, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    if (loss_out) {
+        double acc[2];
+        HIPCHK(c, hipMemcpyAsync(acc, c->loss_acc.p, sizeof(acc), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *loss_out = (1.0 - (double)lam) * acc[0] / (2.0 * (double)n) + (double)lam * (1.0 - acc[1] / (double)n) / 2.0;
+    } else if (mem == GS_MEM_HOST) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return GS_OK;
+}
+
+int gs_sgd_step(gs_ctx *c, float lr, const gs_grads *g) {
+    if (!c || !g) return GS_ERR_INVALID;
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t n = (size_t)c->n;
+    const size_t K3 = (size_t)3 * (c->sh_degree + 1) * (c->sh_degree + 1);
+    float *p[5] = {const_cast<float *>(c->means), const_cast<float *>(c->scales), const_cast<float *>(c->quats),
+                   const_cast<float *>(c->opac), const_cast<float *>(c->shs)};
+    const float *gr[5] = {g->d_means, g->d_scales, g->d_quats, g->d_opacities, g->d_shs};
+    const size_t w[5] = {3, 3, 4, 1, K3};
+    for (int i = 0; i < 5; ++i) HIPCHK(c, gs_launch_sgd(p[i], gr[i], lr, w[i] * n, c->stream));
+    c->did_pre = c->did_bin = c->did_fwd = c->did_bwd = false;       // the model changed
     return GS_OK;
 }
 

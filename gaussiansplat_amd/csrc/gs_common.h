@@ -114,3 +114,8 @@ struct GsPreprocessBwdArgs {
     int overwrite;        // 1: store instead of accumulate
 };
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s);
+
+// loss + SGD (gs_loss.hip)
+hipError_t gs_loss_run(int W, int H, int C, const float *img, const float *gt, float *maps, double *acc, float *dC, float lam,
+                       const float *win121, hipStream_t s);
+hipError_t gs_launch_sgd(float *p, const float *g, float lr, size_t n, hipStream_t s);

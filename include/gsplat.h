@@ -152,6 +152,18 @@ int gs_grads_alloc(gs_ctx *ctx, gs_grads *out);
 int gs_grads_read(gs_ctx *ctx, const gs_grads *grads, float *h_means, float *h_scales, float *h_quats,
                   float *h_opacities, float *h_shs);
 
+/* ---- the step after backward ---------------------------------------- */
+
+/* Loss of src/loss.jl:62-72 and its gradient w.r.t. the rendered image:
+ *   loss = (1-lam) * sum|img-gt| / (2*length) + lam * (1 - mean ssim) / 2,   11x11 window of loss.jl:5-12.
+ * img, gt, dC: W*H*C floats in the image layout (x fastest, channel planes); dC may be NULL.
+ * loss_out (HOST, may be NULL): receives the loss; when non-NULL the call synchronises. */
+int gs_loss_l1_dssim(gs_ctx *ctx, const float *img, const float *gt, int32_t W, int32_t H, int32_t C, float lam,
+                     float *dC, double *loss_out, int mem);
+
+/* train.jl:42-46: param .-= lr * grad on the ctx's resident model arrays (DEVICE gradients). */
+int gs_sgd_step(gs_ctx *ctx, float lr, const gs_grads *grads);
+
 /* ---- introspection (parity tests, profiling) ------------------------------------------- */
 
 typedef enum {
