@@ -10,14 +10,16 @@
 //
 // Mapping (wave64-first, not a 16x16 CUDA block): ONE wave per tile, lane l owns the four
 // pixels (x = l & 15, y = (l >> 4) + 4p).  The tile-wide transmittance vote is a single
-// 64-bit ballot, the per-splat gradient reduction is six DPP steps, and there is no
-// workgroup barrier on the critical path.  Backward replaces splatGrads (splat.jl:271-396),
-// which is not a valid adjoint of the 3-D forward: it is the derived adjoint,
-// walking the list in the SAME order with the suffix colour obtained as D - prefix
-// (D = C_final . dC), so T is recomputed exactly as in the forward and never divided back.
+// 64-bit ballot and there is no workgroup barrier on the critical path.  Backward replaces
+// splatGrads (splat.jl:271-396), which is not a valid adjoint of the 3-D forward:
+// it is the derived adjoint, walking the list in the SAME order with the suffix colour obtained
+// as D - prefix (D = C_final . dC), so T is recomputed exactly as in the forward and never divided
+// back; eight of the nine per-splat sums are reduced by a lane-swap butterfly and written with one
+// 9-lane atomic per (tile, splat).
 //
-// Both kernels are VALU/transcendental bound (about 15 / 45 lane-ops per pixel-splat), not
-// HBM bound; see DESIGN.md section 5 for the roofline accounting.
+// Both kernels are VALU bound (49 / 114 VALU wave-instructions per list entry, VALU pipe ~98 % busy;
+// profiles/r01c_pmc_valu.json), not HBM bound; see DESIGN.md section 5 for the roofline accounting
+// and the measured instruction costs that shaped the inner loops.
 #include "gs_common.h"
 
 #define CB 64                       // splats staged per batch
@@ -35,228 +37,34 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles) {
     return t;
 }
 
-__device__ __forceinline__ GsPayload unpack_payload(const float4 &a, const float4 &b, const float4 &c) {
-    GsPayload P;
-    P.mx = a.x; P.my = a.y; P.sig = a.z; P.bbx = __float_as_uint(a.w);
-    P.i0 = b.x; P.i1 = b.y; P.i2 = b.z; P.i3 = b.w;
-    P.r = c.x; P.g = c.y; P.b = c.z; P.bby = __float_as_uint(c.w);
-    return P;
-}
-
-template <bool EARLY>
-__global__ __launch_bounds__(64) void composite_fwd_kernel(GsCompositeArgs a) {
-    __shared__ float4 sp[CB * 3];                                       // 3 KiB: one batch of payloads
-    const int ntiles = a.gx * a.gy;
-    const int tile = tile_of_block(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
-    const int lane = threadIdx.x;
-    const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;          // 1-based, splat.jl:204
-    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;         // rows py0 + 4p
-    const float fx = (float)px;
-    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
-
-    float Cr[4], Cg[4], Cb[4], T[4];
-    uint32_t walked = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        Cr[p] = Cg[p] = Cb[p] = 0.0f;
-        T[p] = (px <= a.W && py0 + 4 * p <= a.H) ? 1.0f : 0.0f;         // off-image pixels are inert
-    }
-
-    // prefetch batch 0 (three dwordx4 per lane; kept in registers until staged)
-    const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
-    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
-    uint32_t pos = s0 + lane;
-    if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
-    for (uint32_t base = s0; base < s1; base += CB) {
-        const int cnt = (int)min((uint32_t)CB, s1 - base);
-        __syncthreads();                                                // one wave: orders LDS reads/writes only
-        sp[3 * lane] = n0; sp[3 * lane + 1] = n1; sp[3 * lane + 2] = n2;
-        __syncthreads();
-        pos = base + CB + lane;                                         // next batch in flight during the loop below
-        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
-        for (int k = 0; k < cnt; ++k) {
-            const GsPayload P = unpack_payload(sp[3 * k], sp[3 * k + 1], sp[3 * k + 2]);
-            const int xmin = (int)(short)(P.bbx & 0xFFFFu), xmax = (int)(short)(P.bbx >> 16);
-            const int ymin = (int)(short)(P.bby & 0xFFFFu), ymax = (int)(short)(P.bby >> 16);
-            const bool hitx = (px >= xmin) && (px <= xmax);
-            const float dX = fx - P.mx;
-            // -1/2 log2(e) * (i0 dX^2 + (i1+i2) dX dY + i3 dY^2), dY-polynomial coefficients
-            const float A0 = (NEG_HALF_LOG2E * P.i0) * dX * dX;
-            const float B0 = (NEG_HALF_LOG2E * (P.i1 + P.i2)) * dX;
-            const float Cq = NEG_HALF_LOG2E * P.i3;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int py = py0 + 4 * p;
-                const float dY = (float)py - P.my;
-                const float e = fast_exp2(fmaf(dY, fmaf(Cq, dY, B0), A0));
-                bool hit = hitx && (py >= ymin) && (py <= ymax);
-                if (EARLY) hit = hit && !(T[p] < a.t_min);
-                const float alpha = hit ? P.sig * e : 0.0f;
-                const float w = alpha * T[p];
-                Cr[p] = fmaf(P.r, w, Cr[p]);
-                Cg[p] = fmaf(P.g, w, Cg[p]);
-                Cb[p] = fmaf(P.b, w, Cb[p]);
-                T[p] = T[p] - w;                                        // == T*(1-alpha) up to rounding
-            }
-        }
-        walked += (uint32_t)cnt;
-        if (EARLY) {
-            const bool live = !(T[0] < a.t_min) || !(T[1] < a.t_min) || !(T[2] < a.t_min) || !(T[3] < a.t_min);
-            if (__ballot(live) == 0ull) break;                          // whole tile saturated
-        }
-    }
-    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
-    if (px <= a.W) {
-        const size_t plane = (size_t)a.W * a.H;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int py = py0 + 4 * p;
-            if (py <= a.H) {
-                const size_t o = (size_t)(px - 1) + (size_t)a.W * (py - 1);
-                if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p]; }
-                if (a.trans) a.trans[o] = T[p];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------- forward, variant 1
-// Same mapping, leaner inner loop:
-//  * everything lane-independent is computed ONCE per (tile, splat) by the staging lane and kept
-//    in the LDS record: k*inv entries (k = -1/2 log2 e), log2(sig) (folded into the exponent, so
-//    alpha = exp2(pw) directly) and the pixel box as (lo, count) pairs;
-//  * the box test is one unsigned compare per axis ((unsigned)(p - lo) < count), the x result is
-//    folded into the y count, so a pixel costs one v_sub + one v_cmp and no scalar and-chains;
-//  * early-out is evaluated per 64-entry batch: a pixel whose T fell below t_min is frozen
-//    (T recorded, working T = 0, so every later weight is exactly 0) -- no per-entry test.
-struct StagedSplat {            // wave-uniform view of one LDS record
-    float mx, my, l2s, ki0, kB, ki3, r, g, b;
-    int xlo, ylo;
-    uint32_t xcnt, ycnt;
-};
-__device__ __forceinline__ void stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2) {
-    const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
-    const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
-    const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
-    const uint32_t xc = (uint32_t)max(0, xmax - xmin + 1), yc = (uint32_t)max(0, ymax - ymin + 1);
-    // log2(sig), capped one ulp below 0 so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic is PSD);
-    // only matters when sigmoid(o) rounds to exactly 1.0f (o > 16.6): relative change 6e-8
-    const float l2s = fminf(__builtin_amdgcn_logf(n0.z), -8.6e-8f);
-    q0 = make_float4(n0.x, n0.y, n0.z == n0.z ? l2s : n0.z, __uint_as_float(((uint32_t)xmin & 0xFFFFu) | (xc << 16)));
-    q1 = make_float4(NEG_HALF_LOG2E * n1.x, NEG_HALF_LOG2E * (n1.y + n1.z), NEG_HALF_LOG2E * n1.w, n0.z);
-    q2 = make_float4(n2.x, n2.y, n2.z, __uint_as_float(((uint32_t)ymin & 0xFFFFu) | (yc << 16)));
-}
-
-template <bool EARLY, int UNROLL, int MINW>
-__global__ __launch_bounds__(64, MINW) void composite_fwd_v1_kernel(GsCompositeArgs a) {
-    __shared__ float4 sp[CB * 3];
-    const int ntiles = a.gx * a.gy;
-    const int tile = tile_of_block(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
-    const int lane = threadIdx.x;
-    const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
-    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
-    const float fx = (float)px;
-    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
-
-    float Cr[4], Cg[4], Cb[4], T[4], Tdead[4], fy[4];
-    bool dead[4];
-    uint32_t walked = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        Cr[p] = Cg[p] = Cb[p] = 0.0f;
-        fy[p] = (float)(py0 + 4 * p);
-        const bool in = (px <= a.W && py0 + 4 * p <= a.H);
-        T[p] = in ? 1.0f : 0.0f;                                        // off-image pixels are inert
-        Tdead[p] = 0.0f; dead[p] = !in;
-    }
-    const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
-    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
-    uint32_t pos = s0 + lane;
-    if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
-    for (uint32_t base = s0; base < s1; base += CB) {
-        const int cnt = (int)min((uint32_t)CB, s1 - base);
-        if (EARLY) {                                                    // freeze saturated pixels, vote
-            bool live = false;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (!dead[p] && T[p] < a.t_min) { dead[p] = true; Tdead[p] = T[p]; T[p] = 0.0f; }
-                live = live || !dead[p];
-            }
-            if (__ballot(live) == 0ull) break;                          // whole tile saturated
-        }
-        float4 q0, q1, q2;
-        stage_record(q0, q1, q2, n0, n1, n2);
-        __syncthreads();                                                // one wave: orders LDS reads/writes only
-        sp[3 * lane] = q0; sp[3 * lane + 1] = q1; sp[3 * lane + 2] = q2;
-        __syncthreads();
-        pos = base + CB + lane;                                         // next batch in flight during the loop below
-        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
-#pragma unroll UNROLL
-        for (int k = 0; k < cnt; ++k) {
-            const float4 q0k = sp[3 * k], q1k = sp[3 * k + 1], q2k = sp[3 * k + 2];
-            const uint32_t xw = __float_as_uint(q0k.w), yw = __float_as_uint(q2k.w);
-            const bool hitx = (uint32_t)(px - (int)(short)(xw & 0xFFFFu)) < (xw >> 16);
-            const uint32_t ycnt = hitx ? (yw >> 16) : 0u;
-            const int ylo = (int)(short)(yw & 0xFFFFu);
-            const float dX = fx - q0k.x;
-            const float A0 = fmaf(q1k.x * dX, dX, q0k.z);               // k i0 dX^2 + log2(sig)
-            const float B0 = q1k.y * dX;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float dY = fy[p] - q0k.y;
-                const float al = fast_exp2(fmaf(dY, fmaf(q1k.z, dY, B0), A0));
-                const bool hit = (uint32_t)(py0 + 4 * p - ylo) < ycnt;
-                const float w = (hit ? al : 0.0f) * T[p];
-                Cr[p] = fmaf(q2k.x, w, Cr[p]);
-                Cg[p] = fmaf(q2k.y, w, Cg[p]);
-                Cb[p] = fmaf(q2k.z, w, Cb[p]);
-                T[p] = T[p] - w;
-            }
-        }
-        walked += (uint32_t)cnt;
-    }
-    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
-    if (px <= a.W) {
-        const size_t plane = (size_t)a.W * a.H;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int py = py0 + 4 * p;
-            if (py <= a.H) {
-                const size_t o = (size_t)(px - 1) + (size_t)a.W * (py - 1);
-                if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p]; }
-                if (a.trans) a.trans[o] = (EARLY && dead[p]) ? Tdead[p] : T[p];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------- forward, variant 2
-// v1 with the pixel-box test turned into arithmetic: v_cmp / v_cndmask cost ~4 cycles each on
+// ---------------------------------------------------------------- forward
+// The pixel-box test is arithmetic: v_cmp / v_cndmask cost ~4 cycles each on
 // gfx950 (fma: 2), so the box is applied as an exponent penalty
 //     pw' = pw - BIG * |d - med3(d, lo, hi)|        (d = pixel - mu on that axis)
 // which is exactly 0 inside the box (med3 returns d itself) and drives exp2 to 0 outside.
 // lo/hi = box edge - mu -/+ 0.25 are lane independent and staged once per (tile, splat).
 #define GS_BIG 1.0e30f
-__device__ __forceinline__ void stage_record2(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2) {
+// Lane-independent terms of one splat, computed once per (tile, splat) by the staging lane:
+// q0 = {mu_x, mu_y, log2 sig, x_lo}, q1 = {k i0, k (i1+i2), k i3, x_hi}, q2 = {r, g, b, y_lo}, y_hi   (k = -1/2 log2 e)
+__device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2) {
     const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
     const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
     const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
     const bool empty = xmax < xmin || ymax < ymin;
+    // log2(sig), capped one ulp below 0 so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic is PSD); only
+    // matters when sigmoid(o) rounds to exactly 1.0f (o > 16.6): relative change 6e-8
     const float l2s = fminf(__builtin_amdgcn_logf(n0.z), -8.6e-8f);
     // an empty box (near/far-culled splat) gets lo = hi = +BIG: every pixel is "outside"
     const float xlo = empty ? GS_BIG : ((float)xmin - n0.x) - 0.25f, xhi = empty ? GS_BIG : ((float)xmax - n0.x) + 0.25f;
     const float ylo = empty ? GS_BIG : ((float)ymin - n0.y) - 0.25f, yhi = empty ? GS_BIG : ((float)ymax - n0.y) + 0.25f;
-    q0 = make_float4(n0.x, n0.y, n0.z == n0.z ? l2s : n0.z, xlo);
+    q0 = make_float4(n0.x, n0.y, l2s, xlo);
     q1 = make_float4(NEG_HALF_LOG2E * n1.x, NEG_HALF_LOG2E * (n1.y + n1.z), NEG_HALF_LOG2E * n1.w, xhi);
     q2 = make_float4(n2.x, n2.y, n2.z, ylo);
-    // yhi travels in a 4th slot
-    (void)yhi;
+    return yhi;
 }
 
 template <bool EARLY, int UNROLL, int MINW>
-__global__ __launch_bounds__(64, MINW) void composite_fwd_v2_kernel(GsCompositeArgs a) {
+__global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
     const int ntiles = a.gx * a.gy;
@@ -295,17 +103,11 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_v2_kernel(GsCompositeA
             if (__ballot(live) == 0ull) break;
         }
         float4 q0, q1, q2;
-        stage_record2(q0, q1, q2, n0, n1, n2);
-        {
-            const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
-            const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
-            const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
-            const bool empty = xmax < xmin || ymax < ymin;
-            __syncthreads();
-            sp[3 * lane] = q0; sp[3 * lane + 1] = q1; sp[3 * lane + 2] = q2;
-            syhi[lane] = empty ? GS_BIG : ((float)ymax - n0.y) + 0.25f;
-            __syncthreads();
-        }
+        const float yhi_l = stage_record(q0, q1, q2, n0, n1, n2);
+        __syncthreads();                                                // one wave: orders LDS reads/writes only
+        sp[3 * lane] = q0; sp[3 * lane + 1] = q1; sp[3 * lane + 2] = q2;
+        syhi[lane] = yhi_l;
+        __syncthreads();
         pos = base + CB + lane;
         if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
 #pragma unroll UNROLL
@@ -402,245 +204,12 @@ __device__ __forceinline__ int out_component(int lane) {
     return -1;
 }
 
-template <bool EARLY>
-__global__ __launch_bounds__(64) void composite_bwd_kernel(GsCompositeArgs a) {
-    __shared__ float4 sp[CB * 3];
-    __shared__ uint32_t sid[CB];
-    const int ntiles = a.gx * a.gy;
-    const int tile = tile_of_block(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
-    const int lane = threadIdx.x;
-    const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
-    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
-    const float fx = (float)px;
-    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
-    const size_t plane = (size_t)a.W * a.H;
-    const int ocomp = out_component(lane);
-    const bool take_hi = (lane & 15) == 14, take_9 = lane == 61;
-
-    float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
-    uint32_t walked = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int py = py0 + 4 * p;
-        const bool in = (px <= a.W && py <= a.H);
-        const size_t o = in ? (size_t)(px - 1) + (size_t)a.W * (py - 1) : 0;
-        fy[p] = (float)py;
-        dCr[p] = in ? a.dC[o] : 0.0f;
-        dCg[p] = in ? a.dC[o + plane] : 0.0f;
-        dCb[p] = in ? a.dC[o + 2 * plane] : 0.0f;
-        T[p] = in ? 1.0f : 0.0f;
-        // S = colour still to come (dotted with dC): starts at C_final . dC
-        S[p] = in ? (a.image[o] * dCr[p] + a.image[o + plane] * dCg[p] + a.image[o + 2 * plane] * dCb[p]) : 0.0f;
-    }
-
-    const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
-    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
-    uint32_t nid = 0;
-    uint32_t pos = s0 + lane;
-    if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
-    for (uint32_t base = s0; base < s1; base += CB) {
-        const int cnt = (int)min((uint32_t)CB, s1 - base);
-        __syncthreads();
-        sp[3 * lane] = n0; sp[3 * lane + 1] = n1; sp[3 * lane + 2] = n2; sid[lane] = nid;
-        __syncthreads();
-        pos = base + CB + lane;
-        if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
-        for (int k = 0; k < cnt; ++k) {
-            const GsPayload P = unpack_payload(sp[3 * k], sp[3 * k + 1], sp[3 * k + 2]);
-            const int xmin = (int)(short)(P.bbx & 0xFFFFu), xmax = (int)(short)(P.bbx >> 16);
-            const int ymin = (int)(short)(P.bby & 0xFFFFu), ymax = (int)(short)(P.bby >> 16);
-            const bool hitx = (px >= xmin) && (px <= xmax);
-            const float dX = fx - P.mx;
-            const float A0 = (NEG_HALF_LOG2E * P.i0) * dX * dX;
-            const float B0 = (NEG_HALF_LOG2E * (P.i1 + P.i2)) * dX;
-            const float Cq = NEG_HALF_LOG2E * P.i3;
-            float e[4], dY[4];
-            bool any = false;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int py = py0 + 4 * p;
-                dY[p] = fy[p] - P.my;
-                const float ex = fast_exp2(fmaf(dY[p], fmaf(Cq, dY[p], B0), A0));
-                bool hit = hitx && (py >= ymin) && (py <= ymax);
-                if (EARLY) hit = hit && !(T[p] < a.t_min);
-                any = any || hit;
-                e[p] = hit ? ex : 0.0f;
-            }
-            if (__ballot(any) == 0ull) continue;                        // nobody in the tile touched it
-            float ar = 0.0f, ag = 0.0f, ab = 0.0f, asig = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float alpha = P.sig * e[p];
-                const float w = alpha * T[p];
-                const float cdot = fmaf(P.r, dCr[p], fmaf(P.g, dCg[p], P.b * dCb[p]));
-                ar = fmaf(w, dCr[p], ar);
-                ag = fmaf(w, dCg[p], ag);
-                ab = fmaf(w, dCb[p], ab);
-                S[p] = fmaf(-cdot, w, S[p]);                            // colour behind this splat
-                const float om = 1.0f - alpha;
-                const float inv = om > 0.0f ? fast_rcp(om) : 0.0f;
-                const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));   // dL/dalpha
-                asig = fmaf(e[p], dalpha, asig);                        // alpha = sig * e
-                const float dd = -(alpha * dalpha);                     // dL/ddist
-                q0 += dd;
-                q1 = fmaf(dd, dY[p], q1);
-                q2 = fmaf(dd * dY[p], dY[p], q2);
-                T[p] = T[p] - w;
-            }
-            // per-lane outputs (dX differs per lane; everything below is linear in the partials)
-            const float mc = 0.5f * (P.i1 + P.i2);
-            const float qx = dX * q0;
-            float v[8];
-            v[0] = ar; v[1] = ag; v[2] = ab; v[3] = asig;
-            v[4] = -fmaf(P.i0, qx, mc * q1);                            // d mu_x (delta = pixel - mu)
-            v[5] = -fmaf(mc, qx, P.i3 * q1);                            // d mu_y
-            v[6] = 0.5f * dX * qx;                                      // d inv[0]
-            v[7] = 0.5f * dX * q1;                                      // d inv[1] = d inv[2]
-            float lo, hi;
-            reduce8(v, lo, hi);
-            const float t9 = wave_sum_to_lane63(0.5f * q2);             // d inv[3]
-            // hi's totals move one lane down (lane 14), the ninth two lanes down (lane 61): one
-            // atomic wave-instruction then covers the gaussian's 40-byte row with 9 active lanes
-            const float hi_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x101, 0xF, 0xF, true));  // row_shl:1
-            const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));  // row_shl:2
-            const float outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
-            if (ocomp >= 0) atomicAdd(a.g2d + (size_t)sid[k] * 10 + ocomp, outv);
-        }
-        walked += (uint32_t)cnt;
-        if (EARLY) {
-            const bool live = !(T[0] < a.t_min) || !(T[1] < a.t_min) || !(T[2] < a.t_min) || !(T[3] < a.t_min);
-            if (__ballot(live) == 0ull) break;
-        }
-    }
-    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
-}
-
-// ---------------------------------------------------------------- backward, variant 1
-// Same tricks as composite_fwd_v1_kernel (lane-independent terms precomputed at staging, one
-// unsigned compare per pixel, per-batch freeze of saturated pixels: T = S = 0 makes every later
-// contribution exactly zero).  alpha = exp2(pw + log2 sig) is strictly < 1 (see stage_record), so
+// ---------------------------------------------------------------- backward
+// Same staging and arithmetic pixel-box penalty as the forward; per-batch freeze of saturated pixels
+// (T = S = 0 makes every later contribution exactly zero); alpha < 1 strictly (stage_record), so
 // 1/(1-alpha) needs no guard; d sig = -(1/sig) * sum(dd) needs no accumulator of its own.
-template <bool EARLY, int UNROLL, int MINW>
-__global__ __launch_bounds__(64, MINW) void composite_bwd_v1_kernel(GsCompositeArgs a) {
-    __shared__ float4 sp[CB * 4];                                       // 4 KiB
-    const int ntiles = a.gx * a.gy;
-    const int tile = tile_of_block(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
-    const int lane = threadIdx.x;
-    const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
-    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
-    const float fx = (float)px;
-    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
-    const size_t plane = (size_t)a.W * a.H;
-    const int ocomp = out_component(lane);
-    const bool take_hi = (lane & 15) == 14, take_9 = lane == 61;
-
-    float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
-    bool dead[4];
-    uint32_t walked = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int py = py0 + 4 * p;
-        const bool in = (px <= a.W && py <= a.H);
-        const size_t o = in ? (size_t)(px - 1) + (size_t)a.W * (py - 1) : 0;
-        fy[p] = (float)py;
-        dCr[p] = in ? a.dC[o] : 0.0f;
-        dCg[p] = in ? a.dC[o + plane] : 0.0f;
-        dCb[p] = in ? a.dC[o + 2 * plane] : 0.0f;
-        T[p] = in ? 1.0f : 0.0f;
-        S[p] = in ? (a.image[o] * dCr[p] + a.image[o + plane] * dCg[p] + a.image[o + 2 * plane] * dCb[p]) : 0.0f;
-        dead[p] = !in;
-    }
-    const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
-    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
-    uint32_t nid = 0;
-    uint32_t pos = s0 + lane;
-    if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
-    for (uint32_t base = s0; base < s1; base += CB) {
-        const int cnt = (int)min((uint32_t)CB, s1 - base);
-        if (EARLY) {
-            bool live = false;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (!dead[p] && T[p] < a.t_min) { dead[p] = true; T[p] = 0.0f; S[p] = 0.0f; }
-                live = live || !dead[p];
-            }
-            if (__ballot(live) == 0ull) break;
-        }
-        float4 q0, q1, q2;
-        stage_record(q0, q1, q2, n0, n1, n2);
-        const float sg = n0.z;
-        q1.w = sg > 0.0f ? fast_rcp(sg) : 0.0f;                         // 1/sig (sig == 0: d opacity is 0 anyway)
-        __syncthreads();
-        sp[4 * lane] = q0; sp[4 * lane + 1] = q1; sp[4 * lane + 2] = q2;
-        sp[4 * lane + 3] = make_float4(n1.x, 0.5f * (n1.y + n1.z), n1.w, __uint_as_float(nid));
-        __syncthreads();
-        pos = base + CB + lane;
-        if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
-#pragma unroll UNROLL
-        for (int k = 0; k < cnt; ++k) {
-            const float4 q0k = sp[4 * k], q1k = sp[4 * k + 1], q2k = sp[4 * k + 2];
-            const uint32_t xw = __float_as_uint(q0k.w), yw = __float_as_uint(q2k.w);
-            const bool hitx = (uint32_t)(px - (int)(short)(xw & 0xFFFFu)) < (xw >> 16);
-            const uint32_t ycnt = hitx ? (yw >> 16) : 0u;
-            const int ylo = (int)(short)(yw & 0xFFFFu);
-            const float dX = fx - q0k.x;
-            const float A0 = fmaf(q1k.x * dX, dX, q0k.z);
-            const float B0 = q1k.y * dX;
-            float al[4], dY[4];
-            bool any = false;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                dY[p] = fy[p] - q0k.y;
-                const float ex = fast_exp2(fmaf(dY[p], fmaf(q1k.z, dY[p], B0), A0));
-                const bool hit = (uint32_t)(py0 + 4 * p - ylo) < ycnt;
-                any = any || hit;
-                al[p] = hit ? ex : 0.0f;
-            }
-            if (__ballot(any) == 0ull) continue;                        // nobody in the tile touched it
-            float ar = 0.0f, ag = 0.0f, ab = 0.0f, q0s = 0.0f, q1s = 0.0f, q2s = 0.0f;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float w = al[p] * T[p];
-                const float cdot = fmaf(q2k.x, dCr[p], fmaf(q2k.y, dCg[p], q2k.z * dCb[p]));
-                ar = fmaf(w, dCr[p], ar);
-                ag = fmaf(w, dCg[p], ag);
-                ab = fmaf(w, dCb[p], ab);
-                S[p] = fmaf(-cdot, w, S[p]);                            // colour behind this splat
-                const float inv = fast_rcp(1.0f - al[p]);
-                const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));   // dL/dalpha
-                const float dd = -(al[p] * dalpha);                     // dL/ddist ; dL/dsig = -(1/sig) sum dd
-                q0s += dd;
-                q1s = fmaf(dd, dY[p], q1s);
-                q2s = fmaf(dd * dY[p], dY[p], q2s);
-                T[p] = T[p] - w;
-            }
-            const float4 q3k = sp[4 * k + 3];                           // i0, mc, i3, id
-            const float qx = dX * q0s;
-            float v[8];
-            v[0] = ar; v[1] = ag; v[2] = ab; v[3] = -(q1k.w * q0s);
-            v[4] = -fmaf(q3k.x, qx, q3k.y * q1s);                       // d mu_x (delta = pixel - mu)
-            v[5] = -fmaf(q3k.y, qx, q3k.z * q1s);                       // d mu_y
-            v[6] = 0.5f * dX * qx;                                      // d inv[0]
-            v[7] = 0.5f * dX * q1s;                                     // d inv[1] = d inv[2]
-            float lo, hi;
-            reduce8(v, lo, hi);
-            const float t9 = wave_sum_to_lane63(0.5f * q2s);            // d inv[3]
-            const float hi_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x101, 0xF, 0xF, true));  // row_shl:1
-            const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));  // row_shl:2
-            const float outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
-            if (ocomp >= 0) atomicAdd(a.g2d + (size_t)__float_as_uint(q3k.w) * 10 + ocomp, outv);
-        }
-        walked += (uint32_t)cnt;
-    }
-    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
-}
-
-// ---------------------------------------------------------------- backward, variant 2
-// composite_bwd_v1_kernel with the arithmetic pixel-box penalty of composite_fwd_v2_kernel.
 template <bool EARLY, int MINW>
-__global__ __launch_bounds__(64, MINW) void composite_bwd_v2_kernel(GsCompositeArgs a) {
+__global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 4];
     __shared__ float syhi[CB];
     const int ntiles = a.gx * a.gy;
@@ -688,16 +257,14 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_v2_kernel(GsCompositeA
             if (__ballot(live) == 0ull) break;
         }
         float4 q0, q1, q2;
-        stage_record2(q0, q1, q2, n0, n1, n2);
+        const float yhi_l = stage_record(q0, q1, q2, n0, n1, n2);
         {
-            const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
-            const bool empty = (int)(short)(bbx >> 16) < (int)(short)(bbx & 0xFFFFu) || (int)(short)(bby >> 16) < (int)(short)(bby & 0xFFFFu);
             const float sg = n0.z;
             __syncthreads();
             sp[4 * lane] = q0; sp[4 * lane + 1] = q1; sp[4 * lane + 2] = q2;
-            // i0, mc, i3 and 1/sig ; id and yhi in the side array
+            // i0, mc, i3 and 1/sig (sig == 0: d opacity is 0 anyway)
             sp[4 * lane + 3] = make_float4(n1.x, 0.5f * (n1.y + n1.z), n1.w, sg > 0.0f ? fast_rcp(sg) : 0.0f);
-            syhi[lane] = empty ? GS_BIG : ((float)(int)(short)(bby >> 16) - n0.y) + 0.25f;
+            syhi[lane] = yhi_l;
             __syncthreads();
         }
         const uint32_t my_id = nid;                                      // id of entry `lane` of this batch
@@ -757,53 +324,33 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_v2_kernel(GsCompositeA
     if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
 }
 
+// Launch configurations were chosen by A/B timing on MI355X at C3 (tools/abtest.py):
+// forward <unroll 2, 8 waves/SIMD> for literal lists, <unroll 2, unconstrained> with early-out;
+// backward <8 waves/SIMD> literal, <unconstrained> with early-out.  `variant` selects the other
+// instantiations for re-measurement.
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s) {
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
-    const int grid = ((ntiles + 7) / 8) * 8;
-#define GS_V1(U, M) \
-    do { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_fwd_v1_kernel<true, U, M>), dim3(grid), dim3(64), 0, s, a); \
-         else hipLaunchKernelGGL((composite_fwd_v1_kernel<false, U, M>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); } while (0)
-    if (a.variant == 0) {                       // default: measured best on MI355X (tools/abtest.py)
-        if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_fwd_v2_kernel<true, 2, 1>), dim3(grid), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((composite_fwd_v2_kernel<false, 2, 8>), dim3(grid), dim3(64), 0, s, a);
-        return hipGetLastError();
-    }
-#define GS_V2(U, M) \
-    do { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_fwd_v2_kernel<true, U, M>), dim3(grid), dim3(64), 0, s, a); \
-         else hipLaunchKernelGGL((composite_fwd_v2_kernel<false, U, M>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); } while (0)
-    if (a.variant == 10) GS_V2(2, 1);
-    if (a.variant == 11) GS_V2(2, 8);
-    if (a.variant == 12) GS_V2(1, 8);
-    if (a.variant == 1) GS_V1(2, 1);
-    if (a.variant == 2) GS_V1(1, 1);
-    if (a.variant == 3) GS_V1(2, 8);
-    if (a.variant == 4) GS_V1(1, 8);
-    if (a.variant == 5) GS_V1(4, 1);
-    if (a.t_min > 0.0f) hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(grid), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(grid), dim3(64), 0, s, a);
+    const dim3 grid(((ntiles + 7) / 8) * 8), block(64);
+    const bool early = a.t_min > 0.0f;
+    const int v = a.variant == 0 ? (early ? 1 : 2) : a.variant;
+#define GS_F(E, U, M) hipLaunchKernelGGL((composite_fwd_kernel<E, U, M>), grid, block, 0, s, a)
+    if (v == 1) { if (early) GS_F(true, 2, 1); else GS_F(false, 2, 1); }
+    else if (v == 2) { if (early) GS_F(true, 2, 8); else GS_F(false, 2, 8); }
+    else { if (early) GS_F(true, 1, 8); else GS_F(false, 1, 8); }
+#undef GS_F
     return hipGetLastError();
 }
 
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s) {
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
-    const int grid = ((ntiles + 7) / 8) * 8;
-#define GS_B1(U, M) \
-    do { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_bwd_v1_kernel<true, U, M>), dim3(grid), dim3(64), 0, s, a); \
-         else hipLaunchKernelGGL((composite_bwd_v1_kernel<false, U, M>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); } while (0)
-    if (a.variant == 10) { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_bwd_v2_kernel<true, 1>), dim3(grid), dim3(64), 0, s, a);
-                           else hipLaunchKernelGGL((composite_bwd_v2_kernel<false, 1>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); }
-    if (a.variant == 11) { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_bwd_v2_kernel<true, 8>), dim3(grid), dim3(64), 0, s, a);
-                           else hipLaunchKernelGGL((composite_bwd_v2_kernel<false, 8>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); }
-    if (a.variant == 0) { if (a.t_min > 0.0f) hipLaunchKernelGGL((composite_bwd_v2_kernel<true, 1>), dim3(grid), dim3(64), 0, s, a);
-                          else hipLaunchKernelGGL((composite_bwd_v2_kernel<false, 8>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError(); }
-    if (a.variant == 1) GS_B1(1, 1);
-    if (a.variant == 2) GS_B1(2, 1);
-    if (a.variant == 3) GS_B1(1, 6);
-    if (a.variant == 4) GS_B1(1, 8);
-    if (a.variant == 5) GS_B1(2, 5);
-    if (a.t_min > 0.0f) hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(grid), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(grid), dim3(64), 0, s, a);
+    const dim3 grid(((ntiles + 7) / 8) * 8), block(64);
+    const bool early = a.t_min > 0.0f;
+    const int v = a.variant == 0 ? (early ? 1 : 2) : a.variant;
+#define GS_B(E, M) hipLaunchKernelGGL((composite_bwd_kernel<E, M>), grid, block, 0, s, a)
+    if (v == 1) { if (early) GS_B(true, 1); else GS_B(false, 1); }
+    else { if (early) GS_B(true, 8); else GS_B(false, 8); }
+#undef GS_B
     return hipGetLastError();
 }

@@ -217,16 +217,19 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, 
         key = (v != v) ? 0xFFFFFFFFu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
     }
 
-    // ---- payload.  The near/far skip of splat.jl:227 becomes an empty pixel box; a
-    // non-finite colour is carried as sig=NaN, rgb=0 so that only hit pixels turn NaN.
+    // ---- payload.  The near/far skip of splat.jl:227 becomes an empty pixel box.  A splat whose
+    // per-view payload is not finite (degenerate covariance, NaN/Inf SH or opacity) is skipped the
+    // same way: the reference would write NaN into its pixel box, and its example scrubs those NaNs
+    // afterwards (examples/main.jl:35); the composite kernels mask arithmetically and could not keep
+    // a NaN inside the box.
     GsPayload p;
     const bool depth_ok = !(tps[2] < cam.near_ || tps[2] > cam.far_);
-    const bool rgb_ok = isfinite(rgb[0]) && isfinite(rgb[1]) && isfinite(rgb[2]);
-    p.mx = mux; p.my = muy;
-    p.sig = rgb_ok ? sg : __builtin_nanf("");
+    const bool pay_ok = isfinite(rgb[0]) && isfinite(rgb[1]) && isfinite(rgb[2]) && isfinite(sg) && isfinite(mux) && isfinite(muy) &&
+                        isfinite(inv0) && isfinite(inv1) && isfinite(inv2) && isfinite(inv3);
+    p.mx = mux; p.my = muy; p.sig = sg;
     p.i0 = inv0; p.i1 = inv1; p.i2 = inv2; p.i3 = inv3;
-    p.r = rgb_ok ? rgb[0] : 0.0f; p.g = rgb_ok ? rgb[1] : 0.0f; p.b = rgb_ok ? rgb[2] : 0.0f;
-    if (finite_bb && depth_ok) { p.bbx = gs_pack_i16(bxmin, bxmax); p.bby = gs_pack_i16(bymin, bymax); }
+    p.r = rgb[0]; p.g = rgb[1]; p.b = rgb[2];
+    if (finite_bb && depth_ok && pay_ok) { p.bbx = gs_pack_i16(bxmin, bxmax); p.bby = gs_pack_i16(bymin, bymax); }
     else { p.bbx = 1u; p.bby = 1u; }                                   // min 1, max 0: empty
     a.payload[g] = p;
     a.depth_key[g] = key;
@@ -244,8 +247,6 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, 
         a.dbg.invcov[4 * g] = inv0; a.dbg.invcov[4 * g + 1] = inv1; a.dbg.invcov[4 * g + 2] = inv2; a.dbg.invcov[4 * g + 3] = inv3;
         a.dbg.bbs[4 * g] = bxmin; a.dbg.bbs[4 * g + 1] = bymin; a.dbg.bbs[4 * g + 2] = bxmax; a.dbg.bbs[4 * g + 3] = bymax;
     }
-    // rgb / sig are recoverable from the payload except in the sanitised non-finite case;
-    // keep the literal values available for introspection through the debug arrays only.
 }
 
 hipError_t gs_launch_preprocess(const GsPreprocessArgs &a, const GsCamera &cam, hipStream_t stream) {

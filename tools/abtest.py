@@ -9,8 +9,8 @@ from gaussiansplat_amd import synthetic, backend as B
 import torch
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
-variants_f = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"])]
-variants_b = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0"])]
+variants_f = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "2", "3"])]
+variants_b = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["1", "2"])]
 n, W, H, deg = synthetic.CONFIGS[cfg]
 sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1234 + list(synthetic.CONFIGS).index(cfg))
 dC = synthetic.make_dC(W, H, 1)
