@@ -115,7 +115,8 @@ def main():
     seed = 1234 + list(synthetic.CONFIGS).index(args.config)
     scene = synthetic.make_scene(n, W, H, deg, seed=seed)
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    cam = synthetic.scene_camera(W, view=rank % 8)
+    view = int(os.environ.get("GS_BENCH_VIEW", rank % 8))      # one camera per GPU: eye rotated about +y by k*45 degrees
+    cam = synthetic.scene_camera(W, view=view)
     dC = torch.as_tensor(synthetic.make_dC(W, H, seed + rank)).cuda()
 
     def make(t_min):
