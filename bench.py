@@ -57,24 +57,26 @@ def measured_traffic(kernel_stage: str, config: str, t_min: float):
 
 
 def cpu_baseline(t_min: float, order: int):
-    """The oracle (CPU restatement of the reference arithmetic, OpenMP build) on a bounded sample:
-    BASELINE config C2 (100k gaussians, 800x800, SH3), one fwd+bwd."""
+    """The oracle (CPU restatement of the reference arithmetic, OpenMP build) on a bounded sample of the
+    workload: one fwd+bwd of the full C3 scene when the host has >= 32 threads (about 5-10 s of wall
+    time), else of BASELINE config C2 (100k gaussians, 800x800, SH3)."""
     from oracle import oracle as O
     from gaussiansplat_amd import camera as gcam, synthetic
-    n, W, H, deg = synthetic.CONFIGS["C2"]
-    sc = synthetic.make_scene(n, W, H, deg, seed=1235)
+    cores = int(O.lib(omp=True).gso_num_threads())
+    cfg = "C3" if cores >= 32 else "C2"
+    n, W, H, deg = synthetic.CONFIGS[cfg]
+    sc = synthetic.make_scene(n, W, H, deg, seed=1234 + list(synthetic.CONFIGS).index(cfg))
     cam = synthetic.scene_camera(W)
     ocam = O.camera_from_arrays(gcam.compute_transform(cam), gcam.compute_projection(cam, W, H), np.float32(cam.fx), np.float32(cam.fy),
                                 np.float32(cam.near), np.float32(cam.far), cam.eye, cam.lookAt, W, H)
     dC = synthetic.make_dC(W, H, 1235)
-    O.lib(omp=True)
     t0 = time.perf_counter()
     r = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=order, t_min=t_min, omp=True)
     O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, r["ranges"], r["ids"], dC, t_min=t_min, omp=True)
     dt = time.perf_counter() - t0
-    return {"value": n / dt / 1e6, "unit": "Msplats/s", "cores": int(O.lib(omp=True).gso_num_threads()), "kind": "port",
-            "sample": f"C2: {n} gaussians, {W}x{H}, SH{deg}, one fwd+bwd, t_min={t_min:g}, {dt:.2f} s "
-                      "(oracle/gs_oracle.c, OpenMP; fp64 adjoint)"}
+    return {"value": n / dt / 1e6, "unit": "Msplats/s", "cores": cores, "kind": "port",
+            "sample": f"{cfg}: {n} gaussians, {W}x{H}, SH{deg}, one fwd+bwd, t_min={t_min:g}, {dt:.2f} s wall "
+                      "(oracle/gs_oracle.c, OpenMP over gaussians/tiles; list building single-threaded; fp64 adjoint)"}
 
 
 def main():
@@ -183,7 +185,7 @@ def main():
                          "note": "composite kernels are VALU-bound: SQ_ACTIVE_INST_VALU ~98% of kernel cycles "
                                  "(profiles/r01c_pmc_valu.json, DESIGN.md s5); HBM fraction reported as measured"},
         }
-    if not args.no_literal and args.t_min > 0:
+    if not args.no_literal and args.t_min > 0 and world == 1:      # extra measurements only at N = 1
         del r
         torch.cuda.empty_cache()
         r0 = make(0.0)
@@ -195,7 +197,7 @@ def main():
                                       "stage_ms": {k: round(s / c if c else 0.0, 4) for k, (s, c) in st0.items()}}
         del r0
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                # rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.t_min, args.order)
         print(json.dumps(out), flush=True)
     if world > 1:
