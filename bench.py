@@ -56,6 +56,22 @@ def measured_traffic(kernel_stage: str, config: str, t_min: float):
     return None
 
 
+def measured_valu(kernel_stage: str, early: bool):
+    """VALU-pipe occupancy of the dominant kernel from the committed PMC summary
+    (profiles/r01c_pmc_valu.json): SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (1024 SIMDs * kernel cycles)."""
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_valu.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        ks = json.load(fh)["kernels"]
+    for name, v in ks.items():
+        if kernel_stage in name and (("<true" in name) == early):
+            cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+            return {"valu_busy_frac": v["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), "valu_wave_insts": v["SQ_INSTS_VALU"],
+                    "clock_GHz": v["clock_GHz"], "source": "profiles/r01c_pmc_valu.json"}
+    return None
+
+
 def cpu_baseline(t_min: float, order: int):
     """The oracle (CPU restatement of the reference arithmetic, OpenMP build) on a bounded sample of the
     workload: one fwd+bwd of the full C3 scene when the host has >= 32 threads (about 5-10 s of wall
@@ -182,6 +198,7 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, args.config, args.t_min), "algorithmic_bytes": by, "avg_ms": stage_ms[dom],
+                         "valu": measured_valu(dom, args.t_min > 0),
                          "note": "composite kernels are VALU-bound: SQ_ACTIVE_INST_VALU ~98% of kernel cycles "
                                  "(profiles/r01c_pmc_valu.json, DESIGN.md s5); HBM fraction reported as measured"},
         }
