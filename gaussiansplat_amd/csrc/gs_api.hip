@@ -664,7 +664,7 @@ int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
-    a.dC = c->last_dC; a.g2d = c->g2d.as<float>(); a.walked = nullptr; a.variant = variant;
+    a.dC = c->last_dC; a.g2d = c->g2d.as<float>(); a.walked = nullptr; a.variant = variant % 100; a.map_mode = variant / 100;
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));   // warm

@@ -100,6 +100,7 @@ struct GsCompositeArgs {
     float *g2d;                // 10 x n (atomic accumulate): drgb3 dsig dmu2 dinv4
     unsigned long long *walked; // list entries walked by this launch (one atomic per tile)
     int variant;               // kernel variant (A/B testing; 0 = default)
+    int map_mode;              // 0: XCD-banded tile order, 1: plain blockIdx order
 };
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);
