@@ -149,7 +149,6 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (c0.tile_size != GS_TILE) return fail(nullptr, GS_ERR_UNSUPPORTED, "gs_create: only tile_size 16 is supported (reference threads=(16,16))");
     if (c0.order < GS_ORDER_INDEX || c0.order > GS_ORDER_DEPTH_ASC) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad order");
     if (!(c0.t_min >= 0.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: t_min must be >= 0");
-    if (c0.deterministic) return fail(nullptr, GS_ERR_UNSUPPORTED, "gs_create: deterministic gradient reduction is not implemented yet (float atomics only)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -419,25 +418,26 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
         HIPCHK(c, hipMemcpyAsync(c->stage_in.p, dC, sizeof(float) * 3 * px, hipMemcpyHostToDevice, c->stream));
         dC_dev = c->stage_in.as<float>();
     }
-    HIPCHK(c, c->g2d.ensure(sizeof(float) * 10 * n1));
+    const bool det = c->cfg.deterministic != 0;
+    HIPCHK(c, c->g2d.ensure((det ? sizeof(long long) : sizeof(float)) * 10 * n1));
     GsCompositeArgs a{};
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
-    a.dC = dC_dev; a.g2d = c->g2d.as<float>();
+    a.dC = dC_dev; a.g2d = det ? nullptr : c->g2d.as<float>(); a.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
     a.walked = c->counters.as<unsigned long long>() + 1;
     a.variant = c->variant_bwd;
     c->last_dC = dC_dev;
     {
         StageTimer t(c, GS_STAGE_COMPOSITE_BWD);
-        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, sizeof(float) * 10 * n1, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
         HIPCHK(c, hipMemsetAsync(a.walked, 0, 8, c->stream));
         HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
     }
     GsPreprocessBwdArgs b{};
     b.n = c->n; b.sh_degree = c->sh_degree;
     b.means = c->means; b.scales = c->scales; b.quats = c->quats; b.opac = c->opac; b.shs = c->shs;
-    b.g2d = c->g2d.as<float>();
+    b.g2d = det ? nullptr : c->g2d.as<float>(); b.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
     HIPCHK(c, c->dpc.ensure(sizeof(float) * 4 * n1));
     b.dpc = c->dpc.as<float>();
     b.overwrite = (flags & GS_BWD_OVERWRITE) ? 1 : 0;
@@ -616,9 +616,16 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
         case GS_ARR_GRAD2D: {
             if (!c->did_bwd) return fail(c, GS_ERR_INVALID, "gs_get_array: gs_backward first");
             if ((size_t)bytes != sizeof(float) * 10 * n) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
-            if (n) HIPCHK(c, hipMemcpyAsync(dst, c->g2d.p, sizeof(float) * 10 * n, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
             float *o = static_cast<float *>(dst);
+            if (c->cfg.deterministic) {
+                std::vector<long long> fx(10 * (n ? n : 1));
+                if (n) HIPCHK(c, hipMemcpyAsync(fx.data(), c->g2d.p, sizeof(long long) * 10 * n, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                for (size_t i = 0; i < 10 * n; ++i) o[i] = (float)((double)fx[i] * GS_FIXED_INV);
+            } else {
+                if (n) HIPCHK(c, hipMemcpyAsync(dst, c->g2d.p, sizeof(float) * 10 * n, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
             for (size_t g = 0; g < n; ++g) o[10 * g + 8] = o[10 * g + 7];   // d inv[2] == d inv[1] (stored once)
             return GS_OK;
         }
@@ -664,7 +671,8 @@ int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
-    a.dC = c->last_dC; a.g2d = c->g2d.as<float>(); a.walked = nullptr; a.variant = variant % 100; a.map_mode = variant / 100;
+    a.dC = c->last_dC; a.walked = nullptr;
+    a.g2d = c->cfg.deterministic ? nullptr : c->g2d.as<float>(); a.g2d_fixed = c->cfg.deterministic ? c->g2d.as<long long>() : nullptr; a.variant = variant % 100; a.map_mode = variant / 100;
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));   // warm

@@ -98,6 +98,7 @@ struct GsCompositeArgs {
     // backward only
     const float *dC;           // W*H*3
     float *g2d;                // 10 x n (atomic accumulate): drgb3 dsig dmu2 dinv4
+    long long *g2d_fixed;      // deterministic mode: the same sums as 2^-40 fixed point (integer atomics commute)
     unsigned long long *walked; // list entries walked by this launch (one atomic per tile)
     int variant;               // kernel variant (A/B testing; 0 = default)
     int map_mode;              // 0: XCD-banded tile order, 1: plain blockIdx order
@@ -110,11 +111,15 @@ struct GsPreprocessBwdArgs {
     int sh_degree;
     const float *means, *scales, *quats, *opac, *shs;
     const float *g2d;
+    const long long *g2d_fixed;   // non-null: read the 2-D gradients from the fixed-point buffer
     float *d_means, *d_scales, *d_quats, *d_opac, *d_shs;   // accumulate (+=) or overwrite; may be null
     float *dpc;           // scratch 4 x n: d L / d tps[1:3] through the colour
     int overwrite;        // 1: store instead of accumulate
 };
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s);
+
+#define GS_FIXED_SCALE 1099511627776.0f            // 2^40
+#define GS_FIXED_INV (1.0 / 1099511627776.0)
 
 // loss + SGD (gs_loss.hip)
 hipError_t gs_loss_run(int W, int H, int C, const float *img, const float *gt, float *maps, double *acc, float *dC, float lam,

@@ -213,7 +213,9 @@ __device__ __forceinline__ int out_component(int lane) {
 // Same staging and arithmetic pixel-box penalty as the forward; per-batch freeze of saturated pixels
 // (T = S = 0 makes every later contribution exactly zero); alpha < 1 strictly (stage_record), so
 // 1/(1-alpha) needs no guard; d sig = -(1/sig) * sum(dd) needs no accumulator of its own.
-template <bool EARLY, int MINW>
+// DET: the per-(tile, splat) sums are added as 2^-40 fixed-point integers (64-bit integer atomics are
+// order independent, so the gradients are bitwise reproducible run to run); otherwise float atomics.
+template <bool EARLY, int MINW, bool DET>
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 4];
     __shared__ float syhi[CB];
@@ -322,7 +324,15 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
             const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));
             const float outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)my_id, k);
-            if (ocomp >= 0) atomicAdd(a.g2d + (size_t)gid * 10 + ocomp, outv);
+            if (ocomp >= 0) {
+                if (DET) {
+                    const float sc = fminf(fmaxf(outv * GS_FIXED_SCALE, -9.0e18f), 9.0e18f);      // saturate, never wrap
+                    atomicAdd(reinterpret_cast<unsigned long long *>(a.g2d_fixed) + (size_t)gid * 10 + ocomp,
+                              (unsigned long long)__float2ll_rn(sc));
+                } else {
+                    atomicAdd(a.g2d + (size_t)gid * 10 + ocomp, outv);
+                }
+            }
         }
         walked += (uint32_t)cnt;
     }
@@ -353,7 +363,8 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s) {
     const dim3 grid(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8), block(64);
     const bool early = a.t_min > 0.0f;
     const int v = a.variant == 0 ? (early ? 1 : 2) : a.variant;
-#define GS_B(E, M) hipLaunchKernelGGL((composite_bwd_kernel<E, M>), grid, block, 0, s, a)
+#define GS_B(E, M) do { if (a.g2d_fixed) hipLaunchKernelGGL((composite_bwd_kernel<E, M, true>), grid, block, 0, s, a); \
+                        else hipLaunchKernelGGL((composite_bwd_kernel<E, M, false>), grid, block, 0, s, a); } while (0)
     if (v == 1) { if (early) GS_B(true, 1); else GS_B(false, 1); }
     else { if (early) GS_B(true, 8); else GS_B(false, 8); }
 #undef GS_B

@@ -28,6 +28,17 @@ __constant__ float bC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.315391
 __constant__ float bC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                              -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
+// 2-D gradient row of gaussian g: float atomics buffer, or the deterministic fixed-point buffer
+__device__ __forceinline__ void load_g2(const GsPreprocessBwdArgs &a, int64_t g, float (&o)[10]) {
+    if (a.g2d_fixed) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) o[i] = (float)((double)a.g2d_fixed[10 * g + i] * GS_FIXED_INV);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) o[i] = a.g2d[10 * g + i];
+    }
+}
+
 template <int DEG, bool OVERWRITE>
 __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
     constexpr int K = (DEG + 1) * (DEG + 1);
@@ -53,7 +64,8 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
     __syncthreads();
     const int64_t g = gb + threadIdx.x;
     if (g < a.n) {
-        const float *g2 = a.g2d + 10 * g;
+        float g2[10];
+        load_g2(a, g, g2);
         const float grgb[3] = {g2[0], g2[1], g2[2]};
         const float *T = cam.T, *P = cam.P;
         const float m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
@@ -130,7 +142,8 @@ template <bool OVERWRITE>
 __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n) return;
-    const float *g2 = a.g2d + 10 * g;
+    float g2[10];
+    load_g2(a, g, g2);
     const float gsig = g2[3], gmx = g2[4], gmy = g2[5];
     // G[r][c] = dL/dM[r][c]; the composite kernel stores the symmetric off-diagonal once (slot 7)
     const float G[2][2] = {{g2[6], g2[7]}, {g2[7], g2[9]}};

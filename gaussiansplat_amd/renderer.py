@@ -73,7 +73,7 @@ def initGrads(splatData: SplatData3D) -> SplatGrads3D:
 
 class GaussianRenderer3D:               # renderer.jl:205-219
     def __init__(self, splatData: SplatData3D, imgSize, sh_degree: int, device: int = 0, order: int = B.ORDER_DEPTH_DESC,
-                 t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False):
+                 t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False, deterministic: bool = False):
         import torch
         self.splatData = splatData
         self._splatGrads = initGrads(splatData)
@@ -85,7 +85,8 @@ class GaussianRenderer3D:               # renderer.jl:205-219
         self.nGaussians = splatData.means.shape[0]
         self.sh_degree = sh_degree
         self.camera: Camera | None = None
-        self.ctx = B.Context(device=device, order=order, t_min=t_min, export_debug=export_debug, profile_stages=profile_stages)
+        self.ctx = B.Context(device=device, order=order, t_min=t_min, export_debug=export_debug, profile_stages=profile_stages,
+                             deterministic=deterministic)
         # one HIP stream per renderer, shared by the library and by torch's in-place ops on the
         # renderer's tensors; _begin/_end fence it against the caller's current torch stream
         self.stream = torch.cuda.Stream(dev)

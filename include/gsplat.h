@@ -67,8 +67,9 @@ typedef struct {
     float   t_min;            /* transmittance early-out: a pixel stops taking splats once
                                  its T < t_min.  0 = literal reference (splat.jl:224-261 has
                                  no early-out).  Default 1e-5 (pixel error <= t_min*max|rgb|) */
-    int32_t deterministic;    /* reserved: 1 would reduce per-gaussian gradients in a fixed order
-                                 (bitwise reproducible); not implemented -> GS_ERR_UNSUPPORTED.
+    int32_t deterministic;    /* 1: the per-(tile,splat) gradient sums are accumulated as 2^-40 fixed
+                                 point with integer atomics (order independent -> bitwise
+                                 reproducible run to run; absolute resolution 9e-13 per add);
                                  0: float atomics (run-to-run differences in the last bits)    */
     int32_t export_debug;     /* 1: gs_preprocess also materialises the reference's scratch
                                  arrays (ts, tps, mu', cov3ds, cov2ds, invCov2ds, bbs) for
