@@ -25,7 +25,8 @@ STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges
 # every symbol include/gsplat.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
            "gs_synchronize", "gs_set_model", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
-           "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
+           "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
+           "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_debug_time_composite")
 
 
@@ -83,6 +84,10 @@ def load():
     L.gs_reset_grads.argtypes = [vp, C.POINTER(GsGrads)]
     L.gs_loss_l1_dssim.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp, C.POINTER(C.c_double), C.c_int]
     L.gs_sgd_step.argtypes = [vp, C.c_float, C.POINTER(GsGrads)]
+    L.gs_comm_unique_id.argtypes = [vp]
+    L.gs_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.gs_allreduce_grads.argtypes = [vp, C.POINTER(GsGrads)]
+    L.gs_comm_destroy.argtypes = [vp]
     L.gs_grads_alloc.argtypes = [vp, C.POINTER(GsGrads)]
     L.gs_grads_read.argtypes = [vp, C.POINTER(GsGrads), vp, vp, vp, vp, vp]
     L.gs_num_gaussians.argtypes = [vp]; L.gs_num_gaussians.restype = C.c_int64
@@ -211,6 +216,21 @@ class Context:
         self._chk(self.L.gs_loss_l1_dssim(self.h, C.c_void_p(img_ptr), C.c_void_p(gt_ptr), W, H, Cn, lam, C.c_void_p(dC_ptr),
                                           C.byref(out) if want_loss else None, GS_MEM_DEVICE))
         return float(out.value) if want_loss else None
+
+    # -- RCCL directly through the C ABI (what the Julia glue uses; the Python mirror defaults to torch.distributed)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = load().gs_comm_unique_id(buf)
+        if rc != 0:
+            raise GsError(rc, (load().gs_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, rank: int, nranks: int, unique_id: bytes):
+        self._chk(self.L.gs_comm_init(self.h, rank, nranks, C.c_char_p(unique_id)))
+
+    def allreduce_grads(self, grads: GsGrads):
+        self._chk(self.L.gs_allreduce_grads(self.h, C.byref(grads)))
 
     def sgd_step(self, lr: float, grads: GsGrads):
         self._chk(self.L.gs_sgd_step(self.h, lr, C.byref(grads)))

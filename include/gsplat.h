@@ -153,6 +153,20 @@ int gs_grads_alloc(gs_ctx *ctx, gs_grads *out);
 int gs_grads_read(gs_ctx *ctx, const gs_grads *grads, float *h_means, float *h_scales, float *h_quats,
                   float *h_opacities, float *h_shs);
 
+/* ---- multi-GPU: one camera view per GPU, ONE all-reduce of the gradients -------- */
+
+/* RCCL (librccl.so.1, loaded on first use) over xGMI.  Rank 0 calls gs_comm_unique_id and hands
+ * the 128 bytes to the other ranks by any host transport; every rank then calls gs_comm_init on its
+ * own ctx (one process per GPU).  gs_allreduce_grads sums the gradient arrays across ranks on the ctx
+ * stream: a single ncclAllReduce when `grads` is one contiguous buffer
+ * [d_means 3N | d_scales 3N | d_quats 4N | d_opac N | d_shs 3K*N] (the layout of gs_grads_alloc and of
+ * the Python mirror), else one per array. */
+#define GS_COMM_ID_BYTES 128
+int gs_comm_unique_id(void *id128);
+int gs_comm_init(gs_ctx *ctx, int rank, int nranks, const void *id128);
+int gs_allreduce_grads(gs_ctx *ctx, const gs_grads *grads);
+int gs_comm_destroy(gs_ctx *ctx);
+
 /* ---- the step after backward ---------------------------------------- */
 
 /* Loss of src/loss.jl:62-72 and its gradient w.r.t. the rendered image:

@@ -112,6 +112,18 @@ end
 hip_backward!(r::HipRenderer, ΔC::Array{Float32, 3}, grads::GsGrads) =
     check(r, ccall((:gs_backward, libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}, Cint, Ref{GsGrads}), r.ctx, ΔC, GS_MEM_HOST, grads))
 
+# multi-GPU (one process per GPU): rank 0 creates the id, every rank joins, one all-reduce per step
+function hip_commUniqueId()
+    id = zeros(UInt8, 128)
+    rc = ccall((:gs_comm_unique_id, libgs), Cint, (Ptr{UInt8},), id)
+    rc == 0 || error("gs_comm_unique_id failed")
+    return id
+end
+hip_commInit(r::HipRenderer, rank, nranks, id::Vector{UInt8}) =
+    check(r, ccall((:gs_comm_init, libgs), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), r.ctx, rank, nranks, id))
+hip_allreduceGrads!(r::HipRenderer, grads::GsGrads) =
+    check(r, ccall((:gs_allreduce_grads, libgs), Cint, (Ptr{Cvoid}, Ref{GsGrads}), r.ctx, grads))
+
 # resetGrads(renderer.splatGrads)  (src/splat.jl:158-173)
 hip_resetGrads!(r::HipRenderer, grads::GsGrads) =
     check(r, ccall((:gs_reset_grads, libgs), Cint, (Ptr{Cvoid}, Ref{GsGrads}), r.ctx, grads))

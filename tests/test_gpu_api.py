@@ -141,3 +141,24 @@ def test_deterministic_gradients_are_bitwise_reproducible(oracle):
     gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC, t_min=1e-5)
     for k in ("means", "scales", "quats", "opacities", "shs"):
         assert rel_l2(runs[0][k].reshape(-1), gref[k].reshape(-1)) <= 1e-3, k
+
+
+def test_rccl_allreduce_through_c_abi_single_rank():
+    """gs_comm_* / gs_allreduce_grads with a 1-rank RCCL communicator: the sum over one rank is the identity,
+    issued as ONE collective on the flat buffer of gs_grads_alloc.  (N > 1 needs N GPUs: the driver's run.)"""
+    from gaussiansplat_amd import backend as B
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg = 2000, 96, 64, 1
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 31)
+    ctx = hip_context(sc, cam, T, P, W, H, deg)
+    ctx.preprocess(); ctx.bin(); ctx.forward_host()
+    g = ctx.grads_alloc()
+    ctx.backward(synthetic.make_dC(W, H, 31), g)
+    before = ctx.grads_read(g, deg)
+    ctx.comm_init(0, 1, B.Context.comm_unique_id())
+    ctx.allreduce_grads(g)
+    ctx.synchronize()
+    after = ctx.grads_read(g, deg)
+    for k in before:
+        assert np.array_equal(before[k], after[k]), k
+    ctx.close()
