@@ -42,6 +42,12 @@ def test_c3_binning_invariants(c3, order, bin_path):
         assert np.all(np.diff(dk[perm].astype(np.int64)) >= 0)            # depth order, stable: ties by index
         tie = np.diff(dk[perm].astype(np.int64)) == 0
         assert np.all(np.diff(perm.astype(np.int64))[tie] > 0)
+    if order == 1 and bin_path == 0:
+        # the headline configuration, bit-exact against the oracle: 1 M boxes, 30 M sorted instances
+        from oracle import oracle as O
+        pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, omp=True)
+        oranges, oids, okeys = O.bin_lists(pre["bbs"], pre["tps"], 1, 16, gx, gy)
+        assert np.array_equal(ranges, oranges.astype(np.int64)) and np.array_equal(ids, oids) and np.array_equal(keys, okeys)
     ctx.close()
 
 
@@ -78,4 +84,31 @@ def test_c3_forward_deterministic_backward_linear(c3):
     assert np.linalg.norm(outs[1] - 2 * outs[0]) <= 1e-4 * np.linalg.norm(outs[1])
     wf, wb = ctx.work_counters()
     assert 0 < wf <= ctx.num_instances + 64 * 8160 and wb == wf
+    ctx.close()
+
+
+def test_c2_full_size_parity_against_oracle(oracle):
+    """BASELINE config C2 (100k gaussians, 800x800, SH3) end to end against the oracle (OpenMP build):
+    bit-exact lists, pixels and gradients within the stated tolerances, default early-out."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = synthetic.CONFIGS["C2"]
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1235)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5)
+    ctx.preprocess(); ctx.bin()
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ref["ranges"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ref["ids"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), ref["keys"])
+    img, tr = ctx.forward_host()
+    assert np.all(np.abs(img - ref["image"]) <= 1e-4 + 1e-4 * np.abs(ref["image"]))
+    assert np.all(np.abs(tr - ref["trans"]) <= 1e-4 + 1e-4 * np.abs(ref["trans"]))
+    dC = synthetic.make_dC(W, H, 1235)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC,
+                      t_min=1e-5, omp=True)
+    g = ctx.grads_alloc(); ctx.backward(dC, g)
+    got = ctx.grads_read(g, deg)
+    for k in ("means", "scales", "quats", "opacities", "shs"):
+        a = got[k].reshape(-1).astype(np.float64); b = gref[k].reshape(-1)
+        assert np.linalg.norm(a - b) <= 1e-3 * np.linalg.norm(b), k
     ctx.close()
