@@ -90,6 +90,7 @@ struct gs_ctx {
     const float *last_dC = nullptr;          // device dC of the last gs_backward (debug timing)
     int variant_fwd = 0, variant_bwd = 0;
 
+    hipEvent_t ev_count = nullptr;           // instance count landed in pinned memory
     hipEvent_t ev[GS_STAGE_COUNT][2] = {};
     bool ev_valid[GS_STAGE_COUNT] = {};      // a start/stop pair has been recorded
     bool ev_fresh[GS_STAGE_COUNT] = {};      // ... and not yet added to the accumulators
@@ -130,10 +131,10 @@ struct StageTimer {
 };
 
 // After a stream synchronise every recorded pair is complete: fold it into the accumulators.
-void harvest_events(gs_ctx *c) {
+void harvest_events(gs_ctx *c, int skip_stage = -1) {
     if (!c->cfg.profile_stages) return;
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
-        if (c->ev_fresh[s]) {
+        if (c->ev_fresh[s] && s != skip_stage) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) { c->ev_sum[s] += ms; c->ev_cnt[s] += 1; }
             c->ev_fresh[s] = false;
@@ -193,6 +194,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
         for (int k = 0; k < 2; ++k)
             if ((e = hipEventCreate(&c->ev[s][k])) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
+    if ((e = hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
     *out = c;
     return GS_OK;
 }
@@ -212,6 +214,7 @@ int gs_destroy(gs_ctx *c) {
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
         for (int k = 0; k < 2; ++k)
             if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
+    if (c->ev_count) (void)hipEventDestroy(c->ev_count);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -342,16 +345,6 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
         HIPCHK(c, c->block_sums.ensure(sizeof(uint32_t) * (n / 2048 + 2)));
         HIPCHK(c, gs_launch_count_scan(c->rect.as<uint16_t>(), perm, c->offsets.as<uint32_t>(), c->block_sums.as<uint32_t>(), c->n, c->stream));
     }
-    // the one host read-back of the frame (the reference reads maxHits back, forward.jl:139)
-    HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    harvest_events(c);
-    c->n_inst = (int64_t)c->pinned[0];
-    const size_t ni1 = c->n_inst ? (size_t)c->n_inst : 1;
-    HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
-    HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 256));
-    HIPCHK(c, c->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)(ntiles ? ntiles : 1)));
-    HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * ni1));
     int tile_bits = 1;
     while ((1LL << tile_bits) < ntiles) ++tile_bits;
     int gid_bits = 1;
@@ -359,16 +352,29 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     const int passes = (tile_bits + 7) / 8;
     const int lo_bits = passes <= 1 ? tile_bits : (tile_bits + 1) / 2, hi_bits = tile_bits - lo_bits;
     const bool fast = c->cfg.bin_path == 0 && passes <= 2 && hi_bits + gid_bits <= 32 && gs_tile_ranges_supported(c->gx, c->gy);
+    HIPCHK(c, c->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)(ntiles ? ntiles : 1)));
+    // the one host read-back of the frame (the reference reads maxHits back, forward.jl:139).  Work that
+    // does not need the count (the tile ranges) is enqueued BEFORE the host waits, so the GPU stays busy
+    // while the host wakes up and launches the instance passes.
+    HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
+    if (fast) {
+        HIPCHK(c, c->diff.ensure(sizeof(int) * gs_tile_ranges_scratch_ints(c->gx, c->gy)));
+        StageTimer t(c, GS_STAGE_RANGES);
+        HIPCHK(c, gs_launch_tile_ranges(c->rect.as<uint16_t>(), c->n, c->diff.as<int>(), c->gx, c->gy, c->ranges.as<uint32_t>(), c->stream));
+    }
+    HIPCHK(c, hipEventSynchronize(c->ev_count));
+    harvest_events(c, fast ? GS_STAGE_RANGES : -1);
+    c->n_inst = (int64_t)c->pinned[0];
+    const size_t ni1 = c->n_inst ? (size_t)c->n_inst : 1;
+    HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
+    HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 256));
+    HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * ni1));
     if (fast) {
         // ---- generate-in-pass binning on 32-bit words (gs_bin2.hip)
         const size_t nchunks = ((size_t)c->n_inst + 4095) / 4096;
         HIPCHK(c, c->cs.ensure(sizeof(uint32_t) * (nchunks + 2)));
-        HIPCHK(c, c->diff.ensure(sizeof(int) * gs_tile_ranges_scratch_ints(c->gx, c->gy)));
         if (hi_bits > 0) HIPCHK(c, c->words.ensure(sizeof(uint32_t) * ni1));
-        {
-            StageTimer t(c, GS_STAGE_RANGES);
-            HIPCHK(c, gs_launch_tile_ranges(c->rect.as<uint16_t>(), c->n, c->diff.as<int>(), c->gx, c->gy, c->ranges.as<uint32_t>(), c->stream));
-        }
         {
             StageTimer t(c, GS_STAGE_TILE_SORT);
             GsBin2Args b{};
