@@ -79,28 +79,24 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_totals_kernel(const uint3
 
 __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restrict__ block_hist, int nblocks,
                                                               const uint32_t *__restrict__ digit_total) {
+    // one workgroup per digit row; thread t owns the contiguous slice [t*per, (t+1)*per) of the row, so the
+    // whole row is scanned with ONE block-level scan instead of nblocks/256 dependent rounds
     __shared__ uint32_t sm[RS_WAVES];
-    __shared__ uint32_t carry;
     const int d = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t below = (threadIdx.x < d) ? digit_total[threadIdx.x] : 0u;
     below = block_reduce_u32(below, sm);
-    if (threadIdx.x == 0) carry = below;
     __syncthreads();
     uint32_t *row = block_hist + (size_t)d * nblocks;
-    for (int base = 0; base < nblocks; base += RS_THREADS) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? row[i] : 0u;
-        const uint32_t incl = wave_incl_scan(v, lane);
-        if (lane == 63) sm[w] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int k = 0; k < w; ++k) woff += sm[k];
-        const uint32_t c = carry;
-        if (i < nblocks) row[i] = c + woff + incl - v;
-        __syncthreads();
-        if (threadIdx.x == RS_THREADS - 1) carry = c + woff + incl;
-        __syncthreads();
-    }
+    const int per = (nblocks + RS_THREADS - 1) / RS_THREADS;
+    const int i0 = threadIdx.x * per, i1 = min(nblocks, i0 + per);
+    uint32_t s = 0;
+    for (int i = i0; i < i1; ++i) s += row[i];
+    const uint32_t incl = wave_incl_scan(s, lane);
+    if (lane == 63) sm[w] = incl;
+    __syncthreads();
+    uint32_t run = below + incl - s;
+    for (int k = 0; k < w; ++k) run += sm[k];
+    for (int i = i0; i < i1; ++i) { const uint32_t v = row[i]; row[i] = run; run += v; }
 }
 
 // ---------------------------------------------------------------- radix pass: stable scatter

@@ -48,3 +48,19 @@ def test_ply_round_trip_reference_field_mapping(tmp_path):
     d3 = ply.load_ply(p, sh_degree=3)
     for k in ("means", "scales", "quats", "opacities", "shs"):
         assert np.array_equal(d3[k], sc[k]), k
+
+
+def test_export_image_like_reference_viewer(tmp_path):
+    from gaussiansplat_amd import export
+    img = np.zeros((3, 2, 4), np.float32)            # C=3, H=2, W=4
+    img[0, 0, 3] = 2.0                               # clamps to 1
+    img[1, 1, 0] = np.nan                            # scrubbed to 0
+    img[2, 1, 2] = 0.5
+    out = export.to_rgb8(img, rotate=False)
+    assert out.shape == (4, 2, 3) and out.dtype == np.uint8        # Julia: W rows, H columns
+    assert out[3, 0, 0] == 255 and out[0, 1, 1] == 0 and out[2, 1, 2] == 128
+    rot = export.to_rgb8(img)
+    assert rot.shape == (2, 4, 3) and np.array_equal(rot, np.rot90(out, 1, (0, 1)))
+    p = tmp_path / "a.ppm"
+    export.save_ppm(str(p), rot)
+    assert p.read_bytes().startswith(b"P6\n4 2\n255\n") and len(p.read_bytes()) == 11 + 24
