@@ -33,7 +33,7 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
 class GsConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("tile_size", C.c_int32), ("order", C.c_int32), ("t_min", C.c_float),
                 ("deterministic", C.c_int32), ("export_debug", C.c_int32), ("profile_stages", C.c_int32),
-                ("bin_path", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class GsGrads(C.Structure):
@@ -111,12 +111,12 @@ class Context:
     """Owns one gs_ctx (one GPU, one stream)."""
 
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
-                 profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0):
+                 profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 0):
         self.L = load()
         cfg = default_config()
         cfg.order, cfg.t_min = int(order), float(t_min)
         cfg.export_debug, cfg.profile_stages, cfg.deterministic = int(export_debug), int(profile_stages), int(deterministic)
-        cfg.bin_path = int(bin_path)
+        cfg.bin_path, cfg.rank_mode = int(bin_path), int(rank_mode)
         self.cfg = cfg
         self.h = C.c_void_p()
         rc = self.L.gs_create(C.byref(self.h), device, C.byref(cfg))

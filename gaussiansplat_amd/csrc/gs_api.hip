@@ -334,7 +334,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
         HIPCHK(c, gs_launch_depth_pairs(c->depth_key.as<uint32_t>(), c->pairs_a.as<uint64_t>(), c->n, c->stream));
         int in_b = 0;
         HIPCHK(c, gs_radix_sort_u64(c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, 32, 64, c->table.as<uint32_t>(),
-                                    c->digit_total.as<uint32_t>(), &in_b, c->stream));
+                                    c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0));
         perm = c->perm.as<uint32_t>();
         HIPCHK(c, gs_launch_unpack_perm(in_b ? c->pairs_b.as<uint64_t>() : c->pairs_a.as<uint64_t>(), perm, c->n, c->stream));
     }
@@ -381,7 +381,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
             b.n = c->n; b.n_inst = c->n_inst; b.gx = c->gx; b.lo_bits = lo_bits; b.hi_bits = hi_bits; b.gid_bits = gid_bits;
             b.offsets = c->offsets.as<uint32_t>(); b.perm = perm; b.rect = c->rect.as<uint16_t>();
             b.cs = c->cs.as<uint32_t>(); b.block_hist = c->table.as<uint32_t>(); b.digit_total = c->digit_total.as<uint32_t>();
-            b.buf_a = c->words.as<uint32_t>(); b.ids_out = c->ids.as<uint32_t>();
+            b.buf_a = c->words.as<uint32_t>(); b.ids_out = c->ids.as<uint32_t>(); b.ballot_ranks = c->cfg.rank_mode != 0;
             HIPCHK(c, gs_bin2_build_lists(b, c->stream));
         }
     } else {
@@ -397,7 +397,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
             StageTimer t(c, GS_STAGE_TILE_SORT);
             int in_b = 0;
             HIPCHK(c, gs_radix_sort_u64(c->inst_a.as<uint64_t>(), c->inst_b.as<uint64_t>(), c->n_inst, 32, 32 + tile_bits,
-                                        c->table.as<uint32_t>(), c->digit_total.as<uint32_t>(), &in_b, c->stream));
+                                        c->table.as<uint32_t>(), c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0));
             sorted = in_b ? c->inst_b.as<uint64_t>() : c->inst_a.as<uint64_t>();
         }
         {

@@ -244,6 +244,19 @@ __global__ __launch_bounds__(RS_THREADS) void gen_hist_kernel(ExpandArgs a, uint
 
 // stable ranking shared by both scatter kernels: wave w owns items [w*1024, (w+1)*1024) in 16
 // wave-striped rounds; order = (wave, round, lane)
+// Two ways to get a key's stable rank among the wave's earlier same-digit keys:
+//  * ballots (portable): 8 wave64 ballots build the set of same-digit lanes, a running LDS counter adds
+//    the earlier rounds;
+//  * LDS atomic (default): ONE ds_add_rtn_u32 on the wave's counter row.  When several lanes of one wave
+//    instruction hit the same LDS address, gfx950 hands out the pre-values in ascending lane order
+//    (tools/lds_atomic_order.hip: 0 mismatches in 1.7e8 lane-ops) -- exactly the stable rank.  Measured
+//    behaviour, not an architectural guarantee: gs_config.rank_mode = 1 selects the ballot form, and the
+//    GPU tests compare every list bit-for-bit against the oracle with both.
+__device__ __forceinline__ void rank_round_atomic(uint32_t dg, bool valid, uint32_t *wc, uint32_t &rank) {
+    rank = 0;
+    if (valid) rank = atomicAdd(&wc[dg], 1u);
+}
+
 __device__ __forceinline__ void rank_round(uint32_t dg, bool valid, int lane, volatile uint32_t *wc, uint32_t &rank) {
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long peers = __ballot(valid);
@@ -276,6 +289,7 @@ __device__ __forceinline__ void digit_prefixes(uint32_t (*wcnt)[RS_RADIX], uint3
     __syncthreads();
 }
 
+template <bool ATOMIC_RANK>
 __global__ __launch_bounds__(RS_THREADS) void gen_scatter_kernel(ExpandArgs a, const uint32_t *__restrict__ block_hist,
                                                                   uint32_t *__restrict__ out) {
     __shared__ uint32_t own[RS_CHUNK];                   // owners, then reused as the reorder buffer
@@ -304,7 +318,8 @@ __global__ __launch_bounds__(RS_THREADS) void gen_scatter_kernel(ExpandArgs a, c
         if (valid) expand_item(a, own, rec, staged, base, li, s_lo, tile, gid);
         dgs[r] = valid ? (tile & mask) : (RS_RADIX - 1);
         val[r] = ((tile >> a.lo_bits) << a.gid_bits) | gid;
-        rank_round(dgs[r], valid, lane, wcnt[w], rank[r]);
+        if (ATOMIC_RANK) rank_round_atomic(dgs[r], valid, wcnt[w], rank[r]);
+        else rank_round(dgs[r], valid, lane, wcnt[w], rank[r]);
     }
     __syncthreads();                                     // every wave is done reading own[] and rec[]
     digit_prefixes(wcnt, lpre, sm);
@@ -344,6 +359,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs32_hist_kernel(const uint32_t *_
     block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+template <bool ATOMIC_RANK>
 __global__ __launch_bounds__(RS_THREADS) void rs32_scatter_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int64_t n,
                                                                    int shift, uint32_t mask, uint32_t out_mask,
                                                                    const uint32_t *__restrict__ block_hist, int nblocks) {
@@ -366,7 +382,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs32_scatter_kernel(const uint32_t
         const bool valid = li < cnt;
         key[r] = valid ? in[base + li] : 0xFFFFFFFFu;
         const uint32_t dg = valid ? ((key[r] >> shift) & mask) : (RS_RADIX - 1);
-        rank_round(dg, valid, lane, wcnt[w], rank[r]);
+        if (ATOMIC_RANK) rank_round_atomic(dg, valid, wcnt[w], rank[r]);
+        else rank_round(dg, valid, lane, wcnt[w], rank[r]);
     }
     __syncthreads();
     digit_prefixes(wcnt, lpre, sm);
@@ -402,14 +419,19 @@ hipError_t gs_bin2_build_lists(const GsBin2Args &b, hipStream_t s) {
     hipError_t e = gs_launch_radix_scan(b.block_hist, nchunks, b.digit_total, s);
     if (e != hipSuccess) return e;
     uint32_t *first_out = b.hi_bits > 0 ? b.buf_a : b.ids_out;
-    hipLaunchKernelGGL(gen_scatter_kernel, dim3(nchunks), dim3(RS_THREADS), 0, s, a, b.block_hist, first_out);
+    if (b.ballot_ranks) hipLaunchKernelGGL(gen_scatter_kernel<false>, dim3(nchunks), dim3(RS_THREADS), 0, s, a, b.block_hist, first_out);
+    else hipLaunchKernelGGL(gen_scatter_kernel<true>, dim3(nchunks), dim3(RS_THREADS), 0, s, a, b.block_hist, first_out);
     if (b.hi_bits > 0) {
         const uint32_t hmask = (1u << b.hi_bits) - 1u, gmask = b.gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << b.gid_bits) - 1u);
         hipLaunchKernelGGL(rs32_hist_kernel, dim3(nchunks), dim3(RS_THREADS), 0, s, b.buf_a, b.n_inst, b.gid_bits, hmask, b.block_hist, nchunks);
         e = gs_launch_radix_scan(b.block_hist, nchunks, b.digit_total, s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(rs32_scatter_kernel, dim3(nchunks), dim3(RS_THREADS), 0, s, b.buf_a, b.ids_out, b.n_inst, b.gid_bits, hmask, gmask,
-                           b.block_hist, nchunks);
+        if (b.ballot_ranks)
+            hipLaunchKernelGGL(rs32_scatter_kernel<false>, dim3(nchunks), dim3(RS_THREADS), 0, s, b.buf_a, b.ids_out, b.n_inst, b.gid_bits, hmask,
+                               gmask, b.block_hist, nchunks);
+        else
+            hipLaunchKernelGGL(rs32_scatter_kernel<true>, dim3(nchunks), dim3(RS_THREADS), 0, s, b.buf_a, b.ids_out, b.n_inst, b.gid_bits, hmask,
+                               gmask, b.block_hist, nchunks);
     }
     return hipGetLastError();
 }

@@ -54,7 +54,7 @@ size_t gs_sort_table_entries(int64_t n_max);
 // Stable LSD radix sort of n 64-bit keys on bits [bit_lo, bit_hi); result ends in *out_is_b.
 hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
                              uint32_t *block_hist, uint32_t *digit_total, int *result_in_b,
-                             hipStream_t stream);
+                             hipStream_t stream, bool ballot_ranks = false);
 
 hipError_t gs_launch_depth_pairs(const uint32_t *depth_key, uint64_t *pairs, int64_t n, hipStream_t s);
 hipError_t gs_launch_unpack_perm(const uint64_t *pairs, uint32_t *perm, int64_t n, hipStream_t s);
@@ -84,6 +84,7 @@ struct GsBin2Args {
     uint32_t *block_hist, *digit_total;
     uint32_t *buf_a;                  // n_inst words (pass-1 output)
     uint32_t *ids_out;                // n_inst gaussian ids in (tile, list order)
+    bool ballot_ranks;                // portable ballot ranking instead of the LDS-atomic rank
 };
 hipError_t gs_bin2_build_lists(const GsBin2Args &b, hipStream_t s);
 

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
 // the stable rank order is (wave, round, lane).  Ranks come from wave64 ballots (8 per round:
 // the set of lanes holding the same digit) and a per-wave running LDS counter; keys are then
 // placed digit-contiguously in LDS and written out in runs.
+template <bool ATOMIC_RANK>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                                  int64_t n, int shift, uint32_t mask,
                                                                  const uint32_t *__restrict__ block_hist, int nblocks) {
@@ -130,17 +131,22 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
         const bool valid = li < cnt;
         key[r] = valid ? in[base + li] : ~0ull;
         const uint32_t dg = valid ? ((uint32_t)(key[r] >> shift) & mask) : (RS_RADIX - 1);
-        unsigned long long peers = __ballot(valid);
+        if (ATOMIC_RANK) {                                              // see gs_bin2.hip rank_round_atomic
+            rank[r] = 0;
+            if (valid) rank[r] = atomicAdd(&wcnt[w][dg], 1u);
+        } else {
+            unsigned long long peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const unsigned long long bal = __ballot((dg >> b) & 1u);
-            peers &= ((dg >> b) & 1u) ? bal : ~bal;
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long bal = __ballot((dg >> b) & 1u);
+                peers &= ((dg >> b) & 1u) ? bal : ~bal;
+            }
+            const uint32_t before = wcnt[w][dg];                        // same-digit keys of earlier rounds
+            rank[r] = before + (uint32_t)__popcll(peers & lt_mask);
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (peers & lt_mask) == 0ull) wcnt[w][dg] = before + (uint32_t)__popcll(peers);   // group leader
+            __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t before = wcnt[w][dg];                            // same-digit keys of earlier rounds
-        rank[r] = before + (uint32_t)__popcll(peers & lt_mask);
-        __builtin_amdgcn_wave_barrier();
-        if (valid && (peers & lt_mask) == 0ull) wcnt[w][dg] = before + (uint32_t)__popcll(peers);   // group leader
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // thread `tid` == digit: per-wave exclusive offsets and the chunk's digit prefix
@@ -183,7 +189,7 @@ hipError_t gs_launch_radix_scan(uint32_t *block_hist, int nblocks, uint32_t *dig
 }
 
 hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
-                             uint32_t *block_hist, uint32_t *digit_total, int *result_in_b, hipStream_t stream) {
+                             uint32_t *block_hist, uint32_t *digit_total, int *result_in_b, hipStream_t stream, bool ballot_ranks) {
     *result_in_b = 0;
     if (n <= 0) return hipSuccess;
     const int nblocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -198,7 +204,8 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
         hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, n, shift, mask, block_hist, nblocks);
         hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks);
+        if (ballot_ranks) hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks);
+        else hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks);
         uint64_t *t = src; src = dst; dst = t;
         *result_in_b ^= 1;
     }

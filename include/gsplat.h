@@ -77,7 +77,9 @@ typedef struct {
     int32_t profile_stages;   /* 1: record hipEvents around every stage (gs_get_stage_times) */
     int32_t bin_path;         /* 0: generate-in-pass binning on 32-bit words (default); 1: explicit
                                  64-bit tile|id instances + two radix passes (fallback, same result) */
-    int32_t reserved[8];
+    int32_t rank_mode;        /* radix-sort stable ranks: 0 = one LDS atomic-add-return per key (lane-ordered on
+                                 gfx950, measured), 1 = wave64 ballots (portable); same lists either way   */
+    int32_t reserved[7];
 } gs_config;
 
 typedef struct gs_ctx gs_ctx;

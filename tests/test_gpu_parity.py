@@ -35,14 +35,14 @@ def _oracle_rects(O, bbs, gx, gy):
 
 
 @pytest.mark.parametrize("n,W,H,deg,seed", CASES)
-@pytest.mark.parametrize("order,bin_path", [(0, 0), (1, 0), (2, 0), (1, 1), (0, 1)])
-def test_preprocess_and_binning_bit_exact(oracle, n, W, H, deg, seed, order, bin_path):
+@pytest.mark.parametrize("order,bin_path,rank_mode", [(0, 0, 0), (1, 0, 0), (2, 0, 0), (1, 1, 0), (0, 1, 0), (1, 0, 1), (1, 1, 1)])
+def test_preprocess_and_binning_bit_exact(oracle, n, W, H, deg, seed, order, bin_path, rank_mode):
     from gaussiansplat_amd import backend as B
     O = oracle
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
     gx, gy = (W + 15) // 16, (H + 15) // 16
     pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam)
-    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, export_debug=True, t_min=0.0, bin_path=bin_path)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, export_debug=True, t_min=0.0, bin_path=bin_path, rank_mode=rank_mode)
     ctx.preprocess()
     for name, which in (("ts", B.ARR_TS), ("tps", B.ARR_TPS), ("mu", B.ARR_MU), ("cov3d", B.ARR_COV3D), ("cov2d", B.ARR_COV2D),
                         ("invcov", B.ARR_INVCOV), ("bbs", B.ARR_BBS), ("rgb", B.ARR_RGB), ("sig", B.ARR_SIG)):

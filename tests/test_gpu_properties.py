@@ -14,12 +14,12 @@ def c3():
     return (n, W, H, deg) + scene_and_cameras(n, W, H, deg, 1236)
 
 
-@pytest.mark.parametrize("order,bin_path", [(1, 0), (0, 0), (1, 1)])
-def test_c3_binning_invariants(c3, order, bin_path):
+@pytest.mark.parametrize("order,bin_path,rank_mode", [(1, 0, 0), (0, 0, 0), (1, 1, 0), (1, 0, 1)])
+def test_c3_binning_invariants(c3, order, bin_path, rank_mode):
     from gaussiansplat_amd import backend as B
     n, W, H, deg, sc, cam, T, P, ocam = c3
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0, bin_path=bin_path)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0, bin_path=bin_path, rank_mode=rank_mode)
     ctx.preprocess(); ctx.bin()
     I = ctx.num_instances
     rect = ctx.get_array(B.ARR_TILE_RECT).astype(np.int64)
@@ -42,7 +42,7 @@ def test_c3_binning_invariants(c3, order, bin_path):
         assert np.all(np.diff(dk[perm].astype(np.int64)) >= 0)            # depth order, stable: ties by index
         tie = np.diff(dk[perm].astype(np.int64)) == 0
         assert np.all(np.diff(perm.astype(np.int64))[tie] > 0)
-    if order == 1 and bin_path == 0:
+    if order == 1 and bin_path == 0:      # both rank modes
         # the headline configuration, bit-exact against the oracle: 1 M boxes, 30 M sorted instances
         from oracle import oracle as O
         pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, omp=True)
