@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--t-min", type=float, default=1e-5, help="transmittance early-out (0 = literal reference)")
     ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal (t_min=0) measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -139,7 +140,7 @@ def main():
 
     def make(t_min):
         return R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene, device=local, order=args.order, t_min=t_min,
-                             profile_stages=True)
+                             profile_stages=True, alpha_cull=not args.no_cull)
 
     def step(r):
         R.resetGrads(r)
@@ -176,7 +177,8 @@ def main():
     dt = timed(r, args.steps, args.warmup)
     stats = r.ctx.stage_stats()
     I = r.ctx.num_instances
-    wf, wb = r.ctx.work_counters()
+    wc = r.ctx.work_counters_ex()
+    wf, wb = wc["walked_fwd"], wc["walked_bwd"]
     value = world * n * args.steps / dt / 1e6
 
     out = None
@@ -194,7 +196,8 @@ def main():
             "config": {"workload": f"{args.config}: {n} gaussians, {W}x{H}, SH{deg}, one camera view per GPU per step, fwd+bwd"
                                    + (", one RCCL all-reduce of 59N f32" if world > 1 else ""),
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
-                       "instances": I, "walked_fwd": wf, "walked_bwd": wb, "seed": seed},
+                       "instances": I, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
+                       "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "seed": seed},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": measured_traffic(dom, args.config, args.t_min), "algorithmic_bytes": by, "avg_ms": stage_ms[dom],

@@ -27,13 +27,13 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_synchronize", "gs_set_model", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
-           "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_debug_time_composite")
+           "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite")
 
 
 class GsConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("tile_size", C.c_int32), ("order", C.c_int32), ("t_min", C.c_float),
                 ("deterministic", C.c_int32), ("export_debug", C.c_int32), ("profile_stages", C.c_int32),
-                ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("alpha_cull", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class GsGrads(C.Structure):
@@ -96,6 +96,7 @@ def load():
     L.gs_get_stage_times.argtypes = [vp, fp]
     L.gs_get_stage_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.gs_get_work_counters.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.gs_get_work_counters_ex.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gs_debug_time_composite.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -111,12 +112,13 @@ class Context:
     """Owns one gs_ctx (one GPU, one stream)."""
 
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
-                 profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 0):
+                 profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 0,
+                 alpha_cull: bool = True):
         self.L = load()
         cfg = default_config()
         cfg.order, cfg.t_min = int(order), float(t_min)
         cfg.export_debug, cfg.profile_stages, cfg.deterministic = int(export_debug), int(profile_stages), int(deterministic)
-        cfg.bin_path, cfg.rank_mode = int(bin_path), int(rank_mode)
+        cfg.bin_path, cfg.rank_mode, cfg.alpha_cull = int(bin_path), int(rank_mode), int(alpha_cull)
         self.cfg = cfg
         self.h = C.c_void_p()
         rc = self.L.gs_create(C.byref(self.h), device, C.byref(cfg))
@@ -274,6 +276,12 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         self._chk(self.L.gs_get_work_counters(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def work_counters_ex(self) -> dict:
+        """walked = list entries staged; evaluated = those that survived the alpha_cull no-op test."""
+        o = (C.c_int64 * 4)()
+        self._chk(self.L.gs_get_work_counters_ex(self.h, o))
+        return dict(walked_fwd=int(o[0]), walked_bwd=int(o[1]), evaluated_fwd=int(o[2]), evaluated_bwd=int(o[3]))
 
     def time_composite(self, which: int, variant: int, reps: int = 10) -> float:
         ms = C.c_float()

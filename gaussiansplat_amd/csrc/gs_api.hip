@@ -96,7 +96,7 @@ struct gs_ctx {
     bool ev_fresh[GS_STAGE_COUNT] = {};      // ... and not yet added to the accumulators
     double ev_sum[GS_STAGE_COUNT] = {};
     int64_t ev_cnt[GS_STAGE_COUNT] = {};
-    DevBuf counters;                         // 2 x u64: entries walked fwd / bwd
+    DevBuf counters;                         // 4 x u64: entries walked fwd / bwd, evaluated fwd / bwd
     DevBuf grads_flat;                       // gs_grads_alloc
     DevBuf dpc;                              // 4 x n scratch between the two backward kernels
     DevBuf loss_maps, loss_acc, loss_in[2], loss_dc;
@@ -160,6 +160,7 @@ void gs_default_config(gs_config *cfg) {
     cfg->deterministic = 0;
     cfg->export_debug = 0;
     cfg->profile_stages = 0;
+    cfg->alpha_cull = 1;
 }
 
 int gs_abi_version(void) { return GS_ABI_VERSION; }
@@ -422,12 +423,12 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
-    HIPCHK(c, c->counters.ensure(16));
+    HIPCHK(c, c->counters.ensure(32));
     a.walked = c->counters.as<unsigned long long>();
-    a.variant = c->variant_fwd;
+    a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
     {
         StageTimer t(c, GS_STAGE_COMPOSITE_FWD);
-        HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 16, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32, c->stream));
         HIPCHK(c, gs_launch_composite_fwd(a, c->stream));
     }
     const hipMemcpyKind kind = mem == GS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
@@ -461,12 +462,13 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     a.dC = dC_dev; a.g2d = det ? nullptr : c->g2d.as<float>(); a.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
     a.walked = c->counters.as<unsigned long long>() + 1;
-    a.variant = c->variant_bwd;
+    a.variant = c->variant_bwd; a.cull = c->cfg.alpha_cull != 0;
     c->last_dC = dC_dev;
     {
         StageTimer t(c, GS_STAGE_COMPOSITE_BWD);
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
         HIPCHK(c, hipMemsetAsync(a.walked, 0, 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(a.walked + 2, 0, 8, c->stream));
         HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
     }
     GsPreprocessBwdArgs b{};
@@ -761,7 +763,8 @@ int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     a.dC = c->last_dC; a.walked = nullptr;
-    a.g2d = c->cfg.deterministic ? nullptr : c->g2d.as<float>(); a.g2d_fixed = c->cfg.deterministic ? c->g2d.as<long long>() : nullptr; a.variant = variant % 100; a.map_mode = variant / 100;
+    a.g2d = c->cfg.deterministic ? nullptr : c->g2d.as<float>(); a.g2d_fixed = c->cfg.deterministic ? c->g2d.as<long long>() : nullptr; a.variant = variant % 100; a.map_mode = (variant / 100) % 10;
+    a.cull = (c->cfg.alpha_cull != 0) != (variant >= 1000);                  // +1000: the other cull setting
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));   // warm
@@ -786,6 +789,17 @@ int gs_get_work_counters(gs_ctx *c, int64_t *walked_fwd, int64_t *walked_bwd) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (walked_fwd) *walked_fwd = (int64_t)h[0];
     if (walked_bwd) *walked_bwd = (int64_t)h[1];
+    return GS_OK;
+}
+
+int gs_get_work_counters_ex(gs_ctx *c, int64_t out[4]) {
+    if (!c || !out) return GS_ERR_INVALID;
+    if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_work_counters_ex: gs_forward first");
+    if (bind_device(c)) return GS_ERR_HIP;
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, c->counters.p, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 4; ++i) out[i] = (int64_t)h[i];
     return GS_OK;
 }
 

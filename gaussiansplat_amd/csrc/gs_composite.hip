@@ -49,9 +49,15 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles, int gx, int mode
 // which is exactly 0 inside the box (med3 returns d itself) and drives exp2 to 0 outside.
 // lo/hi = box edge - mu -/+ 0.25 are lane independent and staged once per (tile, splat).
 #define GS_BIG 1.0e30f
+// A (tile, splat) entry whose largest alpha over the tile's pixels is below 2^-27 is a no-op in the
+// reference's own fp32 arithmetic: T*(1-alpha) == T exactly (alpha < 2^-25 already rounds 1-alpha to 1)
+// and rgb*alpha*T is below 7.5e-9*|rgb|, under half an ulp of any accumulated colour above 1e-7.  Such
+// entries are dropped while staging (gs_config.alpha_cull, default on; lists stay the reference's).
+#define GS_ALPHA_CULL_LOG2 (-27.0f)
 // Lane-independent terms of one splat, computed once per (tile, splat) by the staging lane:
 // q0 = {mu_x, mu_y, log2 sig, x_lo}, q1 = {k i0, k (i1+i2), k i3, x_hi}, q2 = {r, g, b, y_lo}, y_hi   (k = -1/2 log2 e)
-__device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2) {
+__device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2,
+                                              const int tx0, const int ty0, bool &keep) {
     const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
     const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
     const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
@@ -65,10 +71,34 @@ __device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2
     q0 = make_float4(n0.x, n0.y, l2s, xlo);
     q1 = make_float4(NEG_HALF_LOG2E * n1.x, NEG_HALF_LOG2E * (n1.y + n1.z), NEG_HALF_LOG2E * n1.w, xhi);
     q2 = make_float4(n2.x, n2.y, n2.z, ylo);
+    // No-op test (GS_ALPHA_CULL_LOG2): an upper bound of log2(alpha) over the pixels of THIS tile that lie in
+    // the splat's pixel box.  f(dx,dy) = A dx^2 + B dx dy + C dy^2 (log2 units, concave) is maximised over the
+    // rectangle R = tile /\ box - mu: at the centre if 0 is in R, else on an edge facing the centre, where
+    // the 1-D maximiser is clamped to the edge.  Anything not provably concave and finite is kept.
+    {
+        const float rx0 = (float)max(tx0, xmin) - n0.x, rx1 = (float)min(tx0 + GS_TILE - 1, xmax) - n0.x;
+        const float ry0 = (float)max(ty0, ymin) - n0.y, ry1 = (float)min(ty0 + GS_TILE - 1, ymax) - n0.y;
+        const float A = q1.x, B = q1.y, C = q1.z;
+        const float cx = __builtin_amdgcn_fmed3f(0.0f, rx0, rx1), cy = __builtin_amdgcn_fmed3f(0.0f, ry0, ry1);
+        const float dy1 = __builtin_amdgcn_fmed3f(-0.5f * B * cx * fast_rcp(C), ry0, ry1);
+        const float dx2 = __builtin_amdgcn_fmed3f(-0.5f * B * cy * fast_rcp(A), rx0, rx1);
+        const float f1 = fmaf(A * cx, cx, dy1 * fmaf(B, cx, C * dy1));
+        const float f2 = fmaf(C * cy, cy, dx2 * fmaf(B, cy, A * dx2));
+        const float fm = (cx != 0.0f && cy != 0.0f) ? fmaxf(f1, f2) : (cx != 0.0f ? f1 : f2);
+        const bool concave = A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f;
+        const bool nopix = rx0 > rx1 || ry0 > ry1;                     // no pixel of this tile inside the box
+        const bool noop = empty || nopix || (concave && fm + l2s < GS_ALPHA_CULL_LOG2);
+        keep = !noop;
+    }
     return yhi;
 }
 
-template <bool EARLY, int UNROLL, int MINW>
+// kept-entry slot of this lane inside the wave's keep mask
+__device__ __forceinline__ int slot_of(uint64_t m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+template <bool EARLY, int UNROLL, int MINW, bool CULL>
 __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
@@ -81,9 +111,11 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
     const float fx = (float)px;
     const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
 
+    const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);     // first pixel of the tile (1-based)
+
     float Cr[4], Cg[4], Cb[4], T[4], Tdead[4], fy[4];
     bool dead[4];
-    uint32_t walked = 0;
+    uint32_t walked = 0, evaluated = 0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         Cr[p] = Cg[p] = Cb[p] = 0.0f;
@@ -108,15 +140,24 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
             if (__ballot(live) == 0ull) break;
         }
         float4 q0, q1, q2;
-        const float yhi_l = stage_record(q0, q1, q2, n0, n1, n2);
+        bool keep;
+        const float yhi_l = stage_record(q0, q1, q2, n0, n1, n2, tx0, ty0, keep);
+        int slot = lane, nk = cnt;
+        if (CULL) {                                                     // compact the batch to the entries that can matter
+            keep = keep && lane < cnt;
+            const uint64_t m = __ballot(keep);
+            slot = slot_of(m); nk = __popcll(m);
+        } else keep = true;
         __syncthreads();                                                // one wave: orders LDS reads/writes only
-        sp[3 * lane] = q0; sp[3 * lane + 1] = q1; sp[3 * lane + 2] = q2;
-        syhi[lane] = yhi_l;
+        if (keep) {
+            sp[3 * slot] = q0; sp[3 * slot + 1] = q1; sp[3 * slot + 2] = q2;
+            syhi[slot] = yhi_l;
+        }
         __syncthreads();
         pos = base + CB + lane;
         if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
 #pragma unroll UNROLL
-        for (int k = 0; k < cnt; ++k) {
+        for (int k = 0; k < nk; ++k) {
             const float4 q0k = sp[3 * k], q1k = sp[3 * k + 1], q2k = sp[3 * k + 2];
             const float yhi = syhi[k];
             const float dX = fx - q0k.x;
@@ -135,9 +176,9 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
                 T[p] = T[p] - w;
             }
         }
-        walked += (uint32_t)cnt;
+        walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
     }
-    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
+    if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 2, (unsigned long long)evaluated); }
     if (px <= a.W) {
         const size_t plane = (size_t)a.W * a.H;
 #pragma unroll
@@ -238,10 +279,11 @@ __device__ __forceinline__ int out_component(int lane) {
 // 1/(1-alpha) needs no guard; d sig = -(1/sig) * sum(dd) needs no accumulator of its own.
 // DET: the per-(tile, splat) sums are added as 2^-40 fixed-point integers (64-bit integer atomics are
 // order independent, so the gradients are bitwise reproducible run to run); otherwise float atomics.
-template <bool EARLY, int MINW, bool DET, bool SWZ>
+template <bool EARLY, int MINW, bool DET, bool SWZ, bool CULL>
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 4];
     __shared__ float syhi[CB];
+    __shared__ uint32_t sid[CB];
     const int ntiles = a.gx * a.gy;
     const int tile = tile_of_block(blockIdx.x, ntiles, a.gx, a.map_mode);
     if (tile >= ntiles) return;
@@ -254,9 +296,11 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     const int ocomp = out_component(lane);
     const bool take_hi = (lane & 15) == 14, take_9 = lane == 61;
 
+    const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);
+
     float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
     bool dead[4];
-    uint32_t walked = 0;
+    uint32_t walked = 0, evaluated = 0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int py = py0 + 4 * p;
@@ -287,20 +331,29 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
             if (__ballot(live) == 0ull) break;
         }
         float4 q0, q1, q2;
-        const float yhi_l = stage_record(q0, q1, q2, n0, n1, n2);
+        bool keep;
+        const float yhi_l = stage_record(q0, q1, q2, n0, n1, n2, tx0, ty0, keep);
+        int slot = lane, nk = cnt;
+        if (CULL) {
+            keep = keep && lane < cnt;
+            const uint64_t m = __ballot(keep);
+            slot = slot_of(m); nk = __popcll(m);
+        } else keep = true;
         {
             const float sg = n0.z;
             __syncthreads();
-            sp[4 * lane] = q0; sp[4 * lane + 1] = q1; sp[4 * lane + 2] = q2;
-            // i0, mc, i3 and 1/sig (sig == 0: d opacity is 0 anyway)
-            sp[4 * lane + 3] = make_float4(n1.x, 0.5f * (n1.y + n1.z), n1.w, sg > 0.0f ? fast_rcp(sg) : 0.0f);
-            syhi[lane] = yhi_l;
+            if (keep) {
+                sp[4 * slot] = q0; sp[4 * slot + 1] = q1; sp[4 * slot + 2] = q2;
+                // i0, mc, i3 and 1/sig (sig == 0: d opacity is 0 anyway)
+                sp[4 * slot + 3] = make_float4(n1.x, 0.5f * (n1.y + n1.z), n1.w, sg > 0.0f ? fast_rcp(sg) : 0.0f);
+                syhi[slot] = yhi_l;
+                sid[slot] = nid;                                         // gaussian id of the staged entry
+            }
             __syncthreads();
         }
-        const uint32_t my_id = nid;                                      // id of entry `lane` of this batch
         pos = base + CB + lane;
         if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
-        for (int k = 0; k < cnt; ++k) {
+        for (int k = 0; k < nk; ++k) {
             const float4 q0k = sp[4 * k], q1k = sp[4 * k + 1], q2k = sp[4 * k + 2];
             const float yhi = syhi[k];
             const float dX = fx - q0k.x;
@@ -314,7 +367,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
                 const float ey = dY[p] - __builtin_amdgcn_fmed3f(dY[p], q2k.w, yhi);
                 al[p] = fast_exp2(fmaf(-GS_BIG, fabsf(ey), fmaf(dY[p], fmaf(q1k.z, dY[p], B0), A0)));
             }
-            if (__ballot(((al[0] + al[1]) + (al[2] + al[3])) != 0.0f) == 0ull) continue;   // nobody in the tile touched it
+            if (!CULL && __ballot(((al[0] + al[1]) + (al[2] + al[3])) != 0.0f) == 0ull) continue;   // nobody in the tile touched it
             float ar = 0.0f, ag = 0.0f, ab = 0.0f, q0s = 0.0f, q1s = 0.0f, q2s = 0.0f;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -346,7 +399,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
             const float hi_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x101, 0xF, 0xF, true));
             const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));
             const float outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)my_id, k);
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
             if (ocomp >= 0) {
                 if (DET) {
                     const float sc = fminf(fmaxf(outv * GS_FIXED_SCALE, -9.0e18f), 9.0e18f);      // saturate, never wrap
@@ -357,9 +410,9 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
                 }
             }
         }
-        walked += (uint32_t)cnt;
+        walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
     }
-    if (lane == 0 && a.walked) atomicAdd(a.walked, (unsigned long long)walked);
+    if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 2, (unsigned long long)evaluated); }
 }
 
 // Launch configurations were chosen by A/B timing on MI355X at C3 (tools/abtest.py):
@@ -372,7 +425,8 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s) {
     const dim3 grid(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8), block(64);
     const bool early = a.t_min > 0.0f;
     const int v = a.variant == 0 ? (early ? 1 : 2) : a.variant;
-#define GS_F(E, U, M) hipLaunchKernelGGL((composite_fwd_kernel<E, U, M>), grid, block, 0, s, a)
+#define GS_F(E, U, M) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, U, M, true>), grid, block, 0, s, a); \
+                           else hipLaunchKernelGGL((composite_fwd_kernel<E, U, M, false>), grid, block, 0, s, a); } while (0)
     if (v == 1) { if (early) GS_F(true, 2, 1); else GS_F(false, 2, 1); }
     else if (v == 2) { if (early) GS_F(true, 2, 8); else GS_F(false, 2, 8); }
     else { if (early) GS_F(true, 1, 8); else GS_F(false, 1, 8); }
@@ -386,12 +440,14 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s) {
     const dim3 grid(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8), block(64);
     const bool early = a.t_min > 0.0f;
     const int v = a.variant == 0 ? 3 : a.variant;      // measured best: row sums through ds_swizzle, registers unconstrained
-#define GS_B(E, M, Z) do { if (a.g2d_fixed) hipLaunchKernelGGL((composite_bwd_kernel<E, M, true, Z>), grid, block, 0, s, a); \
-                           else hipLaunchKernelGGL((composite_bwd_kernel<E, M, false, Z>), grid, block, 0, s, a); } while (0)
+#define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, 0, s, a); \
+                               else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, 0, s, a); } while (0)
+#define GS_B(E, M, Z) do { if (a.g2d_fixed) GS_B2(E, M, true, Z); else GS_B2(E, M, false, Z); } while (0)
     if (v == 1) { if (early) GS_B(true, 1, false); else GS_B(false, 1, false); }
     else if (v == 2) { if (early) GS_B(true, 8, false); else GS_B(false, 8, false); }
     else if (v == 3) { if (early) GS_B(true, 1, true); else GS_B(false, 1, true); }
     else { if (early) GS_B(true, 8, true); else GS_B(false, 8, true); }
 #undef GS_B
+#undef GS_B2
     return hipGetLastError();
 }

@@ -73,7 +73,8 @@ def initGrads(splatData: SplatData3D) -> SplatGrads3D:
 
 class GaussianRenderer3D:               # renderer.jl:205-219
     def __init__(self, splatData: SplatData3D, imgSize, sh_degree: int, device: int = 0, order: int = B.ORDER_DEPTH_DESC,
-                 t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False, deterministic: bool = False):
+                 t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False, deterministic: bool = False,
+                 alpha_cull: bool = True):
         import torch
         self.splatData = splatData
         self._splatGrads = initGrads(splatData)
@@ -86,7 +87,7 @@ class GaussianRenderer3D:               # renderer.jl:205-219
         self.sh_degree = sh_degree
         self.camera: Camera | None = None
         self.ctx = B.Context(device=device, order=order, t_min=t_min, export_debug=export_debug, profile_stages=profile_stages,
-                             deterministic=deterministic)
+                             deterministic=deterministic, alpha_cull=alpha_cull)
         # one HIP stream per renderer, shared by the library and by torch's in-place ops on the
         # renderer's tensors; _begin/_end fence it against the caller's current torch stream
         self.stream = torch.cuda.Stream(dev)

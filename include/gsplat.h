@@ -79,7 +79,11 @@ typedef struct {
                                  64-bit tile|id instances + two radix passes (fallback, same result) */
     int32_t rank_mode;        /* radix-sort stable ranks: 0 = one LDS atomic-add-return per key (lane-ordered on
                                  gfx950, measured), 1 = wave64 ballots (portable); same lists either way   */
-    int32_t reserved[7];
+    int32_t alpha_cull;       /* 1 (default): while staging a tile's list the composite kernels drop every
+                                 (tile, splat) entry whose largest alpha over that tile's pixels is below 2^-27
+                                 -- a no-op in the reference's own fp32 arithmetic (T*(1-alpha) == T, colour term
+                                 < 7.5e-9*|rgb|).  The lists (gs_bin) are unchanged.  0: evaluate every entry. */
+    int32_t reserved[6];
 } gs_config;
 
 typedef struct gs_ctx gs_ctx;
@@ -224,6 +228,10 @@ int gs_get_stage_stats(gs_ctx *ctx, double sum_ms[GS_STAGE_COUNT], int64_t count
 /* Work counters of the last frame: list entries actually walked by the composite kernels
  * (== gs_num_instances when t_min == 0; fewer with the transmittance early-out). */
 int gs_get_work_counters(gs_ctx *ctx, int64_t *walked_fwd, int64_t *walked_bwd);
+
+/* out = {walked_fwd, walked_bwd, evaluated_fwd, evaluated_bwd}: `evaluated` counts the walked entries that
+ * survived the alpha_cull no-op test and were evaluated per pixel (== walked when alpha_cull == 0). */
+int gs_get_work_counters_ex(gs_ctx *ctx, int64_t out[4]);
 
 /* Profiling aid: re-launch the composite forward (which=0) or backward (which=1) kernel of the
  * current frame `reps` times with kernel variant `variant` and return the mean hipEvent time.

@@ -26,7 +26,10 @@ mutable struct GsConfig                      # must mirror gs_config (64 bytes)
     deterministic::Int32
     export_debug::Int32
     profile_stages::Int32
-    reserved::NTuple{9, Int32}
+    bin_path::Int32
+    rank_mode::Int32
+    alpha_cull::Int32
+    reserved::NTuple{6, Int32}
 end
 
 struct GsGrads                               # gs_grads: device pointers, may be C_NULL
@@ -52,7 +55,7 @@ function check(r::HipRenderer, rc::Cint)
 end
 
 function defaultConfig()
-    cfg = GsConfig(0, 0, 0, 0f0, 0, 0, 0, ntuple(_ -> Int32(0), 9))
+    cfg = GsConfig(0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, ntuple(_ -> Int32(0), 6))
     ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
     return cfg
 end
