@@ -26,6 +26,9 @@
 #define NEG_HALF_LOG2E (-0.72134752044448170368f)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// A loop-invariant constant the compiler must keep in a VGPR: measured on gfx950 (tools/valu_ubench3.hip) a
+// v_fma_f32 with an SGPR source issues at 4.4 cycles per wave64, with VGPR sources only at 2.3.
+__device__ __forceinline__ float vgpr_const(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // Workgroup -> tile map.  Measured on MI355X at C3 (tools/abtest.py, variants +100/+200): the plain
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
     const float fx = (float)px;
+    const float nbig = vgpr_const(-GS_BIG);
     const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
 
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);     // first pixel of the tile (1-based)
@@ -162,14 +166,14 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
             const float yhi = syhi[k];
             const float dX = fx - q0k.x;
             const float ex = dX - __builtin_amdgcn_fmed3f(dX, q0k.w, q1k.w);          // 0 inside the box columns
-            const float A0 = fmaf(-GS_BIG, fabsf(ex), fmaf(q1k.x * dX, dX, q0k.z));  // k i0 dX^2 + log2 sig - penalty
+            const float A0 = fmaf(nbig, fabsf(ex), fmaf(q1k.x * dX, dX, q0k.z));  // k i0 dX^2 + log2 sig - penalty
             const float B0 = q1k.y * dX;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const float dY = fy[p] - q0k.y;
                 const float ey = dY - __builtin_amdgcn_fmed3f(dY, q2k.w, yhi);
                 const float pw = fmaf(dY, fmaf(q1k.z, dY, B0), A0);
-                const float w = fast_exp2(fmaf(-GS_BIG, fabsf(ey), pw)) * T[p];
+                const float w = fast_exp2(fmaf(nbig, fabsf(ey), pw)) * T[p];
                 Cr[p] = fmaf(q2k.x, w, Cr[p]);
                 Cg[p] = fmaf(q2k.y, w, Cg[p]);
                 Cb[p] = fmaf(q2k.z, w, Cb[p]);
@@ -260,6 +264,60 @@ __device__ __forceinline__ float wave_sum9(float v) {
     return v;
 }
 
+// rows: lanes 0-7 <- a(l)+a(l+8) ; lanes 8-15 <- b(l-8)+b(l).  Two bank-masked DPP adds (lanes of a disabled bank keep
+// their value), 13 cycles for the pair against 17 for two butterfly steps -- and one register remains instead of two.
+// Inline asm: the hazard recogniser does not see the DPP reads, hence the leading s_nop (VALU write -> DPP read).
+__device__ __forceinline__ float fold8(float a, float b) {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3"
+                 : "+v"(b) : "v"(a));
+    return b;
+}
+// Reduce-scatter tree over all six lane bits: lane 16r+7 ends with the wave total of (v0, v2, v1, v3)[r],
+// lane 16r+15 with that of (v4, v6, v5, v7)[r]:  4 + 2 lane-swap folds, one DPP fold, three row_shr adds.
+__device__ __forceinline__ float reduce8_tree(const float (&v)[8]) {
+    const float b0 = fold32(v[0], v[1]), b1 = fold32(v[2], v[3]), b2 = fold32(v[4], v[5]), b3 = fold32(v[6], v[7]);
+    float d = fold8(fold16(b0, b1), fold16(b2, b3));
+    d = dpp_add<0x114, 0xF, 0xF>(d);      // row_shr:4
+    d = dpp_add<0x112, 0xF, 0xF>(d);      // row_shr:2
+    d = dpp_add<0x111, 0xF, 0xF>(d);      // row_shr:1 -> lanes 7 and 15 of every row hold their group's total
+    return d;
+}
+// The same tree with every exchange on the LDS crossbar (ds_swizzle inside 32 lanes, ds_bpermute across the halves):
+// the VALU -- the unit these kernels are bound by -- pays two selects and one add per fold (10.7 cycles against 14.3
+// for a lane-swap fold) and one add per butterfly step (2.3 against 4.9 for a DPP add).  Every lane of an 8-lane
+// group ends with its group's total.
+template <int PATTERN>
+__device__ __forceinline__ float fold_swz(float a, float b, bool upper) {
+    const float send = upper ? a : b, keep = upper ? b : a;
+    return keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), PATTERN));
+}
+__device__ __forceinline__ float fold32_lds(float a, float b, bool upper, int xaddr) {
+    const float send = upper ? a : b, keep = upper ? b : a;
+    return keep + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(send)));
+}
+__device__ __forceinline__ float reduce8_lds(const float (&v)[8], int lane, int xaddr) {
+    const bool u32 = (lane & 32) != 0, u16 = (lane & 16) != 0, u8 = (lane & 8) != 0;
+    const float b0 = fold32_lds(v[0], v[1], u32, xaddr), b1 = fold32_lds(v[2], v[3], u32, xaddr);
+    const float b2 = fold32_lds(v[4], v[5], u32, xaddr), b3 = fold32_lds(v[6], v[7], u32, xaddr);
+    const float c0 = fold_swz<0x401F>(b0, b1, u16), c1 = fold_swz<0x401F>(b2, b3, u16);       // xor 16
+    float d = fold_swz<0x201F>(c0, c1, u8);                                                  // xor 8
+    d = swz_add<0x101F>(d); d = swz_add<0x081F>(d); d = swz_add<0x041F>(d);                  // xor 4, 2, 1
+    return d;
+}
+__device__ __forceinline__ float wave_sum_lds(float v, int xaddr) {
+    v = swz_add<0x041F>(v); v = swz_add<0x081F>(v); v = swz_add<0x101F>(v); v = swz_add<0x201F>(v); v = swz_add<0x401F>(v);
+    return v + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v)));
+}
+__device__ __forceinline__ int out_component_tree(int lane) {
+    const int row = lane >> 4, pos = lane & 15;
+    if (pos == 7) return row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;      // (dr, db, dg, dsig)
+    if (pos == 15) return row == 0 ? 4 : row == 1 ? 6 : row == 2 ? 5 : 7;     // (dmx, d00, dmy, d01)
+    if (lane == 62) return 9;                                                  // d11 (merged in by one DPP move)
+    return -1;
+}
+
 // g2d row of a gaussian: [dr dg db dsig dmx dmy d00 d01 (d10 = d01, filled by the reader) d11]
 // lane 15 of row r adds lo -> LO_COMP[r] ; lane 14 of row r adds hi -> HI_COMP[r] ; lane 61 adds the 9th
 __device__ __forceinline__ int out_component(int lane) {
@@ -279,8 +337,9 @@ __device__ __forceinline__ int out_component(int lane) {
 // 1/(1-alpha) needs no guard; d sig = -(1/sig) * sum(dd) needs no accumulator of its own.
 // DET: the per-(tile, splat) sums are added as 2^-40 fixed-point integers (64-bit integer atomics are
 // order independent, so the gradients are bitwise reproducible run to run); otherwise float atomics.
-template <bool EARLY, int MINW, bool DET, bool SWZ, bool CULL>
+template <bool EARLY, int MINW, bool DET, int RED, bool CULL>      // RED: 0 DPP row sums, 1 ds_swizzle row sums, 2 reduce-scatter tree (lane swaps + DPP), 3 the tree on the LDS crossbar
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
+    constexpr bool SWZ = RED == 1;
     __shared__ float4 sp[CB * 4];
     __shared__ float syhi[CB];
     __shared__ uint32_t sid[CB];
@@ -291,10 +350,13 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
     const float fx = (float)px;
+    const float nbig = vgpr_const(-GS_BIG);
     const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
     const size_t plane = (size_t)a.W * a.H;
-    const int ocomp = out_component(lane);
+    const int ocomp = RED >= 2 ? out_component_tree(lane) : out_component(lane);
+    const int xaddr = (lane ^ 32) << 2;                                  // ds_bpermute address of the partner lane
     const bool take_hi = (lane & 15) == 14, take_9 = lane == 61;
+    const uint32_t ooff = ocomp >= 0 ? 4u * (uint32_t)ocomp : 0u;        // byte offset inside the gaussian's g2d row
 
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);
 
@@ -358,31 +420,33 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
             const float yhi = syhi[k];
             const float dX = fx - q0k.x;
             const float ex = dX - __builtin_amdgcn_fmed3f(dX, q0k.w, q1k.w);
-            const float A0 = fmaf(-GS_BIG, fabsf(ex), fmaf(q1k.x * dX, dX, q0k.z));
+            const float A0 = fmaf(nbig, fabsf(ex), fmaf(q1k.x * dX, dX, q0k.z));
             const float B0 = q1k.y * dX;
             float al[4], dY[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 dY[p] = fy[p] - q0k.y;
                 const float ey = dY[p] - __builtin_amdgcn_fmed3f(dY[p], q2k.w, yhi);
-                al[p] = fast_exp2(fmaf(-GS_BIG, fabsf(ey), fmaf(dY[p], fmaf(q1k.z, dY[p], B0), A0)));
+                al[p] = fast_exp2(fmaf(nbig, fabsf(ey), fmaf(dY[p], fmaf(q1k.z, dY[p], B0), A0)));
             }
             if (!CULL && __ballot(((al[0] + al[1]) + (al[2] + al[3])) != 0.0f) == 0ull) continue;   // nobody in the tile touched it
-            float ar = 0.0f, ag = 0.0f, ab = 0.0f, q0s = 0.0f, q1s = 0.0f, q2s = 0.0f;
+            float ar, ag, ab, q0s, q1s, q2s;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const float w = al[p] * T[p];
                 const float cdot = fmaf(q2k.x, dCr[p], fmaf(q2k.y, dCg[p], q2k.z * dCb[p]));
-                ar = fmaf(w, dCr[p], ar);
-                ag = fmaf(w, dCg[p], ag);
-                ab = fmaf(w, dCb[p], ab);
                 S[p] = fmaf(-cdot, w, S[p]);
                 const float inv = fast_rcp(1.0f - al[p]);
                 const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));
                 const float dd = -(al[p] * dalpha);
-                q0s += dd;
-                q1s = fmaf(dd, dY[p], q1s);
-                q2s = fmaf(dd * dY[p], dY[p], q2s);
+                const float ddy = dd * dY[p];
+                if (p == 0) {                                             // plain products: no fma against a zero
+                    ar = w * dCr[0]; ag = w * dCg[0]; ab = w * dCb[0];
+                    q0s = dd; q1s = ddy; q2s = ddy * dY[0];
+                } else {
+                    ar = fmaf(w, dCr[p], ar); ag = fmaf(w, dCg[p], ag); ab = fmaf(w, dCb[p], ab);
+                    q0s += dd; q1s += ddy; q2s = fmaf(ddy, dY[p], q2s);
+                }
                 T[p] = T[p] - w;
             }
             const float4 q3k = sp[4 * k + 3];                           // i0, mc, i3, 1/sig
@@ -393,20 +457,33 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
             v[5] = -fmaf(q3k.y, qx, q3k.z * q1s);
             v[6] = 0.5f * dX * qx;
             v[7] = 0.5f * dX * q1s;
-            float lo, hi;
-            reduce8<SWZ>(v, lo, hi);
-            const float t9 = wave_sum9<SWZ>(0.5f * q2s);
-            const float hi_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x101, 0xF, 0xF, true));
-            const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));
-            const float outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
+            float outv;
+            if (RED == 3) {
+                const float d = reduce8_lds(v, lane, xaddr);
+                const float t9 = wave_sum_lds(0.5f * q2s, xaddr);
+                outv = lane == 62 ? t9 : d;
+            } else if (RED == 2) {
+                const float d = reduce8_tree(v);
+                const float t9 = wave_sum_to_lane63(0.5f * q2s);
+                // lane 62 <- t9(63): row_shl:1 into row 3 / bank 3 only; lane 63 has no source and keeps d
+                outv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d), __float_as_int(t9), 0x101, 0x8, 0x8, false));
+            } else {
+                float lo, hi;
+                reduce8<SWZ>(v, lo, hi);
+                const float t9 = wave_sum9<SWZ>(0.5f * q2s);
+                const float hi_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x101, 0xF, 0xF, true));
+                const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));
+                outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
+            }
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
-            if (ocomp >= 0) {
+            if (ocomp >= 0) {                                            // row base in SGPRs, per-lane byte offset in one VGPR
                 if (DET) {
                     const float sc = fminf(fmaxf(outv * GS_FIXED_SCALE, -9.0e18f), 9.0e18f);      // saturate, never wrap
-                    atomicAdd(reinterpret_cast<unsigned long long *>(a.g2d_fixed) + (size_t)gid * 10 + ocomp,
-                              (unsigned long long)__float2ll_rn(sc));
+                    char *rowp = reinterpret_cast<char *>(a.g2d_fixed) + (size_t)gid * 80;
+                    atomicAdd(reinterpret_cast<unsigned long long *>(rowp + 2u * ooff), (unsigned long long)__float2ll_rn(sc));
                 } else {
-                    atomicAdd(a.g2d + (size_t)gid * 10 + ocomp, outv);
+                    char *rowp = reinterpret_cast<char *>(a.g2d) + (size_t)gid * 40;
+                    atomicAdd(reinterpret_cast<float *>(rowp + ooff), outv);
                 }
             }
         }
@@ -439,14 +516,17 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8), block(64);
     const bool early = a.t_min > 0.0f;
-    const int v = a.variant == 0 ? 3 : a.variant;      // measured best: row sums through ds_swizzle, registers unconstrained
+    const int v = a.variant == 0 ? 7 : a.variant;      // measured best: reduce-scatter tree on the LDS crossbar, registers unconstrained
 #define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, 0, s, a); \
                                else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, 0, s, a); } while (0)
 #define GS_B(E, M, Z) do { if (a.g2d_fixed) GS_B2(E, M, true, Z); else GS_B2(E, M, false, Z); } while (0)
-    if (v == 1) { if (early) GS_B(true, 1, false); else GS_B(false, 1, false); }
-    else if (v == 2) { if (early) GS_B(true, 8, false); else GS_B(false, 8, false); }
-    else if (v == 3) { if (early) GS_B(true, 1, true); else GS_B(false, 1, true); }
-    else { if (early) GS_B(true, 8, true); else GS_B(false, 8, true); }
+    if (v == 1) { if (early) GS_B(true, 1, 0); else GS_B(false, 1, 0); }
+    else if (v == 2) { if (early) GS_B(true, 8, 0); else GS_B(false, 8, 0); }
+    else if (v == 3) { if (early) GS_B(true, 1, 1); else GS_B(false, 1, 1); }
+    else if (v == 4) { if (early) GS_B(true, 8, 1); else GS_B(false, 8, 1); }
+    else if (v == 5) { if (early) GS_B(true, 1, 2); else GS_B(false, 1, 2); }
+    else if (v == 6) { if (early) GS_B(true, 8, 2); else GS_B(false, 8, 2); }
+    else { if (early) GS_B(true, 1, 3); else GS_B(false, 1, 3); }
 #undef GS_B
 #undef GS_B2
     return hipGetLastError();

@@ -15,16 +15,19 @@ n, W, H, deg = synthetic.CONFIGS[cfg]
 sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1234 + list(synthetic.CONFIGS).index(cfg))
 dC = synthetic.make_dC(W, H, 1)
 K3 = 3 * (deg + 1) ** 2
-out = {}
-for t_min in (0.0, 1e-5):
+rounds = int(os.environ.get("AB_ROUNDS", "6"))
+tmins = [float(x) for x in os.environ.get("AB_TMIN", "0,1e-5").split(",")]
+for t_min in tmins:
     ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=t_min)
     ctx.preprocess(); ctx.bin(); img0, tr0 = ctx.forward_host()
     g = ctx.grads_alloc(); ctx.backward(dC, g); ctx.synchronize()
-    for rnd in range(2):
+    res = {}
+    for rnd in range(rounds):                      # interleaved rounds: clock ramps and noise hit every variant alike
         for v in variants_f:
-            out[f"fwd t_min={t_min:g} v{v} r{rnd}"] = ctx.time_composite(0, v, 5)
+            res.setdefault(("fwd", v), []).append(ctx.time_composite(0, v, 8))
         for v in variants_b:
-            out[f"bwd t_min={t_min:g} v{v} r{rnd}"] = ctx.time_composite(1, v, 3)
+            res.setdefault(("bwd", v), []).append(ctx.time_composite(1, v, 5))
+    for (w, v), ts in res.items():
+        ts = sorted(ts)
+        print(f"{w} t_min={t_min:g} v{v:<5d} min {ts[0]:7.3f}  median {ts[len(ts) // 2]:7.3f}  max {ts[-1]:7.3f} ms")
     ctx.close()
-for k, v in out.items():
-    print(f"{k:36s} {v:8.3f} ms")
