@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -188,6 +189,9 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (!c) return fail(nullptr, GS_ERR_OOM, "gs_create: host allocation failed");
     c->device = device;
     c->cfg = c0;
+    // kernel-variant override for A/B runs and for running the parity tests against a non-default variant
+    if (const char *e = std::getenv("GS_VARIANT_FWD")) c->variant_fwd = std::atoi(e);
+    if (const char *e = std::getenv("GS_VARIANT_BWD")) c->variant_bwd = std::atoi(e);
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipSetDevice"); }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipStreamCreate"); }
     c->own_stream = true;

@@ -14,12 +14,17 @@
 // splatGrads (splat.jl:271-396), which is not a valid adjoint of the 3-D forward:
 // it is the derived adjoint, walking the list in the SAME order with the suffix colour obtained
 // as D - prefix (D = C_final . dC), so T is recomputed exactly as in the forward and never divided
-// back; eight of the nine per-splat sums are reduced by a lane-swap butterfly and written with one
-// 9-lane atomic per (tile, splat).
+// back; the nine per-splat sums are reduced by a reduce-scatter tree on the LDS crossbar and written
+// with one 9-lane atomic per (tile, splat).
 //
-// Both kernels are VALU bound (49 / 114 VALU wave-instructions per list entry, VALU pipe ~98 % busy;
-// profiles/r01c_pmc_valu.json), not HBM bound; see DESIGN.md section 5 for the roofline accounting
-// and the measured instruction costs that shaped the inner loops.
+// While staging a 64-entry batch each lane also bounds the largest alpha its entry can reach on this
+// tile (rect_can_contribute); entries that are no-ops in fp32 are dropped and the batch is compacted in
+// LDS, so the per-pixel loops only see entries that matter (gs_config.alpha_cull; 44 % of the walked
+// entries at C3).  The lists themselves and the batch boundaries of the early-out rule are untouched.
+//
+// Both kernels are VALU bound (50 / 150 VALU wave-instructions per evaluated entry, VALU pipe ~90 % busy;
+// profiles/), not HBM bound; see DESIGN.md section 5 for the roofline accounting and the measured
+// instruction costs that shaped the inner loops.
 #include "gs_common.h"
 
 #define CB 64                       // splats staged per batch
@@ -59,6 +64,24 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles, int gx, int mode
 #define GS_ALPHA_CULL_LOG2 (-27.0f)
 // Lane-independent terms of one splat, computed once per (tile, splat) by the staging lane:
 // q0 = {mu_x, mu_y, log2 sig, x_lo}, q1 = {k i0, k (i1+i2), k i3, x_hi}, q2 = {r, g, b, y_lo}, y_hi   (k = -1/2 log2 e)
+// Can any pixel of the rectangle [rx0,rx1] x [ry0,ry1] (relative to mu, already clipped to the splat's pixel box)
+// reach alpha >= 2^GS_ALPHA_CULL_LOG2?  f(dx,dy) = A dx^2 + B dx dy + C dy^2 (log2 units, concave) is maximised over
+// the rectangle at the centre if it is inside, else on an edge facing the centre, where the 1-D maximiser is clamped
+// to the edge (tests/test_cull_bound.py checks this restated in NumPy against brute force).  Anything not provably
+// concave and finite counts as contributing.
+__device__ __forceinline__ bool rect_can_contribute(float A, float B, float C, float hBrA, float hBrC, bool concave, float l2s,
+                                                    float rx0, float rx1, float ry0, float ry1) {
+    const float cx = __builtin_amdgcn_fmed3f(0.0f, rx0, rx1), cy = __builtin_amdgcn_fmed3f(0.0f, ry0, ry1);
+    const float dy1 = __builtin_amdgcn_fmed3f(-(hBrC * cx), ry0, ry1);
+    const float dx2 = __builtin_amdgcn_fmed3f(-(hBrA * cy), rx0, rx1);
+    const float f1 = fmaf(A * cx, cx, dy1 * fmaf(B, cx, C * dy1));
+    const float f2 = fmaf(C * cy, cy, dx2 * fmaf(B, cy, A * dx2));
+    const float fm = (cx != 0.0f && cy != 0.0f) ? fmaxf(f1, f2) : (cx != 0.0f ? f1 : f2);
+    const bool nopix = rx0 > rx1 || ry0 > ry1;                          // no pixel of the rectangle inside the box
+    return !(nopix || (concave && fm + l2s < GS_ALPHA_CULL_LOG2));
+}
+
+// keep = false: the whole (tile, splat) entry is a no-op (gs_config.alpha_cull).
 __device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2,
                                               const int tx0, const int ty0, bool &keep) {
     const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
@@ -74,24 +97,12 @@ __device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2
     q0 = make_float4(n0.x, n0.y, l2s, xlo);
     q1 = make_float4(NEG_HALF_LOG2E * n1.x, NEG_HALF_LOG2E * (n1.y + n1.z), NEG_HALF_LOG2E * n1.w, xhi);
     q2 = make_float4(n2.x, n2.y, n2.z, ylo);
-    // No-op test (GS_ALPHA_CULL_LOG2): an upper bound of log2(alpha) over the pixels of THIS tile that lie in
-    // the splat's pixel box.  f(dx,dy) = A dx^2 + B dx dy + C dy^2 (log2 units, concave) is maximised over the
-    // rectangle R = tile /\ box - mu: at the centre if 0 is in R, else on an edge facing the centre, where
-    // the 1-D maximiser is clamped to the edge.  Anything not provably concave and finite is kept.
     {
+        const float A = q1.x, B = q1.y, C = q1.z;
+        const bool concave = A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f;
         const float rx0 = (float)max(tx0, xmin) - n0.x, rx1 = (float)min(tx0 + GS_TILE - 1, xmax) - n0.x;
         const float ry0 = (float)max(ty0, ymin) - n0.y, ry1 = (float)min(ty0 + GS_TILE - 1, ymax) - n0.y;
-        const float A = q1.x, B = q1.y, C = q1.z;
-        const float cx = __builtin_amdgcn_fmed3f(0.0f, rx0, rx1), cy = __builtin_amdgcn_fmed3f(0.0f, ry0, ry1);
-        const float dy1 = __builtin_amdgcn_fmed3f(-0.5f * B * cx * fast_rcp(C), ry0, ry1);
-        const float dx2 = __builtin_amdgcn_fmed3f(-0.5f * B * cy * fast_rcp(A), rx0, rx1);
-        const float f1 = fmaf(A * cx, cx, dy1 * fmaf(B, cx, C * dy1));
-        const float f2 = fmaf(C * cy, cy, dx2 * fmaf(B, cy, A * dx2));
-        const float fm = (cx != 0.0f && cy != 0.0f) ? fmaxf(f1, f2) : (cx != 0.0f ? f1 : f2);
-        const bool concave = A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f;
-        const bool nopix = rx0 > rx1 || ry0 > ry1;                     // no pixel of this tile inside the box
-        const bool noop = empty || nopix || (concave && fm + l2s < GS_ALPHA_CULL_LOG2);
-        keep = !noop;
+        keep = !empty && rect_can_contribute(A, B, C, 0.5f * B * fast_rcp(A), 0.5f * B * fast_rcp(C), concave, l2s, rx0, rx1, ry0, ry1);
     }
     return yhi;
 }
@@ -198,12 +209,16 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
 }
 
 // ---------------------------------------------------------------- wave64 reductions
-// Nine per-splat sums are needed.  Reducing them one by one costs 6 DPP adds each; instead
-// eight of them go through a reduce-scatter butterfly built on gfx950's lane-swap
-// instructions: v_permlane32_swap pairs two registers (one add sums BOTH across the wave
-// halves, leaving value A in lanes 0-31 and B in lanes 32-63), v_permlane16_swap does the
-// same across 16-lane rows, and four row_shr DPP adds finish inside the rows.  Result: lane
-// 15 of row r holds the wave total of value ORDER[r] -- 20 VALU ops for 8 values.
+// Nine per-splat sums are needed per (tile, splat).  Eight go through a reduce-scatter tree over the six lane bits:
+// a fold pairs two registers, so one add sums BOTH across one lane bit and leaves value A in the lower lanes and
+// value B in the upper ones -- 4 + 2 + 1 folds bring eight registers down to one whose 8-lane groups each hold one
+// value, three butterfly steps finish inside the groups.  The ninth sum is a plain six-step butterfly.
+//
+// Every exchange runs on the LDS crossbar (ds_swizzle inside 32 lanes, ds_bpermute across the halves), because the
+// VALU is the unit these kernels are bound by: a fold costs it two selects and one add (10.7 cycles per wave64) and
+// a butterfly step one add (2.3), against 14.3 for a v_permlane32/16_swap fold and 4.9 for a DPP add (measured,
+// tools/valu_ubench2.hip, valu_ubench3.hip).  RED = 1 keeps the lane-swap / DPP form for re-measurement; at C3 the
+// LDS form is 6 % faster (tools/abtest.py).
 typedef unsigned int gs_u2 __attribute__((ext_vector_type(2)));
 
 template <int CTRL, int ROW_MASK, int BANK_MASK>
@@ -211,83 +226,11 @@ __device__ __forceinline__ float dpp_add(float v) {
     const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
     return v + __int_as_float(t);
 }
-// Row sums through the LDS crossbar instead: ds_swizzle runs on the LDS pipe (idle here), so the
-// VALU only pays the add (2 cycles) instead of a DPP add (~6.5).  xor butterfly: every lane of the
-// row ends with the row sum.
 template <int PATTERN>
 __device__ __forceinline__ float swz_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN));
 }
-__device__ __forceinline__ float row_sum_swz(float v) {
-    v = swz_add<0x041F>(v);               // xor 1
-    v = swz_add<0x081F>(v);               // xor 2
-    v = swz_add<0x101F>(v);               // xor 4
-    v = swz_add<0x201F>(v);               // xor 8
-    return v;
-}
-__device__ __forceinline__ float row_sum_to_lane15(float v) {
-    v = dpp_add<0x111, 0xF, 0xF>(v);      // row_shr:1
-    v = dpp_add<0x112, 0xF, 0xF>(v);      // row_shr:2
-    v = dpp_add<0x114, 0xF, 0xF>(v);      // row_shr:4
-    v = dpp_add<0x118, 0xF, 0xF>(v);      // row_shr:8   -> lane 15 of each row = row sum
-    return v;
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = row_sum_to_lane15(v);
-    v = dpp_add<0x142, 0xA, 0xF>(v);      // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xC, 0xF>(v);      // row_bcast:31 into rows 2,3 -> lane 63 = total
-    return v;
-}
-// lanes 0-31: a(l)+a(l+32) ; lanes 32-63: b(l-32)+b(l)
-__device__ __forceinline__ float fold32(float a, float b) {
-    const gs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// rows 0,2: a.row(r)+a.row(r+1) ; rows 1,3: b.row(r-1)+b.row(r)
-__device__ __forceinline__ float fold16(float a, float b) {
-    const gs_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// -> lane 15 of rows 0..3 = totals of (v0, v2, v1, v3) in `lo`, of (v4, v6, v5, v7) in `hi`
-template <bool SWZ>
-__device__ __forceinline__ void reduce8(const float (&v)[8], float &lo, float &hi) {
-    const float b0 = fold32(v[0], v[1]), b1 = fold32(v[2], v[3]), b2 = fold32(v[4], v[5]), b3 = fold32(v[6], v[7]);
-    if (SWZ) { lo = row_sum_swz(fold16(b0, b1)); hi = row_sum_swz(fold16(b2, b3)); }
-    else { lo = row_sum_to_lane15(fold16(b0, b1)); hi = row_sum_to_lane15(fold16(b2, b3)); }
-}
-template <bool SWZ>
-__device__ __forceinline__ float wave_sum9(float v) {
-    if (!SWZ) return wave_sum_to_lane63(v);
-    v = row_sum_swz(v);
-    v = dpp_add<0x142, 0xA, 0xF>(v);      // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xC, 0xF>(v);      // row_bcast:31 into rows 2,3 -> lane 63 = total
-    return v;
-}
-
-// rows: lanes 0-7 <- a(l)+a(l+8) ; lanes 8-15 <- b(l-8)+b(l).  Two bank-masked DPP adds (lanes of a disabled bank keep
-// their value), 13 cycles for the pair against 17 for two butterfly steps -- and one register remains instead of two.
-// Inline asm: the hazard recogniser does not see the DPP reads, hence the leading s_nop (VALU write -> DPP read).
-__device__ __forceinline__ float fold8(float a, float b) {
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-                 "v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3"
-                 : "+v"(b) : "v"(a));
-    return b;
-}
-// Reduce-scatter tree over all six lane bits: lane 16r+7 ends with the wave total of (v0, v2, v1, v3)[r],
-// lane 16r+15 with that of (v4, v6, v5, v7)[r]:  4 + 2 lane-swap folds, one DPP fold, three row_shr adds.
-__device__ __forceinline__ float reduce8_tree(const float (&v)[8]) {
-    const float b0 = fold32(v[0], v[1]), b1 = fold32(v[2], v[3]), b2 = fold32(v[4], v[5]), b3 = fold32(v[6], v[7]);
-    float d = fold8(fold16(b0, b1), fold16(b2, b3));
-    d = dpp_add<0x114, 0xF, 0xF>(d);      // row_shr:4
-    d = dpp_add<0x112, 0xF, 0xF>(d);      // row_shr:2
-    d = dpp_add<0x111, 0xF, 0xF>(d);      // row_shr:1 -> lanes 7 and 15 of every row hold their group's total
-    return d;
-}
-// The same tree with every exchange on the LDS crossbar (ds_swizzle inside 32 lanes, ds_bpermute across the halves):
-// the VALU -- the unit these kernels are bound by -- pays two selects and one add per fold (10.7 cycles against 14.3
-// for a lane-swap fold) and one add per butterfly step (2.3 against 4.9 for a DPP add).  Every lane of an 8-lane
-// group ends with its group's total.
+// lower lanes of the bit <- a(l) + a(partner) ; upper lanes <- b(partner) + b(l)
 template <int PATTERN>
 __device__ __forceinline__ float fold_swz(float a, float b, bool upper) {
     const float send = upper ? a : b, keep = upper ? b : a;
@@ -297,6 +240,8 @@ __device__ __forceinline__ float fold32_lds(float a, float b, bool upper, int xa
     const float send = upper ? a : b, keep = upper ? b : a;
     return keep + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(send)));
 }
+// every lane of the 8-lane group (16r .. 16r+7) ends with the wave total of (v0, v2, v1, v3)[r], of group
+// (16r+8 .. 16r+15) with that of (v4, v6, v5, v7)[r]
 __device__ __forceinline__ float reduce8_lds(const float (&v)[8], int lane, int xaddr) {
     const bool u32 = (lane & 32) != 0, u16 = (lane & 16) != 0, u8 = (lane & 8) != 0;
     const float b0 = fold32_lds(v[0], v[1], u32, xaddr), b1 = fold32_lds(v[2], v[3], u32, xaddr);
@@ -310,24 +255,50 @@ __device__ __forceinline__ float wave_sum_lds(float v, int xaddr) {
     v = swz_add<0x041F>(v); v = swz_add<0x081F>(v); v = swz_add<0x101F>(v); v = swz_add<0x201F>(v); v = swz_add<0x401F>(v);
     return v + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v)));
 }
-__device__ __forceinline__ int out_component_tree(int lane) {
-    const int row = lane >> 4, pos = lane & 15;
-    if (pos == 7) return row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;      // (dr, db, dg, dsig)
-    if (pos == 15) return row == 0 ? 4 : row == 1 ? 6 : row == 2 ? 5 : 7;     // (dmx, d00, dmy, d01)
-    if (lane == 62) return 9;                                                  // d11 (merged in by one DPP move)
-    return -1;
+
+// The same tree on the VALU's own cross-lane paths: v_permlane32_swap / v_permlane16_swap folds, one bank-masked
+// DPP fold (lanes of a disabled bank keep their value), row_shr adds.  Totals land in lanes 16r+7 and 16r+15.
+__device__ __forceinline__ float fold32(float a, float b) {
+    const gs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float fold16(float a, float b) {
+    const gs_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// Inline asm: the hazard recogniser does not see the DPP reads, hence the leading s_nop (VALU write -> DPP read).
+__device__ __forceinline__ float fold8(float a, float b) {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3"
+                 : "+v"(b) : "v"(a));
+    return b;
+}
+__device__ __forceinline__ float reduce8_swap(const float (&v)[8]) {
+    const float b0 = fold32(v[0], v[1]), b1 = fold32(v[2], v[3]), b2 = fold32(v[4], v[5]), b3 = fold32(v[6], v[7]);
+    float d = fold8(fold16(b0, b1), fold16(b2, b3));
+    d = dpp_add<0x114, 0xF, 0xF>(d);      // row_shr:4
+    d = dpp_add<0x112, 0xF, 0xF>(d);      // row_shr:2
+    d = dpp_add<0x111, 0xF, 0xF>(d);      // row_shr:1
+    return d;
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0x111, 0xF, 0xF>(v);      // row_shr:1
+    v = dpp_add<0x112, 0xF, 0xF>(v);      // row_shr:2
+    v = dpp_add<0x114, 0xF, 0xF>(v);      // row_shr:4
+    v = dpp_add<0x118, 0xF, 0xF>(v);      // row_shr:8   -> lane 15 of each row = row sum
+    v = dpp_add<0x142, 0xA, 0xF>(v);      // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xC, 0xF>(v);      // row_bcast:31 into rows 2,3 -> lane 63 = total
+    return v;
 }
 
-// g2d row of a gaussian: [dr dg db dsig dmx dmy d00 d01 (d10 = d01, filled by the reader) d11]
-// lane 15 of row r adds lo -> LO_COMP[r] ; lane 14 of row r adds hi -> HI_COMP[r] ; lane 61 adds the 9th
-__device__ __forceinline__ int out_component(int lane) {
+// g2d row of a gaussian: [dr dg db dsig dmx dmy d00 d01 (d10 = d01, filled by the reader) d11].  Nine lanes of the
+// wave issue the one atomic: lane 16r+7 adds (dr, db, dg, dsig)[r], lane 16r+15 adds (dmx, d00, dmy, d01)[r], lane 62 d11.
+__device__ __forceinline__ int out_component_tree(int lane) {
     const int row = lane >> 4, pos = lane & 15;
-    // lo rows hold (v0,v2,v1,v3) = (dr, db, dg, dsig) ; hi rows hold (v4,v6,v5,v7) = (dmx, d00, dmy, d01)
-    const int lo_comp = row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
-    const int hi_comp = row == 0 ? 4 : row == 1 ? 6 : row == 2 ? 5 : 7;
-    if (pos == 15) return lo_comp;
-    if (pos == 14) return hi_comp;
-    if (lane == 61) return 9;
+    if (pos == 7) return row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
+    if (pos == 15) return row == 0 ? 4 : row == 1 ? 6 : row == 2 ? 5 : 7;
+    if (lane == 62) return 9;
     return -1;
 }
 
@@ -337,9 +308,8 @@ __device__ __forceinline__ int out_component(int lane) {
 // 1/(1-alpha) needs no guard; d sig = -(1/sig) * sum(dd) needs no accumulator of its own.
 // DET: the per-(tile, splat) sums are added as 2^-40 fixed-point integers (64-bit integer atomics are
 // order independent, so the gradients are bitwise reproducible run to run); otherwise float atomics.
-template <bool EARLY, int MINW, bool DET, int RED, bool CULL>      // RED: 0 DPP row sums, 1 ds_swizzle row sums, 2 reduce-scatter tree (lane swaps + DPP), 3 the tree on the LDS crossbar
+template <bool EARLY, int MINW, bool DET, int RED, bool CULL>      // RED: 0 reduction tree on the LDS crossbar, 1 on lane swaps + DPP
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
-    constexpr bool SWZ = RED == 1;
     __shared__ float4 sp[CB * 4];
     __shared__ float syhi[CB];
     __shared__ uint32_t sid[CB];
@@ -353,9 +323,8 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     const float nbig = vgpr_const(-GS_BIG);
     const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
     const size_t plane = (size_t)a.W * a.H;
-    const int ocomp = RED >= 2 ? out_component_tree(lane) : out_component(lane);
+    const int ocomp = out_component_tree(lane);
     const int xaddr = (lane ^ 32) << 2;                                  // ds_bpermute address of the partner lane
-    const bool take_hi = (lane & 15) == 14, take_9 = lane == 61;
     const uint32_t ooff = ocomp >= 0 ? 4u * (uint32_t)ocomp : 0u;        // byte offset inside the gaussian's g2d row
 
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);
@@ -458,22 +427,15 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
             v[6] = 0.5f * dX * qx;
             v[7] = 0.5f * dX * q1s;
             float outv;
-            if (RED == 3) {
+            if (RED == 0) {
                 const float d = reduce8_lds(v, lane, xaddr);
                 const float t9 = wave_sum_lds(0.5f * q2s, xaddr);
                 outv = lane == 62 ? t9 : d;
-            } else if (RED == 2) {
-                const float d = reduce8_tree(v);
+            } else {
+                const float d = reduce8_swap(v);
                 const float t9 = wave_sum_to_lane63(0.5f * q2s);
                 // lane 62 <- t9(63): row_shl:1 into row 3 / bank 3 only; lane 63 has no source and keeps d
                 outv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d), __float_as_int(t9), 0x101, 0x8, 0x8, false));
-            } else {
-                float lo, hi;
-                reduce8<SWZ>(v, lo, hi);
-                const float t9 = wave_sum9<SWZ>(0.5f * q2s);
-                const float hi_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hi), 0x101, 0xF, 0xF, true));
-                const float t9_s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t9), 0x102, 0xF, 0xF, true));
-                outv = take_9 ? t9_s : (take_hi ? hi_s : lo);
             }
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
             if (ocomp >= 0) {                                            // row base in SGPRs, per-lane byte offset in one VGPR
@@ -491,6 +453,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     }
     if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 2, (unsigned long long)evaluated); }
 }
+
 
 // Launch configurations were chosen by A/B timing on MI355X at C3 (tools/abtest.py):
 // forward <unroll 2, 8 waves/SIMD> for literal lists, <unroll 2, unconstrained> with early-out;
@@ -516,17 +479,14 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8), block(64);
     const bool early = a.t_min > 0.0f;
-    const int v = a.variant == 0 ? 7 : a.variant;      // measured best: reduce-scatter tree on the LDS crossbar, registers unconstrained
+    const int v = a.variant == 0 ? 1 : a.variant;      // measured best: LDS-crossbar reduction, registers unconstrained
 #define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, 0, s, a); \
                                else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, 0, s, a); } while (0)
 #define GS_B(E, M, Z) do { if (a.g2d_fixed) GS_B2(E, M, true, Z); else GS_B2(E, M, false, Z); } while (0)
     if (v == 1) { if (early) GS_B(true, 1, 0); else GS_B(false, 1, 0); }
     else if (v == 2) { if (early) GS_B(true, 8, 0); else GS_B(false, 8, 0); }
     else if (v == 3) { if (early) GS_B(true, 1, 1); else GS_B(false, 1, 1); }
-    else if (v == 4) { if (early) GS_B(true, 8, 1); else GS_B(false, 8, 1); }
-    else if (v == 5) { if (early) GS_B(true, 1, 2); else GS_B(false, 1, 2); }
-    else if (v == 6) { if (early) GS_B(true, 8, 2); else GS_B(false, 8, 2); }
-    else { if (early) GS_B(true, 1, 3); else GS_B(false, 1, 3); }
+    else { if (early) GS_B(true, 8, 1); else GS_B(false, 8, 1); }
 #undef GS_B
 #undef GS_B2
     return hipGetLastError();
