@@ -69,7 +69,7 @@ struct RcclApi {
 struct gs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool own_stream = false;
+    bool own_stream = false, borrowed_stream = false;
     gs_config cfg{};
     std::string err;
 
@@ -228,11 +228,14 @@ int gs_destroy(gs_ctx *c) {
 
 int gs_set_stream(gs_ctx *c, void *hip_stream) {
     if (!c) return GS_ERR_INVALID;
+    // GS_STREAM_LEGACY (= hipStreamLegacy) names the device's default (null) stream, which a NULL argument cannot
+    hipStream_t want = hip_stream == (void *)1 ? (hipStream_t) nullptr : (hipStream_t)hip_stream;
+    if (hip_stream && !c->own_stream && c->stream == want && c->borrowed_stream) return GS_OK;      // unchanged: no sync
     if (bind_device(c)) return GS_ERR_HIP;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
-    if (hip_stream) { c->stream = (hipStream_t)hip_stream; }
-    else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    if (hip_stream) { c->stream = want; c->borrowed_stream = true; }
+    else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; c->borrowed_stream = false; }
     return GS_OK;
 }
 

@@ -88,10 +88,10 @@ class GaussianRenderer3D:               # renderer.jl:205-219
         self.camera: Camera | None = None
         self.ctx = B.Context(device=device, order=order, t_min=t_min, export_debug=export_debug, profile_stages=profile_stages,
                              deterministic=deterministic, alpha_cull=alpha_cull)
-        # one HIP stream per renderer, shared by the library and by torch's in-place ops on the
-        # renderer's tensors; _begin/_end fence it against the caller's current torch stream
-        self.stream = torch.cuda.Stream(dev)
-        self.ctx.set_stream(self.stream.cuda_stream)
+        # the library enqueues on the caller's CURRENT torch stream (re-read at every API call), like any torch
+        # op: no cross-stream fences, so consecutive calls run back to back on the GPU
+        self._stream_handle = None
+        self._begin()
         self.ctx.set_model_device(self.nGaussians, sh_degree,
                                   [t.data_ptr() for t in (splatData.means, splatData.scales, splatData.quaternions,
                                                           splatData.opacities, splatData.shs)])
@@ -105,20 +105,20 @@ class GaussianRenderer3D:               # renderer.jl:205-219
         next backward overwrites anyway, and materialised here if somebody looks first."""
         if self._grads_lazy_zero:
             import torch
-            self._begin()
-            with torch.cuda.stream(self.stream):
-                self._splatGrads.flat.zero_()
-            self._end()
+            self._splatGrads.flat.zero_()
             self._grads_lazy_zero = False
         return self._splatGrads
 
     def _begin(self):
+        """Bind the ctx to torch's current stream (handle 0 = the legacy default stream = GS_STREAM_LEGACY)."""
         import torch
-        self.stream.wait_stream(torch.cuda.current_stream(self.imageData.device))
+        h = torch.cuda.current_stream(self.imageData.device).cuda_stream or 1
+        if h != self._stream_handle:
+            self.ctx.set_stream(h)
+            self._stream_handle = h
 
-    def _end(self):
-        import torch
-        torch.cuda.current_stream(self.imageData.device).wait_stream(self.stream)
+    def _end(self):                 # kept for callers written against the fenced version: nothing to do
+        pass
 
     # scratch arrays of the reference struct, fetched on demand (export_debug for the fp32 ones)
     @property
@@ -208,13 +208,14 @@ class _LazyTps:
 def compactIdxs(renderer: GaussianRenderer3D, threads=(16, 16), blocks=None):
     """forward.jl:118-161: builds the per-tile splat lists (tile|depth keys, radix sort, ranges)."""
     gx, gy = blocks if blocks is not None else (0, 0)
+    renderer._begin()
     renderer.ctx.bin(int(gx), int(gy))
 
 
 def forward(renderer: GaussianRenderer3D, tps=None, threads=(16, 16), blocks=None):
     """forward.jl:163-198: writes renderer.imageData and renderer.transmittance in place."""
+    renderer._begin()
     renderer.ctx.forward_device(renderer.imageData.data_ptr(), renderer.transmittance.data_ptr())
-    renderer._end()
 
 
 def backward(renderer: GaussianRenderer3D, ΔC):
@@ -227,7 +228,6 @@ def backward(renderer: GaussianRenderer3D, ΔC):
     renderer._begin()
     renderer.ctx.backward(dC.data_ptr(), renderer._grads, overwrite=renderer._grads_lazy_zero)
     renderer._grads_lazy_zero = False
-    renderer._end()
 
 
 def resetGrads(renderer_or_grads):

@@ -98,7 +98,10 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg);
 int gs_destroy(gs_ctx *ctx);
 const char *gs_last_error(const gs_ctx *ctx);   /* ctx may be NULL: last gs_create error */
 
-/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream. */
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream; GS_STREAM_LEGACY
+ * (= hipStreamLegacy) = the device's default (null) stream.  Switching streams synchronises the old one; setting
+ * the stream that is already in use returns at once, so a host may call this before every frame. */
+#define GS_STREAM_LEGACY ((void *)1)
 int gs_set_stream(gs_ctx *ctx, void *hip_stream);
 int gs_synchronize(gs_ctx *ctx);
 
