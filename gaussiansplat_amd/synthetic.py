@@ -56,6 +56,18 @@ def make_scene(n: int, W: int, H: int, sh_degree: int, seed: int = 1234):
     return dict(means=means, scales=scales, quats=quats, opacities=opacities, shs=shs)
 
 
+def make_scene_2d(n: int, W: int, H: int, seed: int = 1234, scale_lo: float = 0.0, scale_hi: float = 2.5):
+    """2-D image-fitting model in the shape of initData(Val(SPLAT2D)) (splat.jl:74-87): means U[0,1)^2 (fractions of
+    the image), rotations pi/2*(U-0.5), opacities and colors U[0,1); the reference draws the log-scales U[0,1) too
+    (1-2.7 px standard deviations) -- a wider range is used by default so footprints span several tiles.
+    Returns dict(means[n,2], scales[n,2], rots[n], opacities[n], colors[n,3]) float32."""
+    rng = np.random.default_rng(seed)
+    return dict(means=rng.random((n, 2), dtype=np.float32),
+                scales=rng.uniform(scale_lo, scale_hi, (n, 2)).astype(np.float32),
+                rots=(np.float32(np.pi / 2) * (rng.random(n, dtype=np.float32) - np.float32(0.5))).astype(np.float32),
+                opacities=rng.random(n, dtype=np.float32), colors=rng.random((n, 3), dtype=np.float32))
+
+
 def make_dC(W: int, H: int, seed: int = 1234) -> np.ndarray:
     """Upstream image gradient, [3, H, W] float32 ~ N(0,1)."""
     return np.random.default_rng(seed + 7919).standard_normal((3, H, W)).astype(np.float32)

@@ -62,6 +62,37 @@ float gso_expf(float x) {
     return (y * s1) * s2;
 }
 
+/* The spec's sin/cos (2-D renderer, cov2d.jl:6-8 CUDA.cos/CUDA.sin): k = rint(x*2/pi), three-term Cody-Waite
+ * reduction by pi/2, Cephes sinf/cosf polynomials on [-pi/4, pi/4], quadrant fix-up; fp32 mul/add only. */
+void gso_sincosf(float x, float *sn, float *cs) {
+    if (!isfinite(x)) { *sn = NAN; *cs = NAN; return; }
+    float kf = rintf(x * 0.636619772f);
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.837512969970703125e-4f;
+    r = r - kf * 7.54978995489188216e-8f;
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * z + 8.3321608736e-3f;
+    ps = ps * z + -1.6666654611e-1f;
+    ps = ps * z;
+    ps = ps * r;
+    ps = ps + r;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * z + -1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    pc = pc * z;
+    pc = pc * z;
+    pc = pc - 0.5f * z;
+    pc = pc + 1.0f;
+    long long k = (long long)kf;
+    switch ((int)(k & 3)) {
+        case 0: *sn = ps;  *cs = pc;  break;
+        case 1: *sn = pc;  *cs = -ps; break;
+        case 2: *sn = -ps; *cs = -pc; break;
+        default: *sn = -pc; *cs = ps; break;
+    }
+}
+
 /* ------------------------------------------------------------------ camera */
 
 /* camera.jl:88-100 computeTransform, camera.jl:102-111 computeProjection.
@@ -299,6 +330,64 @@ void gso_preprocess(int64_t n, int sh_degree,
     }
 }
 
+/* ------------------------------------------------------------------ 2-D renderer preprocess */
+
+/* preprocess(::GaussianRenderer2D), forward.jl:9-33: computeCov2d_kernel (cov2d.jl:3-28), computeInvCov2d
+ * (cov2d.jl:30-45), computeBB (boundingbox.jl:4-36).  SplatData2D (splat.jl:20-26): means 2xN in [0,1]^2,
+ * scales 2xN (log), rotations 1xN (theta), opacities 1xN, colors 3xN.  The pixel position of a gaussian is
+ * (w*mx, h*my) (splat.jl:337-339); the reference passes the [0,1] means to computeBB (forward.jl:25-31), which
+ * would put every box at the image origin -- the spec uses the pixel position (documented deviation).
+ * alpha = opacity*exp(-dist/2) with the raw opacity (splat.jl:341,345), colour = colors (no SH). */
+void gso_preprocess2d(int64_t n, const float *means, const float *scales, const float *rots,
+                      const float *opacities, const float *colors, int W, int H,
+                      float *mu_o, float *cov2d_o, float *invcov_o, float *bbs_o, float *rgb_o, float *sig_o) {
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < n; ++g) {
+        float sn, cs;
+        gso_sincosf(rots[g], &sn, &cs);                               /* cov2d.jl:6-8 */
+        float R[2][2] = { { cs, -sn }, { sn, cs } };                    /* :9-12 */
+        float S[2][2] = { { gso_expf(scales[2 * g]), 0.0f }, { 0.0f, gso_expf(scales[2 * g + 1]) } };   /* :14-17 */
+        float Wm[2][2], Jm[2][2];
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                float s = R[i][0] * S[0][j];
+                s = s + R[i][1] * S[1][j];
+                Wm[i][j] = s;                                          /* :18 W = R*S */
+            }
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                float s = Wm[i][0] * Wm[j][0];
+                s = s + Wm[i][1] * Wm[j][1];
+                Jm[i][j] = s;                                          /* :19 J = W*W' */
+            }
+        const float a0 = (float)((double)Jm[0][0] + 0.3);              /* :25 (+0.3 is Float64, diagonal only) */
+        const float a1 = Jm[1][0], a2 = Jm[0][1];
+        const float a3 = (float)((double)Jm[1][1] + 0.3);              /* :26 */
+        /* computeInvCov2d, cov2d.jl:30-45 */
+        const float det = a0 * a3 - a2 * a1;
+        const float idet = 1.0f / det;
+        const float inv0 = a3 * idet, inv1 = -(a1 * idet), inv2 = -(a2 * idet), inv3 = a0 * idet;
+        /* pixel position, splat.jl:337-339 */
+        const float mux = (float)W * means[2 * g], muy = (float)H * means[2 * g + 1];
+        /* computeBB, boundingbox.jl:19-27 */
+        const float halfad = (a0 + a3) / 2.0f;
+        const double disc = (double)(halfad * halfad - det);
+        const double sq = sqrt(jl_max(0.1, disc));
+        const double e1 = (double)halfad - sq, e2 = (double)halfad + sq;
+        const double r = ceil(3.0 * sqrt(jl_max(e1, e2)));
+        const float bxmin = (float)jl_max(1.0, floor(-r + (double)mux));
+        const float bxmax = (float)jl_min((double)W, ceil(r + (double)mux));
+        const float bymin = (float)jl_max(1.0, floor(-r + (double)muy));
+        const float bymax = (float)jl_min((double)H, ceil(r + (double)muy));
+        if (mu_o) { mu_o[2 * g] = mux; mu_o[2 * g + 1] = muy; }
+        if (cov2d_o) { cov2d_o[4 * g] = a0; cov2d_o[4 * g + 1] = a1; cov2d_o[4 * g + 2] = a2; cov2d_o[4 * g + 3] = a3; }
+        if (invcov_o) { invcov_o[4 * g] = inv0; invcov_o[4 * g + 1] = inv1; invcov_o[4 * g + 2] = inv2; invcov_o[4 * g + 3] = inv3; }
+        if (bbs_o) { bbs_o[4 * g] = bxmin; bbs_o[4 * g + 1] = bymin; bbs_o[4 * g + 2] = bxmax; bbs_o[4 * g + 3] = bymax; }
+        if (rgb_o) { rgb_o[3 * g] = colors[3 * g]; rgb_o[3 * g + 1] = colors[3 * g + 1]; rgb_o[3 * g + 2] = colors[3 * g + 2]; }
+        if (sig_o) sig_o[g] = opacities[g];
+    }
+}
+
 /* ------------------------------------------------------------------ depth order */
 
 uint32_t gso_depth_key(float clipz, int order) {
@@ -451,8 +540,10 @@ void gso_composite_forward(const gso_camera *cam, int tile, int gx, int gy,
                 for (uint32_t k = s0; k < s1; ++k) {                     /* :224 */
                     if (t_min > 0.0f && ((k - s0) % GSO_EARLY_BATCH) == 0 && Tr < t_min) break;   /* extension: early-out */
                     uint32_t b = ids[k];
-                    float cz = tps[4 * (int64_t)b + 2];
-                    if (cz < cam->near_ || cz > cam->far_) continue;     /* :227 */
+                    if (tps) {                                            /* 2-D renderer: no clip z, no skip */
+                        float cz = tps[4 * (int64_t)b + 2];
+                        if (cz < cam->near_ || cz > cam->far_) continue; /* :227 */
+                    }
                     const float *bb = bbs + 4 * (int64_t)b;
                     int hit = (bb[0] <= fi) && (fi <= bb[2]) && (bb[1] <= fj) && (fj <= bb[3]);  /* :240 */
                     if (!hit) continue;
@@ -654,25 +745,15 @@ static void bwd64(int64_t g, int deg, const float *means, const float *scales, c
     dopac[g] += gsig * f.sig * (1.0 - f.sig);
 }
 
-void gso_backward(int64_t n, int sh_degree,
-                  const float *means, const float *scales, const float *quats,
-                  const float *opacities, const float *shs, const gso_camera *cam,
-                  int tile, int gx, int gy, const uint32_t *ranges, const uint32_t *ids,
-                  const float *bbs_in, float t_min, const float *dC,
-                  double *dmeans, double *dscales, double *dquats, double *dopac,
-                  double *dshs, double *g2d_out) {
+/* fp64 adjoint of the composite (shared by the 3-D and the 2-D renderer): walks every pixel's list with the fp32
+ * forward's discrete decisions (boxes, lists, near/far when tps != NULL, early-out rule) and accumulates
+ * g2d[10*g ..] = d{rgb3, sig, mu2, inv4}. */
+static void composite_adjoint64(int64_t n, const g64 *F, const gso_camera *cam, int tile, int gx, int gy,
+                                const uint32_t *ranges, const uint32_t *ids, const float *bbs, const float *tps,
+                                float t_min, const float *dC, double *g2d) {
+    (void)n;
     const int W = cam->W, H = cam->H;
     const int64_t plane = (int64_t)W * H, nt = (int64_t)gx * gy;
-    /* discrete decisions come from the fp32 forward */
-    float *tps = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
-    float *bbs = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
-    gso_preprocess(n, sh_degree, means, scales, quats, opacities, shs, cam, NULL, tps, NULL, NULL, NULL, NULL, bbs, NULL, NULL);
-    if (bbs_in) memcpy(bbs, bbs_in, sizeof(float) * 4 * (size_t)n);
-    g64 *F = (g64 *)malloc(sizeof(g64) * (size_t)(n > 0 ? n : 1));
-#pragma omp parallel for schedule(static)
-    for (int64_t g = 0; g < n; ++g) fwd64(g, sh_degree, means, scales, quats, opacities, shs, cam, &F[g]);
-    double *g2d = (double *)calloc((size_t)(n > 0 ? n : 1) * 10, sizeof(double));
-
 #pragma omp parallel
     {
         size_t capk = 1024;
@@ -699,8 +780,10 @@ void gso_backward(int64_t n, int sh_degree,
                     for (uint32_t k = s0; k < s1; ++k) {
                         if (t_min > 0.0f && ((k - s0) % GSO_EARLY_BATCH) == 0 && Tr < (double)t_min) break;
                         uint32_t b = ids[k];
-                        float cz = tps[4 * (int64_t)b + 2];
-                        if (cz < cam->near_ || cz > cam->far_) continue;
+                        if (tps) {
+                            float cz = tps[4 * (int64_t)b + 2];
+                            if (cz < cam->near_ || cz > cam->far_) continue;
+                        }
                         const float *bb = bbs + 4 * (int64_t)b;
                         if (!((bb[0] <= fi) && (fi <= bb[2]) && (bb[1] <= fj) && (fj <= bb[3]))) continue;
                         const g64 *f = &F[b];
@@ -737,9 +820,98 @@ void gso_backward(int64_t n, int sh_degree,
         }
         free(al); free(who);
     }
+}
+
+void gso_backward(int64_t n, int sh_degree,
+                  const float *means, const float *scales, const float *quats,
+                  const float *opacities, const float *shs, const gso_camera *cam,
+                  int tile, int gx, int gy, const uint32_t *ranges, const uint32_t *ids,
+                  const float *bbs_in, float t_min, const float *dC,
+                  double *dmeans, double *dscales, double *dquats, double *dopac,
+                  double *dshs, double *g2d_out) {
+    /* discrete decisions come from the fp32 forward */
+    float *tps = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+    float *bbs = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+    gso_preprocess(n, sh_degree, means, scales, quats, opacities, shs, cam, NULL, tps, NULL, NULL, NULL, NULL, bbs, NULL, NULL);
+    if (bbs_in) memcpy(bbs, bbs_in, sizeof(float) * 4 * (size_t)n);
+    g64 *F = (g64 *)calloc((size_t)(n > 0 ? n : 1), sizeof(g64));
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < n; ++g) fwd64(g, sh_degree, means, scales, quats, opacities, shs, cam, &F[g]);
+    double *g2d = (double *)calloc((size_t)(n > 0 ? n : 1) * 10, sizeof(double));
+    composite_adjoint64(n, F, cam, tile, gx, gy, ranges, ids, bbs, tps, t_min, dC, g2d);
 #pragma omp parallel for schedule(static)
     for (int64_t g = 0; g < n; ++g)
         bwd64(g, sh_degree, means, scales, quats, opacities, shs, cam, g2d + 10 * g, dmeans, dscales, dquats, dopac, dshs);
     if (g2d_out) memcpy(g2d_out, g2d, sizeof(double) * 10 * (size_t)n);
     free(g2d); free(F); free(tps); free(bbs);
 }
+
+/* ------------------------------------------------------------------ 2-D renderer backward (fp64 adjoint) */
+
+/* Derived adjoint of gso_preprocess2d + composite (the reference's splatGrads, splat.jl:271-396, mixes several
+ * forwards and is not reproduced; its CONTRACT is: gradients accumulate into arrays shaped like the parameters).
+ * Sigma = R S^2 R' + 0.3 I, M = Sigma^-1, mu = (W mx, H my), alpha = opacity * exp(-dist/2), colour = colors. */
+void gso_backward2d(int64_t n, const float *means, const float *scales, const float *rots,
+                    const float *opacities, const float *colors, int W, int H,
+                    int tile, int gx, int gy, const uint32_t *ranges, const uint32_t *ids,
+                    float t_min, const float *dC,
+                    double *dmeans, double *dscales, double *drots, double *dopac, double *dcolors, double *g2d_out) {
+    gso_camera cam;
+    memset(&cam, 0, sizeof(cam));
+    cam.W = W; cam.H = H;
+    float *bbs = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+    gso_preprocess2d(n, means, scales, rots, opacities, colors, W, H, NULL, NULL, NULL, bbs, NULL, NULL);
+    g64 *F = (g64 *)calloc((size_t)(n > 0 ? n : 1), sizeof(g64));
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < n; ++g) {
+        g64 *o = &F[g];
+        double th = rots[g], c = cos(th), s = sin(th);
+        double e1 = exp((double)scales[2 * g]), e2 = exp((double)scales[2 * g + 1]);
+        double Wm[2][2] = { { c * e1, -s * e2 }, { s * e1, c * e2 } };
+        double cov[2][2];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) cov[i][j] = Wm[i][0] * Wm[j][0] + Wm[i][1] * Wm[j][1] + (i == j ? 0.3 : 0.0);
+        double det = cov[0][0] * cov[1][1] - cov[0][1] * cov[1][0];
+        o->M[0] = cov[1][1] / det; o->M[1] = -cov[1][0] / det; o->M[2] = -cov[0][1] / det; o->M[3] = cov[0][0] / det;
+        o->mu[0] = (double)W * means[2 * g]; o->mu[1] = (double)H * means[2 * g + 1];
+        o->sig = opacities[g];
+        for (int k = 0; k < 3; ++k) o->rgb[k] = colors[3 * g + k];
+    }
+    double *g2d = (double *)calloc((size_t)(n > 0 ? n : 1) * 10, sizeof(double));
+    composite_adjoint64(n, F, &cam, tile, gx, gy, ranges, ids, bbs, NULL, t_min, dC, g2d);
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < n; ++g) {
+        const double *g2 = g2d + 10 * g, *gM = g2 + 6;
+        const g64 *f = &F[g];
+        for (int k = 0; k < 3; ++k) dcolors[3 * g + k] += g2[k];
+        dopac[g] += g2[3];
+        dmeans[2 * g] += (double)W * g2[4];
+        dmeans[2 * g + 1] += (double)H * g2[5];
+        /* M = cov^-1 => dcov = -M' gM M' */
+        double M[2][2] = { { f->M[0], f->M[2] }, { f->M[1], f->M[3] } };
+        double G[2][2] = { { gM[0], gM[2] }, { gM[1], gM[3] } };
+        double t1[2][2], dcov[2][2];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) t1[i][j] = M[0][i] * G[0][j] + M[1][i] * G[1][j];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) dcov[i][j] = -(t1[i][0] * M[j][0] + t1[i][1] * M[j][1]);
+        /* cov = Wm Wm' + 0.3 I, Wm = R(theta) diag(e) */
+        double th = rots[g], c = cos(th), s = sin(th);
+        double e[2] = { exp((double)scales[2 * g]), exp((double)scales[2 * g + 1]) };
+        double R[2][2] = { { c, -s }, { s, c } }, dRdth[2][2] = { { -s, -c }, { c, -s } };
+        double Wm[2][2], dWm[2][2];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) Wm[i][j] = R[i][j] * e[j];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
+            double acc = 0;
+            for (int k = 0; k < 2; ++k) acc += (dcov[i][k] + dcov[k][i]) * Wm[k][j];
+            dWm[i][j] = acc;
+        }
+        double dth = 0;
+        for (int j = 0; j < 2; ++j) {
+            double de = 0;
+            for (int i = 0; i < 2; ++i) { de += R[i][j] * dWm[i][j]; dth += dRdth[i][j] * e[j] * dWm[i][j]; }
+            dscales[2 * g + j] += de * e[j];
+        }
+        drots[g] += dth;
+    }
+    if (g2d_out) memcpy(g2d_out, g2d, sizeof(double) * 10 * (size_t)n);
+    free(g2d); free(F); free(bbs);
+}
+

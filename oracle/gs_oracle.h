@@ -106,6 +106,26 @@ void gso_backward(int64_t n, int sh_degree,
                   double *dshs,
                   double *g2d /* optional n*10: drgb3,dsig,dmu2,dinv4 */);
 
+/* ---- 2-D image-fitting renderer (GAUSSIAN_2D) ---------------------------------------- */
+
+/* The spec's sin/cos for cov2d.jl:6-8 (Cody-Waite by pi/2 + Cephes polynomials, fp32 mul/add only). */
+void gso_sincosf(float x, float *sn, float *cs);
+
+/* preprocess(::GaussianRenderer2D), forward.jl:9-33 = cov2d.jl:3-45 + boundingbox.jl:4-36 on the pixel position
+ * (w*mx, h*my) of splat.jl:337-339.  means 2xN in [0,1]^2, scales 2xN (log), rots 1xN, opacities 1xN (raw),
+ * colors 3xN.  Outputs as gso_preprocess (rgb = colors, sig = opacities). */
+void gso_preprocess2d(int64_t n, const float *means, const float *scales, const float *rots,
+                      const float *opacities, const float *colors, int W, int H,
+                      float *mu, float *cov2d, float *invcov, float *bbs, float *rgb, float *sig);
+
+/* fp64 adjoint of gso_preprocess2d + composite; gradients ACCUMULATE (SplatGrads2D, splat.jl:28-34). */
+void gso_backward2d(int64_t n, const float *means, const float *scales, const float *rots,
+                    const float *opacities, const float *colors, int W, int H,
+                    int tile, int gx, int gy, const uint32_t *ranges, const uint32_t *ids,
+                    float t_min, const float *dC,
+                    double *dmeans, double *dscales, double *drots, double *dopac, double *dcolors,
+                    double *g2d /* optional n*10 */);
+
 int gso_num_threads(void);
 
 #ifdef __cplusplus

@@ -48,6 +48,38 @@ def expf_spec(x):
     return out.astype(f32)
 
 
+def sincosf_spec(x):
+    """The spec's sin/cos (stands in for CUDA.sin / CUDA.cos, cov2d.jl:6-8): k = rint(x*2/pi), three-term
+    Cody-Waite reduction by pi/2, Cephes polynomials on [-pi/4, pi/4], quadrant fix-up; fp32 mul/add only."""
+    x = np.asarray(x, dtype=f32)
+    with np.errstate(all="ignore"):
+        fin = np.isfinite(x)
+        xs = np.where(fin, x, f32(0))
+        kf = np.rint(xs * f32(0.636619772))
+        r = xs - kf * f32(1.5703125)
+        r = r - kf * f32(4.837512969970703125e-4)
+        r = r - kf * f32(7.54978995489188216e-8)
+        z = r * r
+        ps = np.full_like(r, f32(-1.9515295891e-4))
+        ps = ps * z + f32(8.3321608736e-3)
+        ps = ps * z + f32(-1.6666654611e-1)
+        ps = ps * z
+        ps = ps * r
+        ps = ps + r
+        pc = np.full_like(r, f32(2.443315711809948e-5))
+        pc = pc * z + f32(-1.388731625493765e-3)
+        pc = pc * z + f32(4.166664568298827e-2)
+        pc = pc * z
+        pc = pc * z
+        pc = pc - f32(0.5) * z
+        pc = pc + f32(1.0)
+        q = kf.astype(np.int64) & 3
+        sn = np.select([q == 0, q == 1, q == 2], [ps, pc, -ps], -pc)
+        cs = np.select([q == 0, q == 1, q == 2], [pc, -ps, -pc], ps)
+        sn = np.where(fin, sn, f32(np.nan)); cs = np.where(fin, cs, f32(np.nan))
+    return sn.astype(f32), cs.astype(f32)
+
+
 def jl_max(a, b):
     """Julia max: NaN if either argument is NaN."""
     with np.errstate(all="ignore"):
@@ -224,6 +256,45 @@ def preprocess(means, scales, quats, opacities, shs, sh_degree, T, P, fx, fy, ey
         return dict(ts=np.stack(ts, 1), tps=np.stack(tps, 1), mu=np.stack([mux, muy], 1), cov3d=cov3d,
                     cov2d=np.stack([a0, a1, a2, a3], 1), invcov=inv.astype(f32),
                     bbs=np.stack([bxmin, bymin, bxmax, bymax], 1), rgb=rgb, sig=sig.astype(f32))
+
+
+# ----------------------------------------------------------------------------- 2-D renderer
+
+def preprocess2d(means, scales, rots, opacities, colors, W, H):
+    """preprocess(::GaussianRenderer2D), forward.jl:9-33: computeCov2d_kernel (cov2d.jl:3-28), computeInvCov2d
+    (cov2d.jl:30-45), computeBB (boundingbox.jl:4-36) on the pixel position (w*mx, h*my) of splat.jl:337-339.
+    alpha uses the raw opacity (splat.jl:341), the colour is `colors` itself."""
+    with np.errstate(all="ignore"):
+        means = np.ascontiguousarray(means, f32); scales = np.ascontiguousarray(scales, f32)
+        theta = np.asarray(rots, f32).reshape(-1)
+        sn, cs = sincosf_spec(theta)                                          # cov2d.jl:6-8
+        zero = np.zeros_like(sn)
+        R = {(0, 0): cs, (0, 1): -sn, (1, 0): sn, (1, 1): cs}                 # :9-12
+        S = {(0, 0): expf_spec(scales[:, 0]), (0, 1): zero, (1, 0): zero, (1, 1): expf_spec(scales[:, 1])}   # :14-17
+        Wm = {(i, j): R[(i, 0)] * S[(0, j)] + R[(i, 1)] * S[(1, j)] for i in range(2) for j in range(2)}     # :18
+        Jm = {(i, j): Wm[(i, 0)] * Wm[(j, 0)] + Wm[(i, 1)] * Wm[(j, 1)] for i in range(2) for j in range(2)}  # :19
+        a0 = (Jm[(0, 0)].astype(f64) + 0.3).astype(f32)                       # :25
+        a1, a2 = Jm[(1, 0)], Jm[(0, 1)]
+        a3 = (Jm[(1, 1)].astype(f64) + 0.3).astype(f32)                       # :26
+        det = a0 * a3 - a2 * a1
+        idet = f32(1) / det
+        inv = np.stack([a3 * idet, -(a1 * idet), -(a2 * idet), a0 * idet], axis=1)       # cov2d.jl:38
+        mux = f32(W) * means[:, 0]; muy = f32(H) * means[:, 1]                # splat.jl:337-339
+        halfad = (a0 + a3) / f32(2)                                           # boundingbox.jl:20
+        disc = (halfad * halfad - det).astype(f64)
+        sq = np.sqrt(jl_max(f64(0.1), disc))
+        e1 = halfad.astype(f64) - sq
+        e2 = halfad.astype(f64) + sq
+        r = np.ceil(3.0 * np.sqrt(jl_max(e1, e2)))
+        bxmin = jl_max(1.0, np.floor(-r + mux.astype(f64))).astype(f32)
+        bxmax = jl_min(f64(W), np.ceil(r + mux.astype(f64))).astype(f32)
+        bymin = jl_max(1.0, np.floor(-r + muy.astype(f64))).astype(f32)
+        bymax = jl_min(f64(H), np.ceil(r + muy.astype(f64))).astype(f32)
+        n = means.shape[0]
+        tps = np.zeros((n, 4), f32)                                           # no clip z: never skipped (near <= 0 <= far)
+        return dict(mu=np.stack([mux, muy], 1), cov2d=np.stack([a0, a1, a2, a3], 1), invcov=inv.astype(f32),
+                    bbs=np.stack([bxmin, bymin, bxmax, bymax], 1), rgb=np.ascontiguousarray(colors, f32).reshape(n, 3),
+                    sig=np.asarray(opacities, f32).reshape(-1), tps=tps)
 
 
 # ----------------------------------------------------------------------------- order / binning

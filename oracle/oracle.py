@@ -54,6 +54,10 @@ def lib(omp: bool = False):
         L.gso_composite_forward.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, u32p, u32p] + [fp] * 6 + [C.c_float, fp, fp]
         L.gso_backward.argtypes = ([C.c_int64, C.c_int] + [fp] * 5 + [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, u32p, u32p, fp,
                                    C.c_float, fp] + [dp] * 6)
+        L.gso_sincosf.argtypes = [C.c_float, fp, fp]
+        L.gso_preprocess2d.argtypes = [C.c_int64] + [fp] * 5 + [C.c_int, C.c_int] + [fp] * 6
+        L.gso_backward2d.argtypes = ([C.c_int64] + [fp] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u32p, u32p, C.c_float, fp]
+                                     + [dp] * 6)
         L.gso_num_threads.restype = C.c_int
         _libs[key] = L
     return _libs[key]
@@ -176,4 +180,64 @@ def backward(means, scales, quats, opacities, shs, sh_degree, cam: Camera, range
     lib(omp).gso_backward(n, sh_degree, _fp(means), _fp(scales), _fp(quats), _fp(opac), _fp(shs), C.byref(cam), tile, gx, gy,
                           _p(ranges, C.c_uint32), _p(ids, C.c_uint32), None, t_min, _fp(dC),
                           *(g[k].ctypes.data_as(dp) for k in ("means", "scales", "quats", "opacities", "shs", "g2d")))
+    return g
+
+
+# ---------------------------------------------------------------- 2-D renderer (GAUSSIAN_2D)
+
+def sincosf(x: float):
+    sn, cs = C.c_float(), C.c_float()
+    lib().gso_sincosf(C.c_float(x), C.cast(C.byref(sn), C.POINTER(C.c_float)), C.cast(C.byref(cs), C.POINTER(C.c_float)))
+    return sn.value, cs.value
+
+
+def image_camera(W: int, H: int) -> Camera:
+    """Camera carrying only the image size (the 2-D renderer has no projection)."""
+    cam = Camera()
+    cam.W, cam.H = int(W), int(H)
+    cam.near_, cam.far_ = -1.0, 1.0
+    return cam
+
+
+def preprocess2d(means, scales, rots, opacities, colors, W, H, omp=False) -> dict:
+    means, scales, colors = (_c32(a) for a in (means, scales, colors))
+    rots = _c32(rots).reshape(-1); opac = _c32(opacities).reshape(-1)
+    n = means.shape[0]
+    o = dict(mu=np.empty((n, 2), np.float32), cov2d=np.empty((n, 4), np.float32), invcov=np.empty((n, 4), np.float32),
+             bbs=np.empty((n, 4), np.float32), rgb=np.empty((n, 3), np.float32), sig=np.empty((n,), np.float32))
+    lib(omp).gso_preprocess2d(n, _fp(means), _fp(scales), _fp(rots), _fp(opac), _fp(colors), int(W), int(H),
+                              *(_fp(o[k]) for k in ("mu", "cov2d", "invcov", "bbs", "rgb", "sig")))
+    o["tps"] = np.zeros((n, 4), np.float32)
+    return o
+
+
+def render2d(means, scales, rots, opacities, colors, W, H, tile=16, t_min=0.0, omp=False):
+    """preprocess -> compactIdxs -> forward for the 2-D renderer; lists in gaussian-index order (no depth)."""
+    gx, gy = (W + tile - 1) // tile, (H + tile - 1) // tile
+    pre = preprocess2d(means, scales, rots, opacities, colors, W, H, omp=omp)
+    ranges, ids, keys = bin_lists(pre["bbs"], pre["tps"], ORDER_INDEX, tile, gx, gy)
+    cam = image_camera(W, H)
+    image = np.zeros((3, H, W), np.float32)
+    trans = np.ones((H, W), np.float32)
+    idsc = np.ascontiguousarray(ids, np.uint32) if len(ids) else np.zeros(1, np.uint32)
+    lib(omp).gso_composite_forward(C.byref(cam), tile, gx, gy, _p(np.ascontiguousarray(ranges, np.uint32), C.c_uint32), _p(idsc, C.c_uint32),
+                                   _fp(pre["mu"]), _fp(pre["invcov"]), _fp(pre["bbs"]), _fp(pre["sig"]), _fp(pre["rgb"]),
+                                   None, t_min, _fp(image), _fp(trans))
+    return dict(pre=pre, ranges=ranges, ids=ids, keys=keys, image=image, trans=trans)
+
+
+def backward2d(means, scales, rots, opacities, colors, W, H, ranges, ids, dC, tile=16, t_min=0.0, omp=False):
+    means, scales, colors = (_c32(a) for a in (means, scales, colors))
+    rots = _c32(rots).reshape(-1); opac = _c32(opacities).reshape(-1)
+    n = means.shape[0]
+    gx, gy = (W + tile - 1) // tile, (H + tile - 1) // tile
+    dC = _c32(dC)
+    ranges = np.ascontiguousarray(ranges, np.uint32)
+    ids = np.ascontiguousarray(ids, np.uint32) if len(ids) else np.zeros(1, np.uint32)
+    g = dict(means=np.zeros((n, 2)), scales=np.zeros((n, 2)), rots=np.zeros(n), opacities=np.zeros(n), colors=np.zeros((n, 3)),
+             g2d=np.zeros((n, 10)))
+    dp = C.POINTER(C.c_double)
+    lib(omp).gso_backward2d(n, _fp(means), _fp(scales), _fp(rots), _fp(opac), _fp(colors), int(W), int(H), tile, gx, gy,
+                            _p(ranges, C.c_uint32), _p(ids, C.c_uint32), C.c_float(t_min), _fp(dC),
+                            *(g[k].ctypes.data_as(dp) for k in ("means", "scales", "rots", "opacities", "colors", "g2d")))
     return g

@@ -62,6 +62,26 @@ def per_gaussian(means, scales, quats, opac, shs, deg, T, P, fx, fy, eye, lookAt
 def render(params, deg, T, P, fx, fy, eye, lookAt, near, far, W, H, ranges, ids, bbs32, clipz32, t_min=0.0):
     means, scales, quats, opac, shs = params
     mux, muy, M, sig, rgb = per_gaussian(means, scales, quats, opac, shs, deg, T, P, fx, fy, eye, lookAt, W, H)
+    return composite(mux, muy, M, sig, rgb, near, far, W, H, ranges, ids, bbs32, clipz32, t_min)
+
+
+def per_gaussian2d(means, scales, rots, opac, colors, W, H):
+    """2-D renderer (cov2d.jl:3-45, splat.jl:337-345): Sigma = R S^2 R' + 0.3 I, mu = (W mx, H my), raw opacity."""
+    c, s = torch.cos(rots), torch.sin(rots)
+    e = torch.exp(scales)
+    Wm = torch.stack([torch.stack([c * e[:, 0], -s * e[:, 1]], 1), torch.stack([s * e[:, 0], c * e[:, 1]], 1)], 1)   # [n, 2, 2]
+    cov = Wm @ Wm.transpose(1, 2) + 0.3 * torch.eye(2, dtype=torch.float64)
+    M = torch.linalg.inv(cov)
+    return W * means[:, 0], H * means[:, 1], M, opac, colors
+
+
+def render2d(params, W, H, ranges, ids, bbs32, t_min=0.0):
+    means, scales, rots, opac, colors = params
+    mux, muy, M, sig, rgb = per_gaussian2d(means, scales, rots, opac, colors, W, H)
+    return composite(mux, muy, M, sig, rgb, -1.0, 1.0, W, H, ranges, ids, bbs32, np.zeros(len(bbs32)), t_min)
+
+
+def composite(mux, muy, M, sig, rgb, near, far, W, H, ranges, ids, bbs32, clipz32, t_min=0.0):
     gx = (W + 15) // 16
     img = torch.zeros(3, H, W, dtype=torch.float64)
     trans = torch.ones(H, W, dtype=torch.float64)
