@@ -24,7 +24,7 @@ STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges
 
 # every symbol include/gsplat.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
-           "gs_synchronize", "gs_set_model", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
+           "gs_synchronize", "gs_set_model", "gs_set_model_2d", "gs_set_image_size", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite")
@@ -96,6 +96,8 @@ def load():
     L.gs_get_stage_times.argtypes = [vp, fp]
     L.gs_get_stage_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.gs_get_work_counters.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.gs_set_model_2d.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int]
+    L.gs_set_image_size.argtypes = [vp, C.c_int32, C.c_int32]
     L.gs_get_work_counters_ex.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gs_debug_time_composite.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     _lib = L
@@ -158,6 +160,19 @@ class Context:
         """ptrs: five device pointers (means, scales, quats, opacities, shs); borrowed, not copied."""
         self._chk(self.L.gs_set_model(self.h, n, sh_degree, *(C.c_void_p(int(p)) for p in ptrs), GS_MEM_DEVICE))
 
+    def set_model_2d_host(self, means, scales, rots, opacities, colors):
+        """SplatData2D (splat.jl:20-26): means [n,2], scales [n,2], rotations [n], opacities [n], colors [n,3]."""
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (means, scales, rots, opacities, colors)]
+        n = arrs[0].shape[0]
+        self._chk(self.L.gs_set_model_2d(self.h, n, *(C.c_void_p(a.ctypes.data) for a in arrs), GS_MEM_HOST))
+
+    def set_model_2d_device(self, n: int, ptrs):
+        self._chk(self.L.gs_set_model_2d(self.h, n, *(C.c_void_p(int(p)) for p in ptrs), GS_MEM_DEVICE))
+
+    def set_image_size(self, W: int, H: int):
+        self._chk(self.L.gs_set_image_size(self.h, int(W), int(H)))
+        self.W, self.H = int(W), int(H)
+
     def set_camera(self, T, P, fx, fy, near, far, eye, lookAt, W, H):
         fp = C.POINTER(C.c_float)
         a = [np.ascontiguousarray(v, np.float32).reshape(-1) for v in (T, P, eye, lookAt)]
@@ -201,6 +216,15 @@ class Context:
                    opacities=np.empty((n,), np.float32), shs=np.empty((n, k3), np.float32))
         self._chk(self.L.gs_grads_read(self.h, C.byref(grads), *(C.c_void_p(out[k].ctypes.data) for k in
                                                                    ("means", "scales", "quats", "opacities", "shs"))))
+        return out
+
+    def grads_read_2d(self, grads: GsGrads) -> dict:
+        """SplatGrads2D (splat.jl:28-34) from a gs_grads whose slots are read as (means, scales, rotations, opacities, colors)."""
+        n = self.num_gaussians
+        out = dict(means=np.empty((n, 2), np.float32), scales=np.empty((n, 2), np.float32), rots=np.empty((n,), np.float32),
+                   opacities=np.empty((n,), np.float32), colors=np.empty((n, 3), np.float32))
+        self._chk(self.L.gs_grads_read(self.h, C.byref(grads), *(C.c_void_p(out[k].ctypes.data) for k in
+                                                                   ("means", "scales", "rots", "opacities", "colors"))))
         return out
 
     def loss_host(self, img: np.ndarray, gt: np.ndarray, lam: float = 0.1):

@@ -21,6 +21,7 @@ ARCH = "gfx950"
 
 SOURCES = {
     "gs_preprocess.hip": ["-ffp-contract=off"],
+    "gs_preprocess2d.hip": ["-ffp-contract=off"],
     "gs_preprocess_bwd.hip": [],
     "gs_sort.hip": [],
     "gs_bin2.hip": [],

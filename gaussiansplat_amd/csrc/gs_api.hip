@@ -75,6 +75,9 @@ struct gs_ctx {
 
     int64_t n = 0;
     int sh_degree = 0;
+    int kind = 0;                            // 0: 3-D renderer (SplatData3D), 1: 2-D image-fitting renderer (SplatData2D)
+    size_t width[5] = {3, 3, 4, 1, 3};       // floats per gaussian of the five parameter / gradient arrays
+    int order() const { return kind == 1 ? (int)GS_ORDER_INDEX : cfg.order; }    // the 2-D model has no depth
     const float *means = nullptr, *scales = nullptr, *quats = nullptr, *opac = nullptr, *shs = nullptr;
     DevBuf model[5];
     GsCamera cam{};
@@ -269,8 +272,50 @@ int gs_set_model(gs_ctx *c, int64_t n, int sh_degree, const float *means, const 
     } else {
         for (int i = 0; i < 5; ++i) dst[i] = src[i];
     }
-    c->n = n; c->sh_degree = sh_degree;
+    c->n = n; c->sh_degree = sh_degree; c->kind = 0;
+    for (int i = 0; i < 5; ++i) c->width[i] = width[i];
     c->means = dst[0]; c->scales = dst[1]; c->quats = dst[2]; c->opac = dst[3]; c->shs = dst[4];
+    c->did_pre = c->did_bin = c->did_fwd = c->did_bwd = false;
+    return GS_OK;
+}
+
+int gs_set_model_2d(gs_ctx *c, int64_t n, const float *means, const float *scales, const float *rotations,
+                    const float *opacities, const float *colors, int mem) {
+    if (!c) return GS_ERR_INVALID;
+    if (n < 0 || n > 0x7FFFFFF0LL) return fail(c, GS_ERR_INVALID, "gs_set_model_2d: n out of range");
+    if (n > 0 && (!means || !scales || !rotations || !opacities || !colors)) return fail(c, GS_ERR_INVALID, "gs_set_model_2d: NULL array");
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(c, GS_ERR_INVALID, "gs_set_model_2d: bad mem");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const float *src[5] = {means, scales, rotations, opacities, colors};
+    const size_t width[5] = {2, 2, 1, 1, 3};
+    const float *dst[5];
+    if (mem == GS_MEM_HOST) {
+        for (int i = 0; i < 5; ++i) {
+            const size_t bytes = sizeof(float) * width[i] * (size_t)n;
+            HIPCHK(c, c->model[i].ensure(bytes ? bytes : 4));
+            if (bytes) HIPCHK(c, hipMemcpyAsync(c->model[i].p, src[i], bytes, hipMemcpyHostToDevice, c->stream));
+            dst[i] = c->model[i].as<float>();
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        for (int i = 0; i < 5; ++i) dst[i] = src[i];
+    }
+    c->n = n; c->sh_degree = 0; c->kind = 1;
+    for (int i = 0; i < 5; ++i) c->width[i] = width[i];
+    c->means = dst[0]; c->scales = dst[1]; c->quats = dst[2]; c->opac = dst[3]; c->shs = dst[4];
+    c->did_pre = c->did_bin = c->did_fwd = c->did_bwd = false;
+    return GS_OK;
+}
+
+int gs_set_image_size(gs_ctx *c, int32_t W, int32_t H) {
+    if (!c) return GS_ERR_INVALID;
+    if (W <= 0 || H <= 0 || W > 32767 || H > 32767) return fail(c, GS_ERR_INVALID, "gs_set_image_size: image size must be in 1..32767");
+    if (!c->have_cam) {                                  // a harmless camera, so the shared paths have one
+        std::memset(&c->cam, 0, sizeof(c->cam));
+        c->cam.near_ = -1.0f; c->cam.far_ = 1.0f;
+    }
+    c->cam.W = W; c->cam.H = H;
+    c->have_cam = true;
     c->did_pre = c->did_bin = c->did_fwd = c->did_bwd = false;
     return GS_OK;
 }
@@ -298,11 +343,29 @@ int gs_preprocess(gs_ctx *c) {
     HIPCHK(c, c->payload.ensure(sizeof(GsPayload) * n1));
     HIPCHK(c, c->depth_key.ensure(sizeof(uint32_t) * n1));
     HIPCHK(c, c->rect.ensure(sizeof(uint16_t) * 4 * n1));
-    GsPreprocessArgs a{};
-    a.n = c->n; a.sh_degree = c->sh_degree; a.order = c->cfg.order;
     // the tile grid is fixed by the image: the reference passes blocks = size/threads (main.jl:9-11)
     c->gx = (c->cam.W + GS_TILE - 1) / GS_TILE;
     c->gy = (c->cam.H + GS_TILE - 1) / GS_TILE;
+    if (c->kind == 1) {                                  // preprocess(::GaussianRenderer2D), forward.jl:9-33
+        GsPreprocess2DArgs a2{};
+        a2.n = c->n; a2.W = c->cam.W; a2.H = c->cam.H; a2.gx = c->gx; a2.gy = c->gy;
+        a2.means = c->means; a2.scales = c->scales; a2.rots = c->quats; a2.opac = c->opac; a2.colors = c->shs;
+        a2.payload = c->payload.as<GsPayload>(); a2.depth_key = c->depth_key.as<uint32_t>(); a2.rect = c->rect.as<uint16_t>();
+        if (c->cfg.export_debug) {
+            const size_t w[7] = {4, 4, 2, 9, 4, 4, 4};
+            for (int i = 0; i < 7; ++i) HIPCHK(c, c->dbg[i].ensure(sizeof(float) * w[i] * n1));
+            a2.dbg.mu = c->dbg[2].as<float>(); a2.dbg.cov2d = c->dbg[4].as<float>(); a2.dbg.invcov = c->dbg[5].as<float>();
+            a2.dbg.bbs = c->dbg[6].as<float>();
+        }
+        {
+            StageTimer t(c, GS_STAGE_PREPROCESS);
+            HIPCHK(c, gs_launch_preprocess2d(a2, c->stream));
+        }
+        c->did_pre = true; c->did_bin = c->did_fwd = c->did_bwd = false;
+        return GS_OK;
+    }
+    GsPreprocessArgs a{};
+    a.n = c->n; a.sh_degree = c->sh_degree; a.order = c->cfg.order;
     a.gx = c->gx; a.gy = c->gy;
     a.means = c->means; a.scales = c->scales; a.quats = c->quats; a.opac = c->opac; a.shs = c->shs;
     a.payload = c->payload.as<GsPayload>();
@@ -332,7 +395,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     const size_t n = (size_t)c->n, n1 = n ? n : 1;
     const int64_t ntiles = (int64_t)c->gx * c->gy;
     uint32_t *perm = nullptr;
-    if (c->cfg.order != GS_ORDER_INDEX) {
+    if (c->order() != GS_ORDER_INDEX) {
         StageTimer t(c, GS_STAGE_DEPTH_SORT);
         HIPCHK(c, c->pairs_a.ensure(sizeof(uint64_t) * n1));
         HIPCHK(c, c->pairs_b.ensure(sizeof(uint64_t) * n1));
@@ -478,6 +541,22 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
         HIPCHK(c, hipMemsetAsync(a.walked + 2, 0, 8, c->stream));
         HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
     }
+    if (c->kind == 1) {                                  // SplatGrads2D, splat.jl:28-34
+        GsPreprocess2DBwdArgs b2{};
+        b2.n = c->n; b2.W = c->cam.W; b2.H = c->cam.H;
+        b2.scales = c->scales; b2.rots = c->quats;
+        b2.g2d = det ? nullptr : c->g2d.as<float>(); b2.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
+        b2.overwrite = (flags & GS_BWD_OVERWRITE) ? 1 : 0;
+        b2.d_means = grads->d_means; b2.d_scales = grads->d_scales; b2.d_rots = grads->d_quats;
+        b2.d_opac = grads->d_opacities; b2.d_colors = grads->d_shs;
+        {
+            StageTimer t(c, GS_STAGE_PREPROCESS_BWD);
+            HIPCHK(c, gs_launch_preprocess2d_bwd(b2, c->stream));
+        }
+        if (mem == GS_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->did_bwd = true;
+        return GS_OK;
+    }
     GsPreprocessBwdArgs b{};
     b.n = c->n; b.sh_degree = c->sh_degree;
     b.means = c->means; b.scales = c->scales; b.quats = c->quats; b.opac = c->opac; b.shs = c->shs;
@@ -527,9 +606,8 @@ int gs_allreduce_grads(gs_ctx *c, const gs_grads *g) {
     if (!c->comm) return fail(c, GS_ERR_INVALID, "gs_allreduce_grads: gs_comm_init first");
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t n = (size_t)c->n;
-    const size_t K3 = (size_t)3 * (c->sh_degree + 1) * (c->sh_degree + 1);
     float *p[5] = {g->d_means, g->d_scales, g->d_quats, g->d_opacities, g->d_shs};
-    const size_t w[5] = {3 * n, 3 * n, 4 * n, n, K3 * n};
+    const size_t w[5] = {c->width[0] * n, c->width[1] * n, c->width[2] * n, c->width[3] * n, c->width[4] * n};
     bool flat = p[0] != nullptr;
     for (int i = 0; i + 1 < 5 && flat; ++i) flat = p[i + 1] == p[i] + w[i];
     auto reduce = [&](float *buf, size_t count) -> int {
@@ -594,11 +672,10 @@ int gs_sgd_step(gs_ctx *c, float lr, const gs_grads *g) {
     if (!c || !g) return GS_ERR_INVALID;
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t n = (size_t)c->n;
-    const size_t K3 = (size_t)3 * (c->sh_degree + 1) * (c->sh_degree + 1);
     float *p[5] = {const_cast<float *>(c->means), const_cast<float *>(c->scales), const_cast<float *>(c->quats),
                    const_cast<float *>(c->opac), const_cast<float *>(c->shs)};
     const float *gr[5] = {g->d_means, g->d_scales, g->d_quats, g->d_opacities, g->d_shs};
-    const size_t w[5] = {3, 3, 4, 1, K3};
+    const size_t *w = c->width;
     for (int i = 0; i < 5; ++i) HIPCHK(c, gs_launch_sgd(p[i], gr[i], lr, w[i] * n, c->stream));
     c->did_pre = c->did_bin = c->did_fwd = c->did_bwd = false;       // the model changed
     return GS_OK;
@@ -608,12 +685,9 @@ int gs_reset_grads(gs_ctx *c, const gs_grads *g) {
     if (!c || !g) return GS_ERR_INVALID;
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t n = (size_t)c->n;
-    const int K = (c->sh_degree + 1) * (c->sh_degree + 1);
-    if (g->d_means) HIPCHK(c, hipMemsetAsync(g->d_means, 0, sizeof(float) * 3 * n, c->stream));
-    if (g->d_scales) HIPCHK(c, hipMemsetAsync(g->d_scales, 0, sizeof(float) * 3 * n, c->stream));
-    if (g->d_quats) HIPCHK(c, hipMemsetAsync(g->d_quats, 0, sizeof(float) * 4 * n, c->stream));
-    if (g->d_opacities) HIPCHK(c, hipMemsetAsync(g->d_opacities, 0, sizeof(float) * n, c->stream));
-    if (g->d_shs) HIPCHK(c, hipMemsetAsync(g->d_shs, 0, sizeof(float) * 3 * K * n, c->stream));
+    float *p[5] = {g->d_means, g->d_scales, g->d_quats, g->d_opacities, g->d_shs};
+    for (int i = 0; i < 5; ++i)
+        if (p[i] && n) HIPCHK(c, hipMemsetAsync(p[i], 0, sizeof(float) * c->width[i] * n, c->stream));
     return GS_OK;
 }
 
@@ -621,12 +695,13 @@ int gs_grads_alloc(gs_ctx *c, gs_grads *out) {
     if (!c || !out) return GS_ERR_INVALID;
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t n = (size_t)c->n;
-    const size_t K3 = (size_t)3 * (c->sh_degree + 1) * (c->sh_degree + 1);
-    const size_t total = n * (11 + K3);
+    size_t off[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; ++i) off[i + 1] = off[i] + c->width[i] * n;
+    const size_t total = off[5];
     HIPCHK(c, c->grads_flat.ensure(sizeof(float) * (total ? total : 1)));
     HIPCHK(c, hipMemsetAsync(c->grads_flat.p, 0, sizeof(float) * total, c->stream));
     float *f = c->grads_flat.as<float>();
-    out->d_means = f; out->d_scales = f + 3 * n; out->d_quats = f + 6 * n; out->d_opacities = f + 10 * n; out->d_shs = f + 11 * n;
+    out->d_means = f; out->d_scales = f + off[1]; out->d_quats = f + off[2]; out->d_opacities = f + off[3]; out->d_shs = f + off[4];
     return GS_OK;
 }
 
@@ -634,10 +709,9 @@ int gs_grads_read(gs_ctx *c, const gs_grads *g, float *h_means, float *h_scales,
     if (!c || !g) return GS_ERR_INVALID;
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t n = (size_t)c->n;
-    const size_t K3 = (size_t)3 * (c->sh_degree + 1) * (c->sh_degree + 1);
     const float *src[5] = {g->d_means, g->d_scales, g->d_quats, g->d_opacities, g->d_shs};
     float *dst[5] = {h_means, h_scales, h_quats, h_opacities, h_shs};
-    const size_t w[5] = {3, 3, 4, 1, K3};
+    const size_t *w = c->width;
     for (int i = 0; i < 5; ++i)
         if (dst[i] && src[i] && n) HIPCHK(c, hipMemcpyAsync(dst[i], src[i], sizeof(float) * w[i] * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -704,7 +778,7 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
                 std::memcpy(dst, h.data(), sizeof(uint32_t) * ni);
             } else {                                   // tile<<32 | depth key (or | id): the key the list order realises
                 uint64_t *o = static_cast<uint64_t *>(dst);
-                const bool by_index = c->cfg.order == GS_ORDER_INDEX;
+                const bool by_index = c->order() == GS_ORDER_INDEX;
                 for (size_t t = 0; t < nt; ++t)
                     for (size_t p = rg[2 * t]; p < rg[2 * t + 1] && p < ni; ++p)
                         o[p] = ((uint64_t)t << 32) | (by_index ? h[p] : dk[h[p]]);

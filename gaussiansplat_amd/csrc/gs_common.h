@@ -46,6 +46,28 @@ struct GsPreprocessArgs {
 // launchers (each enqueues on `stream`, returns hipGetLastError())
 hipError_t gs_launch_preprocess(const GsPreprocessArgs &a, const GsCamera &cam, hipStream_t stream);
 
+// 2-D image-fitting renderer (gs_preprocess2d.hip): SplatData2D, reference src/splat.jl:20-26
+struct GsPreprocess2DArgs {
+    int64_t n;
+    int W, H, gx, gy;
+    const float *means, *scales, *rots, *opac, *colors;    // 2n, 2n, n, n, 3n
+    GsPayload *payload;
+    uint32_t *depth_key;
+    uint16_t *rect;
+    GsDebugArrays dbg;                                     // mu, cov2d, invcov, bbs used
+};
+struct GsPreprocess2DBwdArgs {
+    int64_t n;
+    int W, H;
+    const float *scales, *rots;
+    const float *g2d;
+    const long long *g2d_fixed;
+    float *d_means, *d_scales, *d_rots, *d_opac, *d_colors;   // accumulate (+=) or overwrite; may be null
+    int overwrite;
+};
+hipError_t gs_launch_preprocess2d(const GsPreprocess2DArgs &a, hipStream_t stream);
+hipError_t gs_launch_preprocess2d_bwd(const GsPreprocess2DBwdArgs &a, hipStream_t stream);
+
 struct GsSortScratch {     // sized by gs_sort_scratch_bytes
     uint32_t *block_hist;  // [256][nblocks]
     uint32_t *digit_total; // [256]

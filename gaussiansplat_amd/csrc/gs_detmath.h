@@ -43,3 +43,35 @@ __device__ __forceinline__ float gs_expf(float x) {
 // Julia max/min propagate NaN.
 __device__ __forceinline__ double gs_jlmax(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
 __device__ __forceinline__ double gs_jlmin(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
+
+// The spec's sin/cos (2-D renderer, reference src/cov2d.jl:6-8 CUDA.cos / CUDA.sin): k = rint(x*2/pi), three-term
+// Cody-Waite reduction by pi/2, Cephes sinf/cosf polynomials on [-pi/4, pi/4], quadrant fix-up; fp32 mul/add only
+// (the CPU oracle and its NumPy twin use the same sequence of operations).
+__device__ __forceinline__ void gs_sincosf(float x, float &sn, float &cs) {
+    if (!(x - x == 0.0f)) { sn = __builtin_nanf(""); cs = sn; return; }      // NaN or Inf
+    const float kf = __builtin_rintf(x * 0.636619772f);
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.837512969970703125e-4f;
+    r = r - kf * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * z + 8.3321608736e-3f;
+    ps = ps * z + -1.6666654611e-1f;
+    ps = ps * z;
+    ps = ps * r;
+    ps = ps + r;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * z + -1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    pc = pc * z;
+    pc = pc * z;
+    pc = pc - 0.5f * z;
+    pc = pc + 1.0f;
+    const long long k = (long long)kf;
+    switch ((int)(k & 3)) {
+        case 0: sn = ps;  cs = pc;  break;
+        case 1: sn = pc;  cs = -ps; break;
+        case 2: sn = -ps; cs = -pc; break;
+        default: sn = -pc; cs = ps; break;
+    }
+}

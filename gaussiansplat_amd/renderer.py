@@ -55,6 +55,37 @@ class SplatGrads3D:                     # splat.jl:45-52 -- views into ONE flat 
     Δfeatures: object = None
 
 
+@dataclass
+class SplatData2D:                      # splat.jl:20-26
+    means: "torch.Tensor"               # [n, 2]  fractions of the image, pixel position (W*mx, H*my)
+    scales: "torch.Tensor"              # [n, 2]  log-space
+    rotations: "torch.Tensor"           # [n, 1]  theta
+    opacities: "torch.Tensor"           # [n, 1]  used raw (splat.jl:341)
+    colors: "torch.Tensor"              # [n, 3]
+
+
+@dataclass
+class SplatGrads2D:                     # splat.jl:28-34 -- views into ONE flat buffer
+    flat: "torch.Tensor"
+    Δmeans: "torch.Tensor"
+    Δscales: "torch.Tensor"
+    Δrotations: "torch.Tensor"
+    Δopacities: "torch.Tensor"
+    Δcolors: "torch.Tensor"
+
+
+def initGrads2D(splatData: SplatData2D) -> SplatGrads2D:
+    """initGrads(::SplatData2D), splat.jl:121-135, as one flat buffer [Δmeans 2N | Δscales 2N | Δrot N | Δopac N | Δcolors 3N]."""
+    import torch
+    n = splatData.means.shape[0]
+    sizes = [2 * n, 2 * n, n, n, 3 * n]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=splatData.means.device)
+    parts, o = [], 0
+    for sz in sizes:
+        parts.append(flat[o:o + sz]); o += sz
+    return SplatGrads2D(flat, parts[0].view(n, 2), parts[1].view(n, 2), parts[2].view(n, 1), parts[3].view(n, 1), parts[4].view(n, 3))
+
+
 def initGrads(splatData: SplatData3D) -> SplatGrads3D:
     """splat.jl:137-156; laid out as one flat fp32 buffer
     [Δmeans 3N | Δscales 3N | Δquats 4N | Δopac N | Δshs 3K·N] so that a multi-view step needs a
@@ -120,6 +151,13 @@ class GaussianRenderer3D:               # renderer.jl:205-219
     def _end(self):                 # kept for callers written against the fenced version: nothing to do
         pass
 
+    def _set_view(self, camera):
+        cam = camera or self.camera or default_camera()
+        self.camera = cam
+        H, W = self.transmittance.shape
+        self.ctx.set_camera(compute_transform(cam), compute_projection(cam, W, H), float(np.float32(cam.fx)), float(np.float32(cam.fy)),
+                            float(np.float32(cam.near)), float(np.float32(cam.far)), cam.eye, cam.lookAt, W, H)
+
     # scratch arrays of the reference struct, fetched on demand (export_debug for the fp32 ones)
     @property
     def sortIdxs(self): return self.ctx.get_array(B.ARR_SORT_IDXS)
@@ -133,6 +171,68 @@ class GaussianRenderer3D:               # renderer.jl:205-219
     def invCov2ds(self): return self.ctx.get_array(B.ARR_INVCOV)
     @property
     def bbs(self): return self.ctx.get_array(B.ARR_BBS)
+
+
+class GaussianRenderer2D:               # renderer.jl:7-18
+    """The 2-D image-fitting renderer: same binning and composite kernels as the 3-D one behind a different
+    preprocess (cov2d.jl:3-28).  The reference's own 2-D constructors reference undefined names (renderer.jl:38-82)
+    and its backward (splat.jl:271-396) is not the adjoint of any one forward; this is the consistent version
+    (DESIGN.md, 2-D renderer)."""
+
+    def __init__(self, splatData: SplatData2D, imgSize, device: int = 0, t_min: float = 1e-5, export_debug: bool = False,
+                 profile_stages: bool = False, deterministic: bool = False, alpha_cull: bool = True):
+        import torch
+        self.splatData = splatData
+        self._splatGrads = initGrads2D(splatData)
+        self._grads_lazy_zero = False
+        W, H = int(imgSize[0]), int(imgSize[1])
+        dev = splatData.means.device
+        self.imageData = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+        self.transmittance = torch.ones((H, W), dtype=torch.float32, device=dev)
+        self.nGaussians = splatData.means.shape[0]
+        self.camera = None
+        self.ctx = B.Context(device=device, order=B.ORDER_INDEX, t_min=t_min, export_debug=export_debug, profile_stages=profile_stages,
+                             deterministic=deterministic, alpha_cull=alpha_cull)
+        self._stream_handle = None
+        self._begin()
+        self.ctx.set_model_2d_device(self.nGaussians, [t.data_ptr() for t in (splatData.means, splatData.scales, splatData.rotations,
+                                                                              splatData.opacities, splatData.colors)])
+        g = self._splatGrads
+        self._grads = B.GsGrads(g.Δmeans.data_ptr(), g.Δscales.data_ptr(), g.Δrotations.data_ptr(), g.Δopacities.data_ptr(),
+                                g.Δcolors.data_ptr())
+
+    splatGrads = GaussianRenderer3D.splatGrads
+    _begin = GaussianRenderer3D._begin
+    _end = GaussianRenderer3D._end
+
+    def _set_view(self, camera=None):
+        H, W = self.transmittance.shape
+        self.ctx.set_image_size(W, H)
+
+    @property
+    def positions(self): return self.ctx.get_array(B.ARR_MU)
+    @property
+    def cov2ds(self): return self.ctx.get_array(B.ARR_COV2D)
+    @property
+    def invCov2ds(self): return self.ctx.get_array(B.ARR_INVCOV)
+    @property
+    def bbs(self): return self.ctx.get_array(B.ARR_BBS)
+
+
+def initData2D(nGaussians: int, seed: int = 0) -> dict:
+    """initData(Val(SPLAT2D), n), splat.jl:74-87: everything uniform [0,1), rotations pi/2*(U-0.5)."""
+    rng = np.random.default_rng(seed)
+    r = lambda *sh: rng.random(sh, dtype=np.float32)
+    return dict(means=r(nGaussians, 2), scales=r(nGaussians, 2), rots=np.float32(np.pi / 2) * (r(nGaussians) - np.float32(0.5)),
+                opacities=r(nGaussians), colors=r(nGaussians, 3))
+
+
+def _to_device_data_2d(scene: dict, device) -> SplatData2D:
+    import torch
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(device).contiguous()
+    n = np.asarray(scene["means"]).shape[0]
+    return SplatData2D(means=t(scene["means"]), scales=t(scene["scales"]), rotations=t(np.reshape(scene["rots"], (n, 1))),
+                       opacities=t(np.reshape(scene["opacities"], (n, 1))), colors=t(scene["colors"]))
 
 
 def _to_device_data(scene: dict, device) -> SplatData3D:
@@ -152,15 +252,15 @@ def initData(nGaussians: int, seed: int = 0) -> dict:
                 opacities=r(nGaussians))
 
 
-def getRenderer(rendererType, imgSize, threads, blocks, source=None, *, device: int = 0, **kw) -> GaussianRenderer3D:
+def getRenderer(rendererType, imgSize, threads, blocks, source=None, *, device: int = 0, **kw):
     """renderer.jl:164-186.  `source`: a PLY path (splat.jl:106-119), an int nGaussians
     (splat.jl:90-104) or a dict of arrays (means, scales, quats, opacities, shs[n,K,3])."""
     import torch
     if isinstance(rendererType, str):
         rendererType = RendererType[rendererType.lstrip(":")]
-    if rendererType != RendererType.GAUSSIAN_3D:
-        raise NotImplementedError(f"{rendererType}: only GAUSSIAN_3D exists on this path (the reference's 2-D "
-                                  "constructors reference undefined names, renderer.jl:38-82; OPTIMAL_PROJECTION_3D has no body)")
+    if rendererType == RendererType.OPTIMAL_PROJECTION_3D:
+        raise NotImplementedError("OPTIMAL_PROJECTION_3D: the reference has an enum value and a forwarding method "
+                                  "(renderer.jl:23,189-195) but no implementation to follow")
     if tuple(threads) != (16, 16):
         raise ValueError("threads must be (16, 16) (tile size of the reference's example, main.jl:9)")
     W, H = int(imgSize[0]), int(imgSize[1])
@@ -168,6 +268,15 @@ def getRenderer(rendererType, imgSize, threads, blocks, source=None, *, device: 
         raise ValueError("blocks must be ceil(imgSize/threads)")
     if not torch.cuda.is_available():
         raise RuntimeError("gaussiansplat_amd needs a HIP device (no CPU fallback)")
+    if rendererType == RendererType.GAUSSIAN_2D:         # renderer.jl:38-82: nGaussians or arrays (no PLY form)
+        if isinstance(source, int):
+            scene = initData2D(source)
+        elif isinstance(source, dict):
+            scene = source
+        else:
+            raise TypeError("GAUSSIAN_2D: source must be an int (nGaussians) or a dict of arrays (means, scales, rots, opacities, colors)")
+        kw.pop("order", None)
+        return GaussianRenderer2D(_to_device_data_2d(scene, torch.device("cuda", device)), (W, H), device=device, **kw)
     if isinstance(source, str):
         from .ply import load_ply
         scene = load_ply(source)
@@ -184,20 +293,14 @@ def getRenderer(rendererType, imgSize, threads, blocks, source=None, *, device: 
     return GaussianRenderer3D(data, (W, H), deg, device=device, **kw)
 
 
-def preprocess(renderer: GaussianRenderer3D, camera: Camera | None = None):
-    """forward.jl:35-111.  The reference hard-codes defaultCamera() (forward.jl:53); a camera may
-    be passed instead.  Returns `tps` lazily (the reference returns the clip-space positions only to
-    hand them to forward())."""
-    cam = camera or renderer.camera or default_camera()
-    renderer.camera = cam
-    H, W = renderer.transmittance.shape
-    T = compute_transform(cam)
-    P = compute_projection(cam, W, H)
-    renderer.ctx.set_camera(T, P, float(np.float32(cam.fx)), float(np.float32(cam.fy)), float(np.float32(cam.near)),
-                            float(np.float32(cam.far)), cam.eye, cam.lookAt, W, H)
+def preprocess(renderer, camera: Camera | None = None):
+    """forward.jl:35-111 (3-D; the reference hard-codes defaultCamera(), forward.jl:53 -- a camera may be passed
+    instead) and forward.jl:9-33 (2-D: no camera).  Returns `tps` lazily (the reference returns the clip-space
+    positions only to hand them to forward()); None for the 2-D renderer."""
+    renderer._set_view(camera)
     renderer._begin()
     renderer.ctx.preprocess()
-    return _LazyTps(renderer)
+    return _LazyTps(renderer) if isinstance(renderer, GaussianRenderer3D) else None
 
 
 class _LazyTps:
@@ -205,20 +308,20 @@ class _LazyTps:
     def numpy(self): return self._r.ctx.get_array(B.ARR_TPS)
 
 
-def compactIdxs(renderer: GaussianRenderer3D, threads=(16, 16), blocks=None):
+def compactIdxs(renderer, threads=(16, 16), blocks=None):
     """forward.jl:118-161: builds the per-tile splat lists (tile|depth keys, radix sort, ranges)."""
     gx, gy = blocks if blocks is not None else (0, 0)
     renderer._begin()
     renderer.ctx.bin(int(gx), int(gy))
 
 
-def forward(renderer: GaussianRenderer3D, tps=None, threads=(16, 16), blocks=None):
+def forward(renderer, tps=None, threads=(16, 16), blocks=None):
     """forward.jl:163-198: writes renderer.imageData and renderer.transmittance in place."""
     renderer._begin()
     renderer.ctx.forward_device(renderer.imageData.data_ptr(), renderer.transmittance.data_ptr())
 
 
-def backward(renderer: GaussianRenderer3D, ΔC):
+def backward(renderer, ΔC):
     """backward.jl:3-38: ΔC has the shape of imageData; accumulates into renderer.splatGrads."""
     import torch
     dC = ΔC if isinstance(ΔC, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(ΔC, np.float32))
@@ -233,7 +336,7 @@ def backward(renderer: GaussianRenderer3D, ΔC):
 def resetGrads(renderer_or_grads):
     """splat.jl:158-173."""
     import torch
-    if isinstance(renderer_or_grads, GaussianRenderer3D):
+    if isinstance(renderer_or_grads, (GaussianRenderer3D, GaussianRenderer2D)):
         renderer_or_grads._grads_lazy_zero = True      # zero fill deferred: see GaussianRenderer3D.splatGrads
     else:
         renderer_or_grads.flat.zero_()

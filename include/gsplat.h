@@ -9,7 +9,9 @@
  *   gs_create / gs_destroy    getRenderer(...)                    src/renderer.jl:119-149,164-186
  *   gs_set_model              initData + `|> CuArray` uploads     src/splat.jl:106-119, src/forward.jl:63-69,169-170
  *   gs_set_camera             defaultCamera/computeTransform/...  src/forward.jl:53-62, src/camera.jl:88-111
- *   gs_preprocess             preprocess(renderer)                src/forward.jl:35-111
+ *   gs_set_model_2d           initData(Val(SPLAT2D)) / SplatData2D src/splat.jl:20-26,74-87 (2-D image-fitting renderer)
+ *   gs_set_image_size         size(renderer.imageData)            src/forward.jl:29
+ *   gs_preprocess             preprocess(renderer)                src/forward.jl:35-111 (3-D), :9-33 (2-D)
  *   gs_bin                    compactIdxs(renderer,threads,blocks) src/forward.jl:118-161
  *   gs_forward                forward(renderer,tps,threads,blocks) src/forward.jl:163-198
  *   gs_backward               backward(renderer, dC)              src/backward.jl:3-38
@@ -113,6 +115,18 @@ int gs_synchronize(gs_ctx *ctx);
 int gs_set_model(gs_ctx *ctx, int64_t n, int sh_degree,
                  const float *means, const float *scales, const float *quats,
                  const float *opacities, const float *shs, int mem);
+
+/* The 2-D image-fitting renderer (RendererType GAUSSIAN_2D; renderer.jl:7-18, SplatData2D splat.jl:20-26): means 2xN
+ * in [0,1]^2 (pixel position (W*mx, H*my), splat.jl:337-339), scales 2xN (log, cov2d.jl:14-17), rotations 1xN (theta,
+ * cov2d.jl:5), opacities 1xN (used raw, splat.jl:341: alpha = opacity*exp(-dist/2); values >= 1 saturate just below 1,
+ * values <= 0 contribute nothing), colors 3xN.  After this call gs_preprocess runs cov2d.jl:3-45 + boundingbox.jl on the
+ * pixel position, gs_bin builds the lists in gaussian-index order (there is no depth), gs_forward / gs_backward use the
+ * same composite kernels, and every gs_grads argument is read as SplatGrads2D (splat.jl:28-34):
+ *   d_means 2xN, d_scales 2xN, d_quats -> d_rotations 1xN, d_opacities 1xN, d_shs -> d_colors 3xN.
+ * Needs gs_set_image_size (or gs_set_camera, of which only W and H are used). */
+int gs_set_model_2d(gs_ctx *ctx, int64_t n, const float *means, const float *scales, const float *rotations,
+                    const float *opacities, const float *colors, int mem);
+int gs_set_image_size(gs_ctx *ctx, int32_t W, int32_t H);
 
 /* Camera + image size (forward.jl:41,53-62).  T, P: 16 floats each, column-major. */
 int gs_set_camera(gs_ctx *ctx, const float T[16], const float P[16], float fx, float fy,

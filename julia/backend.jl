@@ -77,6 +77,27 @@ function hip_getRenderer(means::Matrix{Float32}, scales::Matrix{Float32}, quater
     return r
 end
 
+# getRenderer(Val(GAUSSIAN_2D), ...)  (src/renderer.jl:38-82) with SplatData2D arrays (src/splat.jl:20-26): means 2xN in
+# [0,1]^2, scales 2xN (log), rotations 1xN, opacities 1xN, colors 3xN.  Gradient slots of GsGrads are then read as
+# SplatGrads2D: d_means 2xN, d_scales 2xN, d_quats -> rotations 1xN, d_opacities 1xN, d_shs -> colors 3xN.
+function hip_getRenderer2D(means::Matrix{Float32}, scales::Matrix{Float32}, rotations::Matrix{Float32},
+                           opacities::Matrix{Float32}, colors::Matrix{Float32}, imgSize; device = 0, cfg = defaultConfig())
+    ctxref = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:gs_create, libgs), Cint, (Ref{Ptr{Cvoid}}, Cint, Ref{GsConfig}), ctxref, device, cfg)
+    rc == 0 || error("gs_create failed: " * unsafe_string(ccall((:gs_last_error, libgs), Cstring, (Ptr{Cvoid},), C_NULL)))
+    n = size(means, 2)
+    r = HipRenderer(ctxref[], n, 0, imgSize[1], imgSize[2])
+    check(r, ccall((:gs_set_model_2d, libgs), Cint,
+                   (Ptr{Cvoid}, Int64, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cint),
+                   r.ctx, n, means, scales, rotations, opacities, colors, GS_MEM_HOST))
+    check(r, ccall((:gs_set_image_size, libgs), Cint, (Ptr{Cvoid}, Int32, Int32), r.ctx, r.W, r.H))
+    finalizer(x -> ccall((:gs_destroy, libgs), Cint, (Ptr{Cvoid},), x.ctx), r)
+    return r
+end
+
+# preprocess(renderer::GaussianRenderer2D)  (src/forward.jl:9-33): no camera
+hip_preprocess2D(r::HipRenderer) = check(r, ccall((:gs_preprocess, libgs), Cint, (Ptr{Cvoid},), r.ctx))
+
 # preprocess(renderer)  (src/forward.jl:35-111); T, P from computeTransform/computeProjection (.linear)
 function hip_preprocess(r::HipRenderer, camera, T::AbstractMatrix, P::AbstractMatrix)
     Tm = Matrix{Float32}(T); Pm = Matrix{Float32}(P)

@@ -1,0 +1,103 @@
+"""The 2-D image-fitting renderer (GAUSSIAN_2D) on the MI355X through the C ABI: preprocess,
+tile rectangles and lists BIT-EXACT against the oracle, pixels |d| <= 1e-4 + 1e-4|x|, gradients rel-L2 <= 1e-3
+against the fp64 adjoint; the Python mirror of the reference constructors; a short fit that must converge."""
+import numpy as np
+import pytest
+
+from common import rel_l2
+from gaussiansplat_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(3000, 256, 256, 5, 2.5), (1501, 200, 120, 6, 2.0), (777, 90, 70, 7, 3.0)]
+
+
+def _ctx(sc, W, H, **kw):
+    from gaussiansplat_amd import backend as B
+    ctx = B.Context(order=B.ORDER_INDEX, **kw)
+    ctx.set_model_2d_host(sc["means"], sc["scales"], sc["rots"], sc["opacities"], sc["colors"])
+    ctx.set_image_size(W, H)
+    return ctx
+
+
+@pytest.mark.parametrize("n,W,H,seed,shi", CASES)
+@pytest.mark.parametrize("bin_path", [0, 1])
+def test_preprocess_and_lists_bit_exact(oracle, n, W, H, seed, shi, bin_path):
+    from gaussiansplat_amd import backend as B
+    O = oracle
+    sc = synthetic.make_scene_2d(n, W, H, seed, scale_hi=shi)
+    ref = O.render2d(sc["means"], sc["scales"], sc["rots"], sc["opacities"], sc["colors"], W, H)
+    ctx = _ctx(sc, W, H, export_debug=True, bin_path=bin_path)
+    ctx.preprocess(); ctx.bin()
+    for which, key in ((B.ARR_MU, "mu"), (B.ARR_COV2D, "cov2d"), (B.ARR_INVCOV, "invcov"), (B.ARR_BBS, "bbs"), (B.ARR_RGB, "rgb"),
+                       (B.ARR_SIG, "sig")):
+        assert ctx.get_array(which).tobytes() == ref["pre"][key].tobytes(), key
+    assert ctx.num_instances == len(ref["ids"])
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ref["ranges"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ref["ids"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), ref["keys"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,W,H,seed,shi", CASES)
+@pytest.mark.parametrize("t_min,cull", [(0.0, True), (1e-5, True), (0.0, False)])
+def test_pixels_and_gradients(oracle, n, W, H, seed, shi, t_min, cull):
+    O = oracle
+    sc = synthetic.make_scene_2d(n, W, H, seed, scale_hi=shi)
+    ref = O.render2d(sc["means"], sc["scales"], sc["rots"], sc["opacities"], sc["colors"], W, H, t_min=t_min)
+    dC = synthetic.make_dC(W, H, seed)
+    gref = O.backward2d(sc["means"], sc["scales"], sc["rots"], sc["opacities"], sc["colors"], W, H, ref["ranges"], ref["ids"], dC, t_min=t_min)
+    ctx = _ctx(sc, W, H, t_min=t_min, alpha_cull=cull)
+    ctx.preprocess(); ctx.bin()
+    img, tr = ctx.forward_host()
+    assert np.all(np.abs(img - ref["image"]) <= 1e-4 + 1e-4 * np.abs(ref["image"])), np.abs(img - ref["image"]).max()
+    assert np.all(np.abs(tr - ref["trans"]) <= 1e-4 + 1e-4 * np.abs(ref["trans"]))
+    g = ctx.grads_alloc()
+    ctx.backward(dC, g); ctx.backward(dC, g)                     # gradients ACCUMULATE: two calls = 2x
+    got = ctx.grads_read_2d(g)
+    for k in ("means", "scales", "rots", "opacities", "colors"):
+        assert rel_l2(got[k].reshape(-1) / 2.0, gref[k].reshape(-1)) <= 1e-3, (k, rel_l2(got[k].reshape(-1) / 2.0, gref[k].reshape(-1)))
+    ctx.reset_grads(g)
+    assert all(float(np.abs(v).max()) == 0.0 for v in ctx.grads_read_2d(g).values())
+    ctx.close()
+
+
+def test_deterministic_gradients_are_bitwise_reproducible(oracle):
+    n, W, H = 2000, 160, 128
+    sc = synthetic.make_scene_2d(n, W, H, 9, scale_hi=2.5)
+    dC = synthetic.make_dC(W, H, 9)
+    outs = []
+    for rep in range(2):
+        ctx = _ctx(sc, W, H, deterministic=True)
+        ctx.preprocess(); ctx.bin(); ctx.forward_host()
+        g = ctx.grads_alloc(); ctx.backward(dC, g)
+        outs.append(ctx.grads_read_2d(g)); ctx.close()
+    for k in outs[0]:
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+
+
+def test_mirror_constructor_and_image_fit_converges(oracle):
+    """getRenderer(:GAUSSIAN_2D, ...) (renderer.jl:164-170 -> :38-82), then train.jl's loop: fit a target rendered
+    from other parameters; the L1+DSSIM loss (loss.jl:62-72) must fall."""
+    import torch
+    from gaussiansplat_amd import renderer as R, train as TR
+    n, W, H = 400, 96, 80
+    target = synthetic.make_scene_2d(n, W, H, 31, scale_hi=2.2)
+    rt = R.getRenderer("GAUSSIAN_2D", (W, H, 3), (16, 16), ((W + 15) // 16, (H + 15) // 16), target)
+    R.preprocess(rt); R.compactIdxs(rt); R.forward(rt)
+    gt = rt.imageData.clone()
+    ref = oracle.render2d(target["means"], target["scales"], target["rots"], target["opacities"], target["colors"], W, H, t_min=1e-5)
+    assert np.abs(gt.cpu().numpy() - ref["image"]).max() <= 2e-4
+    start = {k: v.copy() for k, v in target.items()}
+    rng = np.random.default_rng(1)
+    start["colors"] = np.clip(start["colors"] + rng.normal(0, 0.25, start["colors"].shape), 0, 1).astype(np.float32)
+    start["opacities"] = np.clip(start["opacities"] * 0.7, 0.02, 0.95).astype(np.float32)
+    r = R.getRenderer(":GAUSSIAN_2D", (W, H, 3), (16, 16), None, start)
+    lf = TR.getLossFunction((W, H), 11, 3, renderer=r)
+    losses = TR.train(r, gt, lr=0.5, lossFunc=lf, iterations=60)       # plain SGD, as train.jl:42-46
+    assert np.isfinite(losses).all() and losses[-1] < 0.75 * losses[0], (losses[0], losses[-1])
+    assert all(b <= a * 1.001 for a, b in zip(losses, losses[1:]))      # and falls steadily
+    assert isinstance(r.splatGrads, R.SplatGrads2D) and tuple(r.splatGrads.Δrotations.shape) == (n, 1)
+    assert float(r.splatGrads.flat.abs().max()) == 0.0            # resetGrads after the last step (train.jl:55)
+    with pytest.raises(NotImplementedError):
+        R.getRenderer("OPTIMAL_PROJECTION_3D", (W, H, 3), (16, 16), None, 10)
