@@ -100,7 +100,7 @@ struct gs_ctx {
     bool ev_fresh[GS_STAGE_COUNT] = {};      // ... and not yet added to the accumulators
     double ev_sum[GS_STAGE_COUNT] = {};
     int64_t ev_cnt[GS_STAGE_COUNT] = {};
-    DevBuf counters;                         // 4 x u64: entries walked fwd / bwd, evaluated fwd / bwd
+    DevBuf counters;                         // 4 x u64: entries walked, evaluated by the forward; walked, evaluated by the backward
     DevBuf grads_flat;                       // gs_grads_alloc
     DevBuf dpc;                              // 4 x n scratch between the two backward kernels
     DevBuf loss_maps, loss_acc, loss_in[2], loss_dc;
@@ -126,7 +126,7 @@ int hipfail(gs_ctx *c, hipError_t e, const char *what) {
 
 struct StageTimer {
     gs_ctx *c; int st; bool on;
-    StageTimer(gs_ctx *c_, int st_) : c(c_), st(st_), on(c_->cfg.profile_stages != 0) {
+    StageTimer(gs_ctx *c_, int st_) : c(c_), st(st_), on(c_->cfg.profile_stages == 1 || c_->cfg.profile_stages == 2 + st_) {
         if (on) (void)hipEventRecord(c->ev[st][0], c->stream);
     }
     ~StageTimer() {
@@ -496,9 +496,9 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     HIPCHK(c, c->counters.ensure(32));
     a.walked = c->counters.as<unsigned long long>();
     a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32, c->stream));
     {
-        StageTimer t(c, GS_STAGE_COMPOSITE_FWD);
-        HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32, c->stream));
+        StageTimer t(c, GS_STAGE_COMPOSITE_FWD);                       // the kernel alone
         HIPCHK(c, gs_launch_composite_fwd(a, c->stream));
     }
     const hipMemcpyKind kind = mem == GS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
@@ -531,14 +531,13 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     a.dC = dC_dev; a.g2d = det ? nullptr : c->g2d.as<float>(); a.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
-    a.walked = c->counters.as<unsigned long long>() + 1;
+    a.walked = c->counters.as<unsigned long long>() + 2;
     a.variant = c->variant_bwd; a.cull = c->cfg.alpha_cull != 0;
     c->last_dC = dC_dev;
+    HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
+    HIPCHK(c, hipMemsetAsync(a.walked, 0, 16, c->stream));
     {
-        StageTimer t(c, GS_STAGE_COMPOSITE_BWD);
-        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
-        HIPCHK(c, hipMemsetAsync(a.walked, 0, 8, c->stream));
-        HIPCHK(c, hipMemsetAsync(a.walked + 2, 0, 8, c->stream));
+        StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                       // the kernel alone (what rocprof reports for it)
         HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
     }
     if (c->kind == 1) {                                  // SplatGrads2D, splat.jl:28-34
@@ -865,11 +864,11 @@ int gs_get_work_counters(gs_ctx *c, int64_t *walked_fwd, int64_t *walked_bwd) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_work_counters: gs_forward first");
     if (bind_device(c)) return GS_ERR_HIP;
-    unsigned long long h[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(h, c->counters.p, 16, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, c->counters.p, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (walked_fwd) *walked_fwd = (int64_t)h[0];
-    if (walked_bwd) *walked_bwd = (int64_t)h[1];
+    if (walked_bwd) *walked_bwd = (int64_t)h[2];
     return GS_OK;
 }
 
@@ -880,7 +879,7 @@ int gs_get_work_counters_ex(gs_ctx *c, int64_t out[4]) {
     unsigned long long h[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(h, c->counters.p, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 4; ++i) out[i] = (int64_t)h[i];
+    out[0] = (int64_t)h[0]; out[1] = (int64_t)h[2]; out[2] = (int64_t)h[1]; out[3] = (int64_t)h[3];
     return GS_OK;
 }
 

@@ -122,7 +122,7 @@ struct GsCompositeArgs {
     const float *dC;           // W*H*3
     float *g2d;                // 10 x n (atomic accumulate): drgb3 dsig dmu2 dinv4
     long long *g2d_fixed;      // deterministic mode: the same sums as 2^-40 fixed point (integer atomics commute)
-    unsigned long long *walked; // [0] list entries walked (staged) by this launch, [2] entries evaluated per pixel
+    unsigned long long *walked; // [0] list entries walked (staged) by this launch, [1] entries evaluated per pixel
                                 // after the no-op cull (one atomic each per tile); may be null
     int cull;                  // 1: drop (tile, splat) entries that are provably no-ops while staging (gs_config.alpha_cull)
     int variant;               // kernel variant (A/B testing; 0 = default)

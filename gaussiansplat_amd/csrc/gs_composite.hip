@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
     }
-    if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 2, (unsigned long long)evaluated); }
+    if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
     if (px <= a.W) {
         const size_t plane = (size_t)a.W * a.H;
 #pragma unroll
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
     }
-    if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 2, (unsigned long long)evaluated); }
+    if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
 }
 
 

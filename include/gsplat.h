@@ -76,7 +76,8 @@ typedef struct {
     int32_t export_debug;     /* 1: gs_preprocess also materialises the reference's scratch
                                  arrays (ts, tps, mu', cov3ds, cov2ds, invCov2ds, bbs) for
                                  gs_get_array; costs 124 extra bytes/gaussian of HBM writes   */
-    int32_t profile_stages;   /* 1: record hipEvents around every stage (gs_get_stage_times) */
+    int32_t profile_stages;   /* 1: record hipEvents around every stage (gs_get_stage_times; costs ~3 % of a C3 frame);
+                                 2 + s: around stage s (gs_stage) only; 0: none */
     int32_t bin_path;         /* 0: generate-in-pass binning on 32-bit words (default); 1: explicit
                                  64-bit tile|id instances + two radix passes (fallback, same result) */
     int32_t rank_mode;        /* radix-sort stable ranks: 0 = one LDS atomic-add-return per key (lane-ordered on
