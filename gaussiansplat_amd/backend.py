@@ -26,7 +26,7 @@ STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges
 SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
            "gs_synchronize", "gs_set_model", "gs_set_model_2d", "gs_set_image_size", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
-           "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
+           "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite")
 
 
@@ -98,6 +98,8 @@ def load():
     L.gs_get_work_counters.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.gs_set_model_2d.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int]
     L.gs_set_image_size.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gs_color_grads_pack.argtypes = [vp, vp]
+    L.gs_sh_grads_from_views.argtypes = [vp, C.c_int32, vp, vp, vp, C.c_int]
     L.gs_get_work_counters_ex.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gs_debug_time_composite.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     _lib = L
@@ -203,6 +205,17 @@ class Context:
             self._chk(self.L.gs_backward_ex(self.h, C.c_void_p(a.ctypes.data), GS_MEM_HOST, C.byref(grads), flags))
         else:
             self._chk(self.L.gs_backward_ex(self.h, C.c_void_p(int(dC_ptr_or_array)), GS_MEM_DEVICE, C.byref(grads), flags))
+
+    def color_grads_pack(self, drgb_ptr: int):
+        """d rgb of the last backward, packed [n, 3] into a device buffer (colour-factored exchange)."""
+        self._chk(self.L.gs_color_grads_pack(self.h, C.c_void_p(int(drgb_ptr))))
+
+    def sh_grads_from_views(self, cam_records: np.ndarray, drgb_ptr: int, d_shs_ptr: int, overwrite: bool = True):
+        """cam_records [nviews, 38] host float32 {T16, P16, eye3, lookAt3}; drgb [nviews, n, 3] device."""
+        cr = np.ascontiguousarray(cam_records, np.float32)
+        assert cr.ndim == 2 and cr.shape[1] == 38
+        self._chk(self.L.gs_sh_grads_from_views(self.h, cr.shape[0], C.c_void_p(cr.ctypes.data), C.c_void_p(int(drgb_ptr)),
+                                                C.c_void_p(int(d_shs_ptr)), 1 if overwrite else 0))
 
     def grads_alloc(self) -> GsGrads:
         """Library-owned flat gradient buffer (for hosts without a device allocator, e.g. plain Julia)."""

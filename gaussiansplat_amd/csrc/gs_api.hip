@@ -103,7 +103,7 @@ struct gs_ctx {
     DevBuf counters;                         // 4 x u64: entries walked, evaluated by the forward; walked, evaluated by the backward
     DevBuf grads_flat;                       // gs_grads_alloc
     DevBuf dpc;                              // 4 x n scratch between the two backward kernels
-    DevBuf loss_maps, loss_acc, loss_in[2], loss_dc;
+    DevBuf loss_maps, loss_acc, loss_in[2], loss_dc, view_cams;
     ncclComm_t comm = nullptr;
     int comm_ranks = 0;
 };
@@ -215,7 +215,7 @@ int gs_destroy(gs_ctx *c) {
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
                       &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
-                      &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc};
+                      &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->model) b.release();
     for (auto &b : c->dbg) b.release();
@@ -571,6 +571,28 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     }
     if (mem == GS_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));   // dC host buffer no longer needed
     c->did_bwd = true;
+    return GS_OK;
+}
+
+int gs_color_grads_pack(gs_ctx *c, float *drgb) {
+    if (!c || !drgb) return GS_ERR_INVALID;
+    if (c->kind != 0) return fail(c, GS_ERR_UNSUPPORTED, "gs_color_grads_pack: 3-D renderer only");
+    if (!c->did_bwd) return fail(c, GS_ERR_INVALID, "gs_color_grads_pack: gs_backward first");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const bool det = c->cfg.deterministic != 0;
+    HIPCHK(c, gs_launch_pack_drgb(det ? nullptr : c->g2d.as<float>(), det ? c->g2d.as<long long>() : nullptr, drgb, c->n, c->stream));
+    return GS_OK;
+}
+
+int gs_sh_grads_from_views(gs_ctx *c, int32_t nviews, const float *cams, const float *drgb, float *d_shs, int flags) {
+    if (!c || !cams || !drgb || !d_shs || nviews <= 0) return GS_ERR_INVALID;
+    if (c->kind != 0) return fail(c, GS_ERR_UNSUPPORTED, "gs_sh_grads_from_views: 3-D renderer only");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t bytes = sizeof(float) * GS_VIEW_RECORD_FLOATS * (size_t)nviews;
+    HIPCHK(c, c->view_cams.ensure(bytes));
+    HIPCHK(c, hipMemcpyAsync(c->view_cams.p, cams, bytes, hipMemcpyHostToDevice, c->stream));   // pageable source: staged before return
+    HIPCHK(c, gs_launch_sh_from_views(c->n, c->sh_degree, c->means, nviews, c->view_cams.as<float>(), drgb, d_shs,
+                                      (flags & GS_BWD_OVERWRITE) ? 1 : 0, c->stream));
     return GS_OK;
 }
 

@@ -143,6 +143,11 @@ struct GsPreprocessBwdArgs {
 };
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s);
 
+// colour-factored gradient exchange (gs_preprocess_bwd.hip)
+hipError_t gs_launch_pack_drgb(const float *g2d, const long long *g2d_fixed, float *out, int64_t n, hipStream_t s);
+hipError_t gs_launch_sh_from_views(int64_t n, int sh_degree, const float *means, int nviews, const float *cams, const float *drgb,
+                                   float *d_shs, int overwrite, hipStream_t s);
+
 #define GS_FIXED_SCALE 1099511627776.0f            // 2^40
 #define GS_FIXED_INV (1.0 / 1099511627776.0)
 

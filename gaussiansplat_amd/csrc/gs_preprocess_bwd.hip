@@ -287,6 +287,98 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
     }
 }
 
+// ---------------------------------------------------------------- colour-factored gradient exchange (multi-GPU)
+// d L / d sh[k][c] of one view is basis_k(dir_view) * d rgb[c]: rank one in (k, c).  A multi-view step therefore need
+// not all-reduce the 3K floats per gaussian (48 at degree 3 = 81 % of the gradient buffer): ranks exchange the THREE
+// floats d rgb per (view, gaussian) -- an all-gather of 12 B instead of an all-reduce of 192 B per gaussian -- and
+// every rank rebuilds sum_v basis(dir_v) (x) d rgb_v locally from the cameras it already knows.
+__global__ __launch_bounds__(256) void gs_pack_drgb_kernel(const float *__restrict__ g2d, const long long *__restrict__ g2d_fixed,
+                                                            float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over 3n
+    if (i >= 3 * n) return;
+    const int64_t g = i / 3; const int c = (int)(i - 3 * g);
+    out[i] = g2d_fixed ? (float)((double)g2d_fixed[10 * g + c] * GS_FIXED_INV) : g2d[10 * g + c];
+}
+
+// cams: nviews records of 38 floats {T[16], P[16], eye[3], lookAt[3]}; drgb: [nviews][3n]; the direction and the
+// basis are computed exactly as in gs_sh_bwd_kernel.
+template <int DEG, bool OVERWRITE>
+__global__ __launch_bounds__(256) void gs_sh_from_views_kernel(int64_t n, const float *__restrict__ means, int nviews,
+                                                                const float *__restrict__ cams, const float *__restrict__ drgb,
+                                                                float *__restrict__ d_shs) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    constexpr int ROW = 3 * K + 1;
+    extern __shared__ __attribute__((aligned(16))) float tile[];       // [256][ROW] accumulators
+    const int64_t gb = (int64_t)blockIdx.x * blockDim.x;
+    const int nb = (int)min((int64_t)blockDim.x, n - gb);
+    const int64_t g = gb + threadIdx.x;
+    float *acc = tile + threadIdx.x * ROW;
+#pragma unroll
+    for (int i = 0; i < 3 * K; ++i) acc[i] = 0.0f;
+    if (g < n) {
+        const float m1 = means[3 * g], m2 = means[3 * g + 1], m3 = means[3 * g + 2];
+        for (int v = 0; v < nviews; ++v) {
+            const float *T = cams + 38 * v, *P = T + 16, *eye = T + 32, *lookAt = T + 35;
+            float t[4], p[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = T[i] * m1 + T[i + 4] * m2 + T[i + 8] * m3 + T[i + 12];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[i] = P[i] * t[0] + P[i + 4] * t[1] + P[i + 8] * t[2] + P[i + 12] * t[3];
+            const float v0 = p[0] - (lookAt[0] - eye[0]);
+            const float v1 = p[1] - (lookAt[1] - eye[1]);
+            const float v2 = p[2] - (lookAt[2] - eye[2]);
+            const float inrm = rsqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+            const float X = v0 * inrm, Y = v1 * inrm, Z = v2 * inrm;
+            float bs[K];
+            bs[0] = SH_C0;
+            if constexpr (DEG >= 1) { bs[1] = -Y * SH_C1; bs[2] = Z * SH_C1; bs[3] = -X * SH_C1; }
+            if constexpr (DEG >= 2) {
+                const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+                bs[4] = bC2[0] * xy; bs[5] = bC2[1] * yz; bs[6] = bC2[2] * (2 * zz - xx - yy); bs[7] = bC2[3] * xz; bs[8] = bC2[4] * (xx - yy);
+                if constexpr (DEG >= 3) {
+                    bs[9] = bC3[0] * Y * (3 * xx - yy); bs[10] = bC3[1] * xy * Z; bs[11] = bC3[2] * Y * (4 * zz - xx - yy);
+                    bs[12] = bC3[3] * Z * (2 * zz - 3 * xx - 3 * yy); bs[13] = bC3[4] * X * (4 * zz - xx - yy);
+                    bs[14] = bC3[5] * Z * (xx - yy); bs[15] = bC3[6] * X * (xx - 3 * yy);
+                }
+            }
+            const float *gr = drgb + (size_t)v * 3 * (size_t)n + 3 * g;
+            const float g0 = gr[0], g1 = gr[1], g2 = gr[2];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { acc[3 * k] += bs[k] * g0; acc[3 * k + 1] += bs[k] * g1; acc[3 * k + 2] += bs[k] * g2; }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x) {     // coalesced rows
+        const float v = tile[(idx / (3 * K)) * ROW + idx % (3 * K)];
+        if (OVERWRITE) d_shs[gb * 3 * K + idx] = v; else d_shs[gb * 3 * K + idx] += v;
+    }
+}
+
+hipError_t gs_launch_pack_drgb(const float *g2d, const long long *g2d_fixed, float *out, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gs_pack_drgb_kernel, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, s, g2d, g2d_fixed, out, n);
+    return hipGetLastError();
+}
+
+hipError_t gs_launch_sh_from_views(int64_t n, int sh_degree, const float *means, int nviews, const float *cams, const float *drgb,
+                                   float *d_shs, int overwrite, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const dim3 block(256), grid((unsigned)((n + 255) / 256));
+    const int K = (sh_degree + 1) * (sh_degree + 1);
+    const size_t lds = sizeof(float) * 256 * (3 * K + 1);
+#define GS_SV(D) do { if (overwrite) hipLaunchKernelGGL((gs_sh_from_views_kernel<D, true>), grid, block, lds, s, n, means, nviews, cams, drgb, d_shs); \
+                      else hipLaunchKernelGGL((gs_sh_from_views_kernel<D, false>), grid, block, lds, s, n, means, nviews, cams, drgb, d_shs); } while (0)
+    switch (sh_degree) {
+        case 0: GS_SV(0); break;
+        case 1: GS_SV(1); break;
+        case 2: GS_SV(2); break;
+        case 3: GS_SV(3); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef GS_SV
+    return hipGetLastError();
+}
+
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s) {
     if (a.n <= 0) return hipSuccess;
     const dim3 block(256), grid((unsigned)((a.n + 255) / 256));

@@ -321,15 +321,20 @@ def forward(renderer, tps=None, threads=(16, 16), blocks=None):
     renderer.ctx.forward_device(renderer.imageData.data_ptr(), renderer.transmittance.data_ptr())
 
 
-def backward(renderer, ΔC):
-    """backward.jl:3-38: ΔC has the shape of imageData; accumulates into renderer.splatGrads."""
+def backward(renderer, ΔC, skip_shs: bool = False):
+    """backward.jl:3-38: ΔC has the shape of imageData; accumulates into renderer.splatGrads.
+    skip_shs (3-D renderer, colour-factored multi-GPU exchange): leave Δshs alone -- the caller rebuilds it from the
+    per-view colour gradients (distributed.multi_view_step(sync="factored"))."""
     import torch
     dC = ΔC if isinstance(ΔC, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(ΔC, np.float32))
     dC = dC.to(renderer.imageData.device, torch.float32).contiguous()
     assert dC.shape == renderer.imageData.shape
     renderer._dC_keepalive = dC
     renderer._begin()
-    renderer.ctx.backward(dC.data_ptr(), renderer._grads, overwrite=renderer._grads_lazy_zero)
+    grads = renderer._grads
+    if skip_shs:
+        grads = B.GsGrads(grads.d_means, grads.d_scales, grads.d_quats, grads.d_opacities, None)
+    renderer.ctx.backward(dC.data_ptr(), grads, overwrite=renderer._grads_lazy_zero)
     renderer._grads_lazy_zero = False
 
 

@@ -37,6 +37,42 @@ class OracleViewRenderer:
         self.flat += torch.from_numpy(np.concatenate([g[k].reshape(-1) for k in ("means", "scales", "quats", "opacities", "shs")]))
 
 
+class OracleFactoredRenderer(OracleViewRenderer):
+    """The colour-factored protocol of distributed.multi_view_step on the CPU: geometry gradients and d rgb per view
+    from the oracle's adjoint, SH gradients rebuilt as sum_v basis(dir_v) (x) d rgb_v in NumPy (fp64)."""
+
+    @property
+    def geometry_floats(self):
+        return 11 * N
+
+    def color_slots(self, nviews):
+        return torch.zeros((nviews, N, 3), dtype=torch.float64)
+
+    def render_view_factored(self, cam, dC, slot):
+        O, sc = self.O, self.sc
+        ocam = O.camera_from_arrays(gcam.compute_transform(cam), gcam.compute_projection(cam, W, H), np.float32(cam.fx), np.float32(cam.fy),
+                                    np.float32(cam.near), np.float32(cam.far), cam.eye, cam.lookAt, W, H)
+        r = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], DEG, ocam)
+        g = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], DEG, ocam, r["ranges"], r["ids"], dC)
+        self.flat[:11 * N] += torch.from_numpy(np.concatenate([g[k].reshape(-1) for k in ("means", "scales", "quats", "opacities")]))
+        slot.copy_(torch.from_numpy(g["g2d"][:, :3]))
+
+    def sh_from_views(self, cameras, drgb_all):
+        from oracle import gs_oracle_np as ONP
+        m = self.sc["means"].astype(np.float64)
+        K = (DEG + 1) ** 2
+        acc = np.zeros((N, K, 3))
+        for cam, d in zip(cameras, drgb_all.numpy()):
+            T = np.asarray(gcam.compute_transform(cam), np.float64).reshape(4, 4, order="F")
+            P = np.asarray(gcam.compute_projection(cam, W, H), np.float64).reshape(4, 4, order="F")
+            p = (P @ (T @ np.concatenate([m, np.ones((N, 1))], 1).T)).T
+            v = p[:, :3] - (np.asarray(cam.lookAt, np.float64) - np.asarray(cam.eye, np.float64))
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+            B = np.stack([np.broadcast_to(np.asarray(b, np.float64), (N,)) for b in ONP.sh_basis(DEG, v[:, 0], v[:, 1], v[:, 2])], 1)   # [N, K]
+            acc += B[:, :, None] * d[:, None, :]
+        self.flat[11 * N:] = torch.from_numpy(acc.reshape(-1))
+
+
 def _views():
     cams = [synthetic.scene_camera(W, view=v) for v in range(VIEWS)]
     dCs = [synthetic.make_dC(W, H, 100 + v) for v in range(VIEWS)]
@@ -56,6 +92,35 @@ def _worker(rank, world, port, out):
         assert all(torch.equal(gathered[0], g) for g in gathered)       # identical on every rank
     finally:
         dist.destroy_process_group()
+
+
+def _worker_factored(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cams, dCs = _views()
+        flat = D.multi_view_step(OracleFactoredRenderer(), cams, dCs, sync="factored")
+        if rank == 1:
+            np.save(out, flat.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_factored_sync_equals_plain_sum(tmp_path):
+    """all-reduce of the geometry part + all-gather of d rgb + local rebuild of the SH gradients == the plain sum."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "flat_f.npy")
+    mp.spawn(_worker_factored, args=(2, port, out), nprocs=2, join=True)
+    cams, dCs = _views()
+    single = OracleViewRenderer()
+    D.multi_view_step(single, cams, dCs)
+    got, want = np.load(out), single.flat.numpy()
+    assert np.allclose(got[:11 * N], want[:11 * N], rtol=1e-12, atol=1e-14)
+    assert np.linalg.norm(got[11 * N:] - want[11 * N:]) <= 1e-6 * np.linalg.norm(want[11 * N:])     # fp32 camera matrices vs fp64 here
+    one = OracleFactoredRenderer()
+    D.multi_view_step(one, cams, dCs, sync="factored")                   # world 1 takes the same path without collectives
+    assert np.allclose(one.flat.numpy(), got, rtol=1e-12, atol=1e-14)
 
 
 def test_shard_views_partitions_exactly():

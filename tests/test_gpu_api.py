@@ -162,3 +162,40 @@ def test_rccl_allreduce_through_c_abi_single_rank():
     for k in before:
         assert np.array_equal(before[k], after[k]), k
     ctx.close()
+
+
+def test_colour_factored_exchange_equals_plain_accumulation(oracle):
+    """distributed.multi_view_step(sync="factored") on one GPU (no process group): geometry gradients accumulate over
+    the views, d rgb of every view is packed, and gs_sh_grads_from_views rebuilds the SH gradients -- the flat buffer
+    must equal the plain accumulation over the same views, and (for one view) the fp64 oracle."""
+    import torch
+    from gaussiansplat_amd import distributed as D, renderer as R, synthetic
+    n, W, H, deg = 3000, 160, 112, 3
+    scene = synthetic.make_scene(n, W, H, deg, seed=61)
+    cams = [synthetic.scene_camera(W, view=v) for v in range(3)]
+    dCs = [synthetic.make_dC(W, H, 200 + v) for v in range(3)]
+    flats = {}
+    for sync in ("allreduce", "factored"):
+        r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, scene, t_min=0.0, deterministic=True)   # bitwise reproducible sums
+        flats[sync] = D.multi_view_step(D.HipViewRenderer(r), cams, dCs, sync=sync).clone()
+        torch.cuda.synchronize()
+    a, b = flats["allreduce"].cpu().numpy().astype(np.float64), flats["factored"].cpu().numpy().astype(np.float64)
+    assert np.array_equal(a[:11 * n], b[:11 * n])                                   # geometry part: the same kernels
+    assert np.linalg.norm(a[11 * n:] - b[11 * n:]) <= 2e-6 * np.linalg.norm(a[11 * n:])
+    assert np.abs(a[11 * n:]).max() > 0
+    # deterministic mode and accumulate-into (overwrite = False) through the raw ABI
+    from common import hip_context, scene_and_cameras
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 61)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=0.0, deterministic=True)
+    ctx.preprocess(); ctx.bin(); ctx.forward_host()
+    g = ctx.grads_alloc()
+    ctx.backward(dCs[0], g)
+    want = ctx.grads_read(g, deg)["shs"].astype(np.float64)
+    drgb = torch.empty((1, n, 3), dtype=torch.float32, device="cuda")
+    ctx.color_grads_pack(drgb.data_ptr())
+    out = torch.full((n, 3 * (deg + 1) ** 2), 1.0, dtype=torch.float32, device="cuda")
+    ctx.sh_grads_from_views(D.view_records([cam], W, H), drgb.data_ptr(), out.data_ptr(), overwrite=False)
+    ctx.synchronize()
+    got = out.cpu().numpy().astype(np.float64) - 1.0
+    assert np.linalg.norm(got - want) <= 1e-5 * np.linalg.norm(want)
+    ctx.close()
