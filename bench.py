@@ -151,7 +151,7 @@ def main():
     from gaussiansplat_amd import distributed as D
     factored = world > 1 and args.grad_sync == "factored"
     all_cams = [synthetic.scene_camera(W, view=int(os.environ.get("GS_BENCH_VIEW", k % 8))) for k in range(world)]   # rank k renders view k
-    state = {}
+    cam_records = D.view_records(all_cams, W, H)                                # host, once: the cameras of all ranks' views
 
     def step(r):
         R.resetGrads(r)
@@ -164,15 +164,17 @@ def main():
                 dist.all_reduce(r.splatGrads.flat)       # ONE flat RCCL all-reduce (59 N floats at SH3)
             return
         # colour-factored exchange: same gradients, 11N floats all-reduced + 3N per view all-gathered
-        hv = state.setdefault(id(r), D.HipViewRenderer(r))
+        if "_bench_hv" not in r.__dict__:                                   # (cycle r <-> hv: collected by gc below)
+            r._bench_hv = D.HipViewRenderer(r)
+            r._bench_allc = torch.empty(world * 3 * n, dtype=torch.float32, device="cuda")
+        hv, allc = r._bench_hv, r._bench_allc
         slots = hv.color_slots(1)
         R.backward(r, dC, skip_shs=True)
         r.ctx.color_grads_pack(slots.data_ptr())
         flat = r.splatGrads.flat
         dist.all_reduce(flat[:hv.geometry_floats])
-        allc = state.setdefault(("allc", id(r)), torch.empty(world * slots.numel(), dtype=torch.float32, device=slots.device))
         dist.all_gather_into_tensor(allc, slots.reshape(-1))
-        hv.sh_from_views(all_cams, allc)
+        r.ctx.sh_grads_from_views(cam_records, allc.data_ptr(), r.splatGrads.Δshs.data_ptr(), overwrite=True)
 
     def timed(r, steps, warmup):
         for _ in range(warmup):
@@ -211,6 +213,8 @@ def main():
         dist.broadcast(di, 0)
         dom = STAGES[int(di.item())]
     del ra
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
 
     # Pass B: THE timed region -- W warmup steps, then exactly K steps between barriers + synchronize.
