@@ -436,6 +436,8 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     }
     HIPCHK(c, hipEventSynchronize(c->ev_count));
     harvest_events(c, fast ? GS_STAGE_RANGES : -1);
+    if (c->pinned[0] == 0xFFFFFFFFu)
+        return fail(c, GS_ERR_UNSUPPORTED, "gs_bin: more than 2^32 - 2 tile instances (32-bit list offsets); reduce the scene or the image");
     c->n_inst = (int64_t)c->pinned[0];
     const size_t ni1 = c->n_inst ? (size_t)c->n_inst : 1;
     HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));

@@ -272,12 +272,15 @@ __global__ __launch_bounds__(SC_THREADS) void count_reduce_kernel(const uint16_t
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t *__restrict__ block_sums, int nb, uint32_t *__restrict__ total_out) {
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
+    __shared__ unsigned long long wide[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
+    unsigned long long t64 = 0;                          // the same total in 64 bits: offsets are 32-bit, so it must fit
     for (int base = 0; base < nb; base += 1024) {
         const int i = base + threadIdx.x;
         const uint32_t v = (i < nb) ? block_sums[i] : 0u;
+        t64 += v;
         const uint32_t incl = wave_incl_scan(v, lane);
         if (lane == 63) sm[w] = incl;
         __syncthreads();
@@ -289,7 +292,15 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t *__restr
         if (threadIdx.x == 1023) carry = c + woff + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = carry;
+#pragma unroll
+    for (int d = GS_WAVE / 2; d > 0; d >>= 1) t64 += __shfl_down(t64, d);
+    if (lane == 0) wide[w] = t64;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < 16; ++k) tot += wide[k];
+        *total_out = tot >= 0xFFFFFFFFull ? 0xFFFFFFFFu : carry;       // sentinel: too many tile instances (gs_bin refuses)
+    }
 }
 // pass 3: per-chunk exclusive scan with the chunk base.  Thread t owns SC_ITEMS consecutive
 // gaussians so the scan order is the list order.

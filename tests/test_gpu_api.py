@@ -199,3 +199,21 @@ def test_colour_factored_exchange_equals_plain_accumulation(oracle):
     got = out.cpu().numpy().astype(np.float64) - 1.0
     assert np.linalg.norm(got - want) <= 1e-5 * np.linalg.norm(want)
     ctx.close()
+
+
+def test_more_than_2_32_instances_is_refused_not_corrupted():
+    """140 k screen-filling gaussians on a 4K tile grid = 4.5e9 tile instances: the 32-bit list offsets cannot hold
+    that, gs_bin must say so (GS_ERR_UNSUPPORTED) instead of wrapping."""
+    from common import hip_context, scene_and_cameras
+    from gaussiansplat_amd import backend as B
+    n, W, H, deg = 140_000, 3840, 2160, 0
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 5)
+    sc["scales"] = np.full_like(sc["scales"], 3.0)
+    ctx = hip_context(sc, cam, T, P, W, H, deg)
+    ctx.preprocess()
+    with pytest.raises(B.GsError) as e:
+        ctx.bin()
+    assert e.value.code == -5 and "tile instances" in str(e.value)
+    with pytest.raises(B.GsError):
+        ctx.forward_host()                       # nothing to draw: the frame has no lists
+    ctx.close()
