@@ -217,3 +217,17 @@ def test_more_than_2_32_instances_is_refused_not_corrupted():
     with pytest.raises(B.GsError):
         ctx.forward_host()                       # nothing to draw: the frame has no lists
     ctx.close()
+
+
+def test_plain_c_host_without_python_or_torch(tmp_path):
+    """examples/render_c.c: the C ABI driven from a C program linked against /opt/rocm's HIP runtime only (what a Julia
+    ccall host sees): must build with gcc, run a few fwd+bwd frames and exit 0 with finite checksums."""
+    import os, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "render_c")
+    libdir = os.path.join(root, "gaussiansplat_amd", "lib")
+    subprocess.run([shutil.which("gcc") or "gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "render_c.c"),
+                    "-o", exe, "-L" + libdir, "-lgsplat_hip", "-lm", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([exe, "20000", "320", "208", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "render_c ok" in r.stdout and "instances=" in r.stdout
