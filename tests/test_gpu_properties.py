@@ -112,3 +112,26 @@ def test_c2_full_size_parity_against_oracle(oracle):
         a = got[k].reshape(-1).astype(np.float64); b = gref[k].reshape(-1)
         assert np.linalg.norm(a - b) <= 1e-3 * np.linalg.norm(b), k
     ctx.close()
+
+
+def test_c5_full_size_lists_bit_exact_against_oracle(oracle):
+    """BASELINE config C5 (5 M gaussians, 3840x2160, SH3): 507 M tile instances -- the maximum configuration.  Tile
+    ranges and sorted ids BIT-EXACT against the oracle's lists; forward deterministic."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = synthetic.CONFIGS["C5"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1234 + list(synthetic.CONFIGS).index("C5"))
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5)
+    ctx.preprocess(); ctx.bin()
+    pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, omp=True)
+    oranges, oids, okeys = O.bin_lists(pre["bbs"], pre["tps"], 1, 16, gx, gy)
+    del okeys
+    assert ctx.num_instances == len(oids) > 400_000_000
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), oranges)
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), oids)
+    del oids
+    img1, tr1 = ctx.forward_host()
+    img2, tr2 = ctx.forward_host()
+    assert img1.tobytes() == img2.tobytes() and tr1.tobytes() == tr2.tobytes() and np.isfinite(img1).all()
+    ctx.close()
