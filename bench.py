@@ -155,26 +155,20 @@ def main():
 
     def step(r):
         R.resetGrads(r)
-        tps = R.preprocess(r, cam)
-        R.compactIdxs(r, (16, 16), (gx, gy))
-        R.forward(r, tps, (16, 16), (gx, gy))
         if not factored:
+            tps = R.preprocess(r, cam)
+            R.compactIdxs(r, (16, 16), (gx, gy))
+            R.forward(r, tps, (16, 16), (gx, gy))
             R.backward(r, dC)
             if world > 1:
                 dist.all_reduce(r.splatGrads.flat)       # ONE flat RCCL all-reduce (59 N floats at SH3)
             return
-        # colour-factored exchange: same gradients, 11N floats all-reduced + 3N per view all-gathered
+        # colour-factored exchange: same gradients, 11N floats all-reduced + 3N per view all-gathered; the gather
+        # overlaps the per-gaussian backward (gaussiansplat_amd/distributed.py)
         if "_bench_hv" not in r.__dict__:                                   # (cycle r <-> hv: collected by gc below)
             r._bench_hv = D.HipViewRenderer(r)
             r._bench_allc = torch.empty(world * 3 * n, dtype=torch.float32, device="cuda")
-        hv, allc = r._bench_hv, r._bench_allc
-        slots = hv.color_slots(1)
-        R.backward(r, dC, skip_shs=True)
-        r.ctx.color_grads_pack(slots.data_ptr())
-        flat = r.splatGrads.flat
-        dist.all_reduce(flat[:hv.geometry_floats])
-        dist.all_gather_into_tensor(allc, slots.reshape(-1))
-        r.ctx.sh_grads_from_views(cam_records, allc.data_ptr(), r.splatGrads.Δshs.data_ptr(), overwrite=True)
+        D.factored_one_view_step(r._bench_hv, cam, dC, cam_records, r._bench_allc)
 
     def timed(r, steps, warmup):
         for _ in range(warmup):

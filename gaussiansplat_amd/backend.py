@@ -198,8 +198,9 @@ class Context:
     def forward_device(self, image_ptr: int = 0, trans_ptr: int = 0):
         self._chk(self.L.gs_forward(self.h, C.c_void_p(image_ptr), C.c_void_p(trans_ptr), GS_MEM_DEVICE))
 
-    def backward(self, dC_ptr_or_array, grads: GsGrads, overwrite: bool = False):
-        flags = 1 if overwrite else 0          # GS_BWD_OVERWRITE
+    def backward(self, dC_ptr_or_array, grads: GsGrads, overwrite: bool = False, phase: str = "all"):
+        """phase: "all", "composite" (GS_BWD_COMPOSITE_ONLY) or "params" (GS_BWD_PARAMS_ONLY)."""
+        flags = (1 if overwrite else 0) | {"all": 0, "composite": 2, "params": 4}[phase]          # GS_BWD_*
         if isinstance(dC_ptr_or_array, np.ndarray):
             a = np.ascontiguousarray(dC_ptr_or_array, np.float32)
             self._chk(self.L.gs_backward_ex(self.h, C.c_void_p(a.ctypes.data), GS_MEM_HOST, C.byref(grads), flags))

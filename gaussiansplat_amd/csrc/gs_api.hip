@@ -81,7 +81,7 @@ struct gs_ctx {
     const float *means = nullptr, *scales = nullptr, *quats = nullptr, *opac = nullptr, *shs = nullptr;
     DevBuf model[5];
     GsCamera cam{};
-    bool have_cam = false, did_pre = false, did_bin = false, did_fwd = false, did_bwd = false;
+    bool have_cam = false, did_pre = false, did_bin = false, did_fwd = false, did_bwd = false, did_bwd_composite = false;
     int gx = 0, gy = 0;
 
     DevBuf payload, depth_key, rect, pairs_a, pairs_b, perm, offsets, block_sums;
@@ -507,7 +507,7 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     if (image) HIPCHK(c, hipMemcpyAsync(image, c->image.p, sizeof(float) * 3 * px, kind, c->stream));
     if (transmittance) HIPCHK(c, hipMemcpyAsync(transmittance, c->trans.p, sizeof(float) * px, kind, c->stream));
     if (mem == GS_MEM_HOST && (image || transmittance)) HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->did_fwd = true; c->did_bwd = false;
+    c->did_fwd = true; c->did_bwd = false; c->did_bwd_composite = false;
     return GS_OK;
 }
 
@@ -516,12 +516,15 @@ int gs_backward(gs_ctx *c, const float *dC, int mem, const gs_grads *grads) { re
 int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, int flags) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_backward: gs_forward first");
-    if (!dC || !grads) return fail(c, GS_ERR_INVALID, "gs_backward: NULL argument");
+    const bool params_only = (flags & GS_BWD_PARAMS_ONLY) != 0, composite_only = (flags & GS_BWD_COMPOSITE_ONLY) != 0;
+    if (params_only && composite_only) return fail(c, GS_ERR_INVALID, "gs_backward: COMPOSITE_ONLY and PARAMS_ONLY exclude each other");
+    if (params_only && !c->did_bwd_composite) return fail(c, GS_ERR_INVALID, "gs_backward: GS_BWD_PARAMS_ONLY needs a GS_BWD_COMPOSITE_ONLY call on this frame");
+    if ((!dC && !params_only) || (!grads && !composite_only)) return fail(c, GS_ERR_INVALID, "gs_backward: NULL argument");
     if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(c, GS_ERR_INVALID, "gs_backward: bad mem");
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t px = (size_t)c->cam.W * c->cam.H, n1 = c->n ? (size_t)c->n : 1;
     const float *dC_dev = dC;
-    if (mem == GS_MEM_HOST) {
+    if (mem == GS_MEM_HOST && !params_only) {
         HIPCHK(c, c->stage_in.ensure(sizeof(float) * 3 * px));
         HIPCHK(c, hipMemcpyAsync(c->stage_in.p, dC, sizeof(float) * 3 * px, hipMemcpyHostToDevice, c->stream));
         dC_dev = c->stage_in.as<float>();
@@ -535,12 +538,20 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     a.dC = dC_dev; a.g2d = det ? nullptr : c->g2d.as<float>(); a.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
     a.walked = c->counters.as<unsigned long long>() + 2;
     a.variant = c->variant_bwd; a.cull = c->cfg.alpha_cull != 0;
-    c->last_dC = dC_dev;
-    HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
-    HIPCHK(c, hipMemsetAsync(a.walked, 0, 16, c->stream));
-    {
-        StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                       // the kernel alone (what rocprof reports for it)
-        HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
+    if (!params_only) {
+        c->last_dC = dC_dev;
+        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
+        HIPCHK(c, hipMemsetAsync(a.walked, 0, 16, c->stream));
+        {
+            StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                   // the kernel alone (what rocprof reports for it)
+            HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
+        }
+        c->did_bwd_composite = true;
+    }
+    if (composite_only) {
+        if (mem == GS_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->did_bwd = true;                                             // the 2-D gradient sums exist (gs_color_grads_pack, GS_ARR_GRAD2D)
+        return GS_OK;
     }
     if (c->kind == 1) {                                  // SplatGrads2D, splat.jl:28-34
         GsPreprocess2DBwdArgs b2{};

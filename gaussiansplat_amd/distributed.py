@@ -124,6 +124,36 @@ class HipViewRenderer:
         R_.ctx.sh_grads_from_views(view_records(cameras, W, H), drgb_all.contiguous().data_ptr(), R_.splatGrads.Δshs.data_ptr(), overwrite=True)
 
 
+def factored_one_view_step(hv: "HipViewRenderer", camera, dC, cam_records, gathered, group=None) -> None:
+    """The colour-factored step for ONE view per rank (the 8-GPU batch of BASELINE.json), with the all-gather of the
+    colour gradients started right after the composite adjoint so that it overlaps the per-gaussian chain:
+        preprocess, bin, forward, composite backward -> pack d rgb -> all_gather (async)
+        per-gaussian chain (no Δshs)                 -> all_reduce of the 11N geometry floats
+        wait for the gather                          -> Δshs from all views.
+    cam_records: view_records of ALL ranks' cameras in rank order (host, computed once); gathered: [world * 3N] float32
+    device buffer (allocated once).  Without a process group it degenerates to the single-view factored path."""
+    import torch.distributed as dist
+    from . import renderer as R
+    r = hv.r
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    tps = R.preprocess(r, camera)
+    R.compactIdxs(r)
+    R.forward(r, tps)
+    R.backward(r, dC, phase="composite")
+    slot = hv.color_slots(1)
+    r.ctx.color_grads_pack(slot.data_ptr())
+    work = dist.all_gather_into_tensor(gathered, slot.reshape(-1), group=group, async_op=True) if world > 1 else None
+    R.backward(r, dC, skip_shs=True, phase="params")
+    flat = r.splatGrads.flat
+    if world > 1:
+        dist.all_reduce(flat[:hv.geometry_floats], group=group)
+        work.wait()
+        src = gathered
+    else:
+        src = slot
+    r.ctx.sh_grads_from_views(cam_records, src.data_ptr(), r.splatGrads.Δshs.data_ptr(), overwrite=True)
+
+
 def view_records(cameras, W: int, H: int):
     """[nviews, 38] float32 {T16, P16, eye3, lookAt3} (column-major matrices, as gs_set_camera takes them)."""
     import numpy as np

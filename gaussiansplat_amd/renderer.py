@@ -321,7 +321,7 @@ def forward(renderer, tps=None, threads=(16, 16), blocks=None):
     renderer.ctx.forward_device(renderer.imageData.data_ptr(), renderer.transmittance.data_ptr())
 
 
-def backward(renderer, ΔC, skip_shs: bool = False):
+def backward(renderer, ΔC, skip_shs: bool = False, phase: str = "all"):
     """backward.jl:3-38: ΔC has the shape of imageData; accumulates into renderer.splatGrads.
     skip_shs (3-D renderer, colour-factored multi-GPU exchange): leave Δshs alone -- the caller rebuilds it from the
     per-view colour gradients (distributed.multi_view_step(sync="factored"))."""
@@ -334,8 +334,9 @@ def backward(renderer, ΔC, skip_shs: bool = False):
     grads = renderer._grads
     if skip_shs:
         grads = B.GsGrads(grads.d_means, grads.d_scales, grads.d_quats, grads.d_opacities, None)
-    renderer.ctx.backward(dC.data_ptr(), grads, overwrite=renderer._grads_lazy_zero)
-    renderer._grads_lazy_zero = False
+    renderer.ctx.backward(dC.data_ptr(), grads, overwrite=renderer._grads_lazy_zero, phase=phase)
+    if phase != "composite":
+        renderer._grads_lazy_zero = False
 
 
 def resetGrads(renderer_or_grads):

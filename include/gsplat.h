@@ -164,6 +164,11 @@ int gs_backward(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads);
  * the first backward after a reset, so the caller can skip the zero fill and this pass skips
  * the read of the old values (the result equals reset + accumulate). */
 #define GS_BWD_OVERWRITE 1
+/* Split backward, so a multi-GPU host can start exchanging the colour gradients while the per-gaussian chain still runs:
+ * GS_BWD_COMPOSITE_ONLY stops after the composite adjoint (the per-gaussian 2-D sums exist: gs_color_grads_pack,
+ * GS_ARR_GRAD2D; grads may be NULL); GS_BWD_PARAMS_ONLY runs only the chain from those sums to `grads` (dC may be NULL). */
+#define GS_BWD_COMPOSITE_ONLY 2
+#define GS_BWD_PARAMS_ONLY 4
 int gs_backward_ex(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads, int flags);
 
 /* resetGrads: zero the arrays of `grads` (DEVICE pointers) on the ctx stream. */

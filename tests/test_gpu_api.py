@@ -231,3 +231,36 @@ def test_plain_c_host_without_python_or_torch(tmp_path):
     r = subprocess.run([exe, "20000", "320", "208", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "render_c ok" in r.stdout and "instances=" in r.stdout
+
+
+def test_split_backward_and_overlapped_factored_step_equal_plain_backward(oracle):
+    """GS_BWD_COMPOSITE_ONLY + GS_BWD_PARAMS_ONLY == one gs_backward; distributed.factored_one_view_step (what bench.py
+    runs per rank for N > 1; without a process group here) == the plain step's flat gradient buffer."""
+    import torch
+    from gaussiansplat_amd import backend as B, distributed as D, renderer as R, synthetic
+    n, W, H, deg = 2500, 144, 96, 3
+    scene = synthetic.make_scene(n, W, H, deg, seed=71)
+    cam = synthetic.scene_camera(W, view=3)
+    dC = torch.as_tensor(synthetic.make_dC(W, H, 71)).cuda()
+    out = {}
+    for mode in ("plain", "split", "factored"):
+        r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, scene, t_min=1e-5, deterministic=True)
+        R.resetGrads(r)
+        if mode == "factored":
+            hv = D.HipViewRenderer(r)
+            gathered = torch.empty(3 * n, dtype=torch.float32, device="cuda")
+            D.factored_one_view_step(hv, cam, dC, D.view_records([cam], W, H), gathered)
+        else:
+            tps = R.preprocess(r, cam); R.compactIdxs(r); R.forward(r, tps)
+            if mode == "plain":
+                R.backward(r, dC)
+            else:
+                with pytest.raises(B.GsError):
+                    R.backward(r, dC, phase="params")            # needs the composite phase first
+                R.backward(r, dC, phase="composite")
+                R.backward(r, dC, phase="params")
+        torch.cuda.synchronize()
+        out[mode] = r.splatGrads.flat.cpu().numpy().astype(np.float64)
+    assert np.array_equal(out["plain"], out["split"])
+    assert np.array_equal(out["plain"][:11 * n], out["factored"][:11 * n])
+    assert np.linalg.norm(out["plain"][11 * n:] - out["factored"][11 * n:]) <= 2e-6 * np.linalg.norm(out["plain"][11 * n:])
