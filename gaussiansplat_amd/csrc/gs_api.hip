@@ -556,7 +556,7 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     if (c->kind == 1) {                                  // SplatGrads2D, splat.jl:28-34
         GsPreprocess2DBwdArgs b2{};
         b2.n = c->n; b2.W = c->cam.W; b2.H = c->cam.H;
-        b2.scales = c->scales; b2.rots = c->quats;
+        b2.scales = c->scales; b2.rots = c->quats; b2.opac = c->opac;
         b2.g2d = det ? nullptr : c->g2d.as<float>(); b2.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
         b2.overwrite = (flags & GS_BWD_OVERWRITE) ? 1 : 0;
         b2.d_means = grads->d_means; b2.d_scales = grads->d_scales; b2.d_rots = grads->d_quats;

@@ -59,7 +59,7 @@ struct GsPreprocess2DArgs {
 struct GsPreprocess2DBwdArgs {
     int64_t n;
     int W, H;
-    const float *scales, *rots;
+    const float *scales, *rots, *opac;
     const float *g2d;
     const long long *g2d_fixed;
     float *d_means, *d_scales, *d_rots, *d_opac, *d_colors;   // accumulate (+=) or overwrite; may be null

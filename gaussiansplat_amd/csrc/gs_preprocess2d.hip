@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_kernel(GsPreprocess2DArgs
             }
         }
     }
-    const float sg = a.opac[g];
+    // raw opacity (splat.jl:341) clamped to [0, 1): alpha must stay below 1 for the adjoint's 1/(1-alpha); NaN -> 0
+    const float sg = fminf(fmaxf(a.opac[g], 0.0f), 0.99999994f);
     const float cr = a.colors[3 * g], cg = a.colors[3 * g + 1], cb = a.colors[3 * g + 2];
     GsPayload p;
     const bool pay_ok = isfinite(cr) && isfinite(cg) && isfinite(cb) && isfinite(sg) && isfinite(mux) && isfinite(muy) &&
@@ -171,7 +172,9 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_bwd_kernel(GsPreprocess2D
         else { a.d_scales[2 * g] += ds[0]; a.d_scales[2 * g + 1] += ds[1]; }
     }
     if (a.d_rots) { if (OVERWRITE) a.d_rots[g] = dth; else a.d_rots[g] += dth; }
-    if (a.d_opac) { if (OVERWRITE) a.d_opac[g] = g2[3]; else a.d_opac[g] += g2[3]; }
+    const float op = a.opac[g];
+    const float dop = (op > 0.0f && op < 0.99999994f) ? g2[3] : 0.0f;       // the clamp of the forward has zero slope outside
+    if (a.d_opac) { if (OVERWRITE) a.d_opac[g] = dop; else a.d_opac[g] += dop; }
     if (a.d_colors) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { if (OVERWRITE) a.d_colors[3 * g + k] = g2[k]; else a.d_colors[3 * g + k] += g2[k]; }

@@ -119,8 +119,8 @@ int gs_set_model(gs_ctx *ctx, int64_t n, int sh_degree,
 
 /* The 2-D image-fitting renderer (RendererType GAUSSIAN_2D; renderer.jl:7-18, SplatData2D splat.jl:20-26): means 2xN
  * in [0,1]^2 (pixel position (W*mx, H*my), splat.jl:337-339), scales 2xN (log, cov2d.jl:14-17), rotations 1xN (theta,
- * cov2d.jl:5), opacities 1xN (used raw, splat.jl:341: alpha = opacity*exp(-dist/2); values >= 1 saturate just below 1,
- * values <= 0 contribute nothing), colors 3xN.  After this call gs_preprocess runs cov2d.jl:3-45 + boundingbox.jl on the
+ * cov2d.jl:5), opacities 1xN (used raw, splat.jl:341: alpha = opacity*exp(-dist/2), clamped to [0, 1 - 2^-24] so that a step
+ * of the optimiser cannot push alpha to 1 or below 0; the clamp has zero gradient outside), colors 3xN.  After this call gs_preprocess runs cov2d.jl:3-45 + boundingbox.jl on the
  * pixel position, gs_bin builds the lists in gaussian-index order (there is no depth), gs_forward / gs_backward use the
  * same composite kernels, and every gs_grads argument is read as SplatGrads2D (splat.jl:28-34):
  *   d_means 2xN, d_scales 2xN, d_quats -> d_rotations 1xN, d_opacities 1xN, d_shs -> d_colors 3xN.

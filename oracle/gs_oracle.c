@@ -384,7 +384,7 @@ void gso_preprocess2d(int64_t n, const float *means, const float *scales, const 
         if (invcov_o) { invcov_o[4 * g] = inv0; invcov_o[4 * g + 1] = inv1; invcov_o[4 * g + 2] = inv2; invcov_o[4 * g + 3] = inv3; }
         if (bbs_o) { bbs_o[4 * g] = bxmin; bbs_o[4 * g + 1] = bymin; bbs_o[4 * g + 2] = bxmax; bbs_o[4 * g + 3] = bymax; }
         if (rgb_o) { rgb_o[3 * g] = colors[3 * g]; rgb_o[3 * g + 1] = colors[3 * g + 1]; rgb_o[3 * g + 2] = colors[3 * g + 2]; }
-        if (sig_o) sig_o[g] = opacities[g];
+        if (sig_o) sig_o[g] = fminf(fmaxf(opacities[g], 0.0f), 0.99999994f);   /* raw opacity clamped to [0, 1): the spec */
     }
 }
 
@@ -873,7 +873,7 @@ void gso_backward2d(int64_t n, const float *means, const float *scales, const fl
         double det = cov[0][0] * cov[1][1] - cov[0][1] * cov[1][0];
         o->M[0] = cov[1][1] / det; o->M[1] = -cov[1][0] / det; o->M[2] = -cov[0][1] / det; o->M[3] = cov[0][0] / det;
         o->mu[0] = (double)W * means[2 * g]; o->mu[1] = (double)H * means[2 * g + 1];
-        o->sig = opacities[g];
+        o->sig = fminf(fmaxf(opacities[g], 0.0f), 0.99999994f);
         for (int k = 0; k < 3; ++k) o->rgb[k] = colors[3 * g + k];
     }
     double *g2d = (double *)calloc((size_t)(n > 0 ? n : 1) * 10, sizeof(double));
@@ -883,7 +883,7 @@ void gso_backward2d(int64_t n, const float *means, const float *scales, const fl
         const double *g2 = g2d + 10 * g, *gM = g2 + 6;
         const g64 *f = &F[g];
         for (int k = 0; k < 3; ++k) dcolors[3 * g + k] += g2[k];
-        dopac[g] += g2[3];
+        if (opacities[g] > 0.0f && opacities[g] < 0.99999994f) dopac[g] += g2[3];     /* clamp: zero slope outside */
         dmeans[2 * g] += (double)W * g2[4];
         dmeans[2 * g + 1] += (double)H * g2[5];
         /* M = cov^-1 => dcov = -M' gM M' */

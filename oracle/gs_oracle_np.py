@@ -294,7 +294,7 @@ def preprocess2d(means, scales, rots, opacities, colors, W, H):
         tps = np.zeros((n, 4), f32)                                           # no clip z: never skipped (near <= 0 <= far)
         return dict(mu=np.stack([mux, muy], 1), cov2d=np.stack([a0, a1, a2, a3], 1), invcov=inv.astype(f32),
                     bbs=np.stack([bxmin, bymin, bxmax, bymax], 1), rgb=np.ascontiguousarray(colors, f32).reshape(n, 3),
-                    sig=np.asarray(opacities, f32).reshape(-1), tps=tps)
+                    sig=np.fmin(np.fmax(np.asarray(opacities, f32).reshape(-1), f32(0)), f32(0.99999994)), tps=tps)   # C fmaxf/fminf: NaN -> 0
 
 
 # ----------------------------------------------------------------------------- order / binning

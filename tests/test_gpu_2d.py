@@ -44,6 +44,7 @@ def test_preprocess_and_lists_bit_exact(oracle, n, W, H, seed, shi, bin_path):
 def test_pixels_and_gradients(oracle, n, W, H, seed, shi, t_min, cull):
     O = oracle
     sc = synthetic.make_scene_2d(n, W, H, seed, scale_hi=shi)
+    sc["opacities"][:5] = np.array([-0.3, 0.0, 1.0, 1.7, np.nan], np.float32)                   # outside [0, 1): clamped, zero gradient
     ref = O.render2d(sc["means"], sc["scales"], sc["rots"], sc["opacities"], sc["colors"], W, H, t_min=t_min)
     dC = synthetic.make_dC(W, H, seed)
     gref = O.backward2d(sc["means"], sc["scales"], sc["rots"], sc["opacities"], sc["colors"], W, H, ref["ranges"], ref["ids"], dC, t_min=t_min)
@@ -57,6 +58,7 @@ def test_pixels_and_gradients(oracle, n, W, H, seed, shi, t_min, cull):
     got = ctx.grads_read_2d(g)
     for k in ("means", "scales", "rots", "opacities", "colors"):
         assert rel_l2(got[k].reshape(-1) / 2.0, gref[k].reshape(-1)) <= 1e-3, (k, rel_l2(got[k].reshape(-1) / 2.0, gref[k].reshape(-1)))
+    assert np.all(got["opacities"][:5] == 0.0)
     ctx.reset_grads(g)
     assert all(float(np.abs(v).max()) == 0.0 for v in ctx.grads_read_2d(g).values())
     ctx.close()

@@ -25,6 +25,7 @@ def test_sincos_spec_c_vs_numpy_and_accuracy(oracle):
 def test_c_vs_numpy_bit_exact_2d(oracle, n, W, H, seed):
     O = oracle
     sc = synthetic.make_scene_2d(n, W, H, seed)
+    sc["opacities"][:6] = np.array([-0.3, 0.0, 1.0, 1.7, np.nan, 0.99999994], np.float32)      # the clamp of the spec
     a = O.preprocess2d(sc["means"], sc["scales"], sc["rots"], sc["opacities"], sc["colors"], W, H)
     b = ONP.preprocess2d(sc["means"], sc["scales"], sc["rots"], sc["opacities"], sc["colors"], W, H)
     for k in ("mu", "cov2d", "invcov", "bbs", "rgb", "sig"):
@@ -36,6 +37,10 @@ def test_c_vs_numpy_bit_exact_2d(oracle, n, W, H, seed):
     img, tr = ONP.composite_forward(b, ranges_np, ids_np, -1.0, 1.0, W, H, 16, gx, gy)
     assert img.tobytes() == r["image"].tobytes() and tr.tobytes() == r["trans"].tobytes()
     assert float(r["trans"].min()) < 0.9            # the scene actually covers pixels
+    assert tuple(a["sig"][:6]) == (0.0, 0.0, np.float32(0.99999994), np.float32(0.99999994), 0.0, np.float32(0.99999994))
+    g = O.backward2d(sc["means"], sc["scales"], sc["rots"], sc["opacities"], sc["colors"], W, H, r["ranges"], r["ids"],
+                     synthetic.make_dC(W, H, seed))
+    assert np.all(g["opacities"][:5] == 0.0) and np.isfinite(g["opacities"]).all() and np.abs(g["opacities"][6:]).max() > 0
 
 
 def test_known_answer_axis_aligned(oracle):

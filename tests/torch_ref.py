@@ -72,7 +72,7 @@ def per_gaussian2d(means, scales, rots, opac, colors, W, H):
     Wm = torch.stack([torch.stack([c * e[:, 0], -s * e[:, 1]], 1), torch.stack([s * e[:, 0], c * e[:, 1]], 1)], 1)   # [n, 2, 2]
     cov = Wm @ Wm.transpose(1, 2) + 0.3 * torch.eye(2, dtype=torch.float64)
     M = torch.linalg.inv(cov)
-    return W * means[:, 0], H * means[:, 1], M, opac, colors
+    return W * means[:, 0], H * means[:, 1], M, torch.clamp(opac, 0.0, 0.99999994), colors
 
 
 def render2d(params, W, H, ranges, ids, bbs32, t_min=0.0):
