@@ -832,7 +832,16 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
                 if (n) HIPCHK(c, hipMemcpyAsync(dst, c->g2d.p, sizeof(float) * 10 * n, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
             }
-            for (size_t g = 0; g < n; ++g) o[10 * g + 8] = o[10 * g + 7];   // d inv[2] == d inv[1] (stored once)
+            // the device rows hold raw moments: apply the per-gaussian factors with the view's payload (sig, conic)
+            std::vector<GsPayload> pay(n ? n : 1);
+            if (n) HIPCHK(c, hipMemcpyAsync(pay.data(), c->payload.p, sizeof(GsPayload) * n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (size_t g = 0; g < n; ++g) {
+                float row[10];
+                for (int i = 0; i < 10; ++i) row[i] = o[10 * g + i];
+                gs_g2d_to_grads(row, pay[g].sig, pay[g].i0, 0.5f * (pay[g].i1 + pay[g].i2), pay[g].i3);
+                for (int i = 0; i < 10; ++i) o[10 * g + i] = row[i];
+            }
             return GS_OK;
         }
         default: return fail(c, GS_ERR_INVALID, "gs_get_array: unknown array");

@@ -148,6 +148,18 @@ hipError_t gs_launch_pack_drgb(const float *g2d, const long long *g2d_fixed, flo
 hipError_t gs_launch_sh_from_views(int64_t n, int sh_degree, const float *means, int nviews, const float *cams, const float *drgb,
                                    float *d_shs, int overwrite, hipStream_t s);
 
+// The composite backward accumulates, per gaussian, the colour gradient and the RAW moments of dd = dL/d(log alpha)
+// about the splat's 2-D mean: row = [dr dg db | S0 Sx Sy Sxx Sxy - Syy].  With the view's sig and conic M (column
+// major i0 i1 i2 i3, mc = (i1 + i2)/2):  dL/dsig = -S0/sig,  dL/dmu = -(i0 Sx + mc Sy, mc Sx + i3 Sy),
+// dL/dM = 1/2 [Sxx Sxy; Sxy Syy].  In place: row becomes [dr dg db dsig dmx dmy d00 d01 d10 d11].
+__host__ __device__ inline void gs_g2d_to_grads(float (&g2)[10], float sig, float i0, float mc, float i3) {
+    const float S0 = g2[3], Sx = g2[4], Sy = g2[5], Sxx = g2[6], Sxy = g2[7], Syy = g2[9];
+    g2[3] = sig > 0.0f ? -S0 / sig : 0.0f;
+    g2[4] = -(i0 * Sx + mc * Sy);
+    g2[5] = -(mc * Sx + i3 * Sy);
+    g2[6] = 0.5f * Sxx; g2[7] = 0.5f * Sxy; g2[8] = 0.5f * Sxy; g2[9] = 0.5f * Syy;
+}
+
 #define GS_FIXED_SCALE 1099511627776.0f            // 2^40
 #define GS_FIXED_INV (1.0 / 1099511627776.0)
 

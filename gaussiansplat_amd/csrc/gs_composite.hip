@@ -292,8 +292,10 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-// g2d row of a gaussian: [dr dg db dsig dmx dmy d00 d01 (d10 = d01, filled by the reader) d11].  Nine lanes of the
-// wave issue the one atomic: lane 16r+7 adds (dr, db, dg, dsig)[r], lane 16r+15 adds (dmx, d00, dmy, d01)[r], lane 62 d11.
+// g2d row of a gaussian: [dr dg db | S0 Sx Sy Sxx Sxy (unused) Syy] -- the colour gradient and the raw moments
+// S.. = sum over pixels of dd * {1, dX, dY, dX^2, dX dY, dY^2}, dd = d L / d(log alpha); gs_g2d_to_grads (gs_common.h)
+// turns them into d{sig, mu, conic} once per gaussian.  Nine lanes of the wave issue the one atomic: lane 16r+7 adds
+// (dr, db, dg, S0)[r], lane 16r+15 adds (Sx, Sxx, Sy, Sxy)[r], lane 62 Syy.
 __device__ __forceinline__ int out_component_tree(int lane) {
     const int row = lane >> 4, pos = lane & 15;
     if (pos == 7) return row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
@@ -310,7 +312,7 @@ __device__ __forceinline__ int out_component_tree(int lane) {
 // order independent, so the gradients are bitwise reproducible run to run); otherwise float atomics.
 template <bool EARLY, int MINW, bool DET, int RED, bool CULL>      // RED: 0 reduction tree on the LDS crossbar, 1 on lane swaps + DPP
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
-    __shared__ float4 sp[CB * 4];
+    __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
     __shared__ uint32_t sid[CB];
     const int ntiles = a.gx * a.gy;
@@ -370,22 +372,17 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
             const uint64_t m = __ballot(keep);
             slot = slot_of(m); nk = __popcll(m);
         } else keep = true;
-        {
-            const float sg = n0.z;
-            __syncthreads();
-            if (keep) {
-                sp[4 * slot] = q0; sp[4 * slot + 1] = q1; sp[4 * slot + 2] = q2;
-                // i0, mc, i3 and 1/sig (sig == 0: d opacity is 0 anyway)
-                sp[4 * slot + 3] = make_float4(n1.x, 0.5f * (n1.y + n1.z), n1.w, sg > 0.0f ? fast_rcp(sg) : 0.0f);
-                syhi[slot] = yhi_l;
-                sid[slot] = nid;                                         // gaussian id of the staged entry
-            }
-            __syncthreads();
+        __syncthreads();
+        if (keep) {
+            sp[3 * slot] = q0; sp[3 * slot + 1] = q1; sp[3 * slot + 2] = q2;
+            syhi[slot] = yhi_l;
+            sid[slot] = nid;                                             // gaussian id of the staged entry
         }
+        __syncthreads();
         pos = base + CB + lane;
         if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
         for (int k = 0; k < nk; ++k) {
-            const float4 q0k = sp[4 * k], q1k = sp[4 * k + 1], q2k = sp[4 * k + 2];
+            const float4 q0k = sp[3 * k], q1k = sp[3 * k + 1], q2k = sp[3 * k + 2];
             const float yhi = syhi[k];
             const float dX = fx - q0k.x;
             const float ex = dX - __builtin_amdgcn_fmed3f(dX, q0k.w, q1k.w);
@@ -418,22 +415,21 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
                 }
                 T[p] = T[p] - w;
             }
-            const float4 q3k = sp[4 * k + 3];                           // i0, mc, i3, 1/sig
+            // raw moments of dd = d L / d(log alpha) about the splat's mean; the factors that are constant per gaussian
+            // (1/sig, the conic, 1/2) are applied once per gaussian by the parameter kernels, not once per (tile, splat)
             const float qx = dX * q0s;
             float v[8];
-            v[0] = ar; v[1] = ag; v[2] = ab; v[3] = -(q3k.w * q0s);
-            v[4] = -fmaf(q3k.x, qx, q3k.y * q1s);
-            v[5] = -fmaf(q3k.y, qx, q3k.z * q1s);
-            v[6] = 0.5f * dX * qx;
-            v[7] = 0.5f * dX * q1s;
+            v[0] = ar; v[1] = ag; v[2] = ab; v[3] = q0s;
+            v[4] = qx; v[5] = q1s;
+            v[6] = dX * qx; v[7] = dX * q1s;
             float outv;
             if (RED == 0) {
                 const float d = reduce8_lds(v, lane, xaddr);
-                const float t9 = wave_sum_lds(0.5f * q2s, xaddr);
+                const float t9 = wave_sum_lds(q2s, xaddr);
                 outv = lane == 62 ? t9 : d;
             } else {
                 const float d = reduce8_swap(v);
-                const float t9 = wave_sum_to_lane63(0.5f * q2s);
+                const float t9 = wave_sum_to_lane63(q2s);
                 // lane 62 <- t9(63): row_shl:1 into row 3 / bank 3 only; lane 63 has no source and keeps d
                 outv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d), __float_as_int(t9), 0x101, 0x8, 0x8, false));
             }

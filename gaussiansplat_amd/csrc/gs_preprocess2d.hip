@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_bwd_kernel(GsPreprocess2D
 #pragma unroll
         for (int i = 0; i < 10; ++i) g2[i] = a.g2d[10 * g + i];
     }
-    g2[8] = g2[7];                                                     // d inv[0][1] = d inv[1][0] (written once)
     // forward pieces again (cheaper than storing them): Sigma = Wm Wm' + 0.3 I, M = Sigma^-1
     float sn, cs;
     gs_sincosf(a.rots[g], sn, cs);
@@ -135,6 +134,8 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_bwd_kernel(GsPreprocess2D
     const float c11 = Wm[1][0] * Wm[1][0] + Wm[1][1] * Wm[1][1] + 0.3f;
     const float idet = 1.0f / (c00 * c11 - c01 * c01);
     const float M[2][2] = {{c11 * idet, -c01 * idet}, {-c01 * idet, c00 * idet}};
+    const float op = a.opac[g];
+    gs_g2d_to_grads(g2, fminf(fmaxf(op, 0.0f), 0.99999994f), M[0][0], M[0][1], M[1][1]);      // raw moments -> d{sig, mu, conic}
     const float G[2][2] = {{g2[6], g2[8]}, {g2[7], g2[9]}};            // column-major inv4: [r + 2c]
     // dSigma = -M' G M'
     float t1[2][2], dcov[2][2];
@@ -172,7 +173,6 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_bwd_kernel(GsPreprocess2D
         else { a.d_scales[2 * g] += ds[0]; a.d_scales[2 * g + 1] += ds[1]; }
     }
     if (a.d_rots) { if (OVERWRITE) a.d_rots[g] = dth; else a.d_rots[g] += dth; }
-    const float op = a.opac[g];
     const float dop = (op > 0.0f && op < 0.99999994f) ? g2[3] : 0.0f;       // the clamp of the forward has zero slope outside
     if (a.d_opac) { if (OVERWRITE) a.d_opac[g] = dop; else a.d_opac[g] += dop; }
     if (a.d_colors) {

@@ -143,10 +143,7 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n) return;
     float g2[10];
-    load_g2(a, g, g2);
-    const float gsig = g2[3], gmx = g2[4], gmy = g2[5];
-    // G[r][c] = dL/dM[r][c]; the composite kernel stores the symmetric off-diagonal once (slot 7)
-    const float G[2][2] = {{g2[6], g2[7]}, {g2[7], g2[9]}};
+    load_g2(a, g, g2);                                  // colour gradient + raw moments (gs_common.h: gs_g2d_to_grads)
     const float *T = cam.T, *P = cam.P;
 
     // ---- forward recompute (same formulas as gs_preprocess.hip)
@@ -189,6 +186,11 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
         for (int j = 0; j < 2; ++j) cov[i][j] = ASg[i][0] * A[j][0] + ASg[i][1] * A[j][1] + ASg[i][2] * A[j][2] + 0.3f;
     const float idet = 1.0f / (cov[0][0] * cov[1][1] - cov[0][1] * cov[1][0]);
     const float M[2][2] = {{cov[1][1] * idet, -cov[0][1] * idet}, {-cov[1][0] * idet, cov[0][0] * idet}};
+    const float ez = __expf(a.opac[g]);
+    const float sg = ez / (1.0f + ez);
+    gs_g2d_to_grads(g2, sg, M[0][0], 0.5f * (M[0][1] + M[1][0]), M[1][1]);
+    const float gsig = g2[3], gmx = g2[4], gmy = g2[5];
+    const float G[2][2] = {{g2[6], g2[7]}, {g2[8], g2[9]}};           // G[r][c] = dL/dM[r][c]
 
     // ---- M = cov^-1  =>  dcov = -M^T G M^T
     float t1[2][2], dcov[2][2];
@@ -280,8 +282,6 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
         *q = o;
     }
     if (a.d_opac) {
-        const float ez = __expf(a.opac[g]);
-        const float sg = ez / (1.0f + ez);
         const float v = gsig * sg * (1.0f - sg);
         if (OVERWRITE) a.d_opac[g] = v; else a.d_opac[g] += v;
     }

