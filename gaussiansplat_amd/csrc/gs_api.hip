@@ -827,7 +827,7 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
                 std::vector<long long> fx(10 * (n ? n : 1));
                 if (n) HIPCHK(c, hipMemcpyAsync(fx.data(), c->g2d.p, sizeof(long long) * 10 * n, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
-                for (size_t i = 0; i < 10 * n; ++i) o[i] = (float)((double)fx[i] * GS_FIXED_INV);
+                for (size_t i = 0; i < 10 * n; ++i) o[i] = (float)((double)fx[i] * gs_fixed_inv((int)(i % 10)));
             } else {
                 if (n) HIPCHK(c, hipMemcpyAsync(dst, c->g2d.p, sizeof(float) * 10 * n, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));

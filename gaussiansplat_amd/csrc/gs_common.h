@@ -160,8 +160,14 @@ __host__ __device__ inline void gs_g2d_to_grads(float (&g2)[10], float sig, floa
     g2[6] = 0.5f * Sxx; g2[7] = 0.5f * Sxy; g2[8] = 0.5f * Sxy; g2[9] = 0.5f * Syy;
 }
 
+// deterministic mode: fixed-point scale of g2d component c.  2^-40 for the colour gradient and the moments of order
+// 0 and 1 (range +-8.4e6), 2^-28 for the second-order moments Sxx, Sxy, Syy (components 6, 7, 9): they carry dX^2 in
+// pixels^2 and would saturate at 8.4e6 for very large footprints; range +-3.4e10, resolution 3.7e-9.
 #define GS_FIXED_SCALE 1099511627776.0f            // 2^40
 #define GS_FIXED_INV (1.0 / 1099511627776.0)
+#define GS_FIXED_SCALE2 268435456.0f               // 2^28
+#define GS_FIXED_INV2 (1.0 / 268435456.0)
+__host__ __device__ inline double gs_fixed_inv(int comp) { return comp >= 6 ? GS_FIXED_INV2 : GS_FIXED_INV; }
 
 // loss + SGD (gs_loss.hip)
 hipError_t gs_loss_run(int W, int H, int C, const float *img, const float *gt, float *maps, double *acc, float *dC, float lam,

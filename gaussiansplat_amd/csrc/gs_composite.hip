@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
             if (ocomp >= 0) {                                            // row base in SGPRs, per-lane byte offset in one VGPR
                 if (DET) {
-                    const float sc = fminf(fmaxf(outv * GS_FIXED_SCALE, -9.0e18f), 9.0e18f);      // saturate, never wrap
+                    const float sc = fminf(fmaxf(outv * (ocomp >= 6 ? GS_FIXED_SCALE2 : GS_FIXED_SCALE), -9.0e18f), 9.0e18f);      // saturate, never wrap
                     char *rowp = reinterpret_cast<char *>(a.g2d_fixed) + (size_t)gid * 80;
                     atomicAdd(reinterpret_cast<unsigned long long *>(rowp + 2u * ooff), (unsigned long long)__float2ll_rn(sc));
                 } else {

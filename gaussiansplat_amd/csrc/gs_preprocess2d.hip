@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_bwd_kernel(GsPreprocess2D
     float g2[10];
     if (a.g2d_fixed) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) g2[i] = (float)((double)a.g2d_fixed[10 * g + i] * GS_FIXED_INV);
+        for (int i = 0; i < 10; ++i) g2[i] = (float)((double)a.g2d_fixed[10 * g + i] * gs_fixed_inv(i));
     } else {
 #pragma unroll
         for (int i = 0; i < 10; ++i) g2[i] = a.g2d[10 * g + i];

@@ -32,7 +32,7 @@ __constant__ float bC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 __device__ __forceinline__ void load_g2(const GsPreprocessBwdArgs &a, int64_t g, float (&o)[10]) {
     if (a.g2d_fixed) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) o[i] = (float)((double)a.g2d_fixed[10 * g + i] * GS_FIXED_INV);
+        for (int i = 0; i < 10; ++i) o[i] = (float)((double)a.g2d_fixed[10 * g + i] * gs_fixed_inv(i));
     } else {
 #pragma unroll
         for (int i = 0; i < 10; ++i) o[i] = a.g2d[10 * g + i];

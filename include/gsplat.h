@@ -70,8 +70,8 @@ typedef struct {
                                  its T < t_min.  0 = literal reference (splat.jl:224-261 has
                                  no early-out).  Default 1e-5 (pixel error <= t_min*max|rgb|) */
     int32_t deterministic;    /* 1: the per-(tile,splat) gradient sums are accumulated as 2^-40 fixed
-                                 point with integer atomics (order independent -> bitwise
-                                 reproducible run to run; absolute resolution 9e-13 per add);
+                                 point (2^-28 for the second-order moments) with integer atomics (order independent ->
+                                 bitwise reproducible run to run; absolute resolution 9e-13 / 3.7e-9 per add);
                                  0: float atomics (run-to-run differences in the last bits)    */
     int32_t export_debug;     /* 1: gs_preprocess also materialises the reference's scratch
                                  arrays (ts, tps, mu', cov3ds, cov2ds, invCov2ds, bbs) for
