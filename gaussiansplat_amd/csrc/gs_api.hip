@@ -404,10 +404,9 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
         HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 256));
         HIPCHK(c, gs_launch_depth_pairs(c->depth_key.as<uint32_t>(), c->pairs_a.as<uint64_t>(), c->n, c->stream));
         int in_b = 0;
+        perm = c->perm.as<uint32_t>();                  // the last pass writes the permutation itself (low word of the pairs)
         HIPCHK(c, gs_radix_sort_u64(c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, 32, 64, c->table.as<uint32_t>(),
-                                    c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0));
-        perm = c->perm.as<uint32_t>();
-        HIPCHK(c, gs_launch_unpack_perm(in_b ? c->pairs_b.as<uint64_t>() : c->pairs_a.as<uint64_t>(), perm, c->n, c->stream));
+                                    c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0, perm));
     }
     c->perm_ptr = perm;
     {

@@ -73,10 +73,11 @@ struct GsSortScratch {     // sized by gs_sort_scratch_bytes
     uint32_t *digit_total; // [256]
 };
 size_t gs_sort_table_entries(int64_t n_max);
-// Stable LSD radix sort of n 64-bit keys on bits [bit_lo, bit_hi); result ends in *out_is_b.
+// Stable LSD radix sort of n 64-bit keys on bits [bit_lo, bit_hi); result ends in *out_is_b.  final_low32 != null: the
+// last pass writes only the low 32 bits of every key (the id of a (key | id) pair) to final_low32, not the 64-bit keys.
 hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
                              uint32_t *block_hist, uint32_t *digit_total, int *result_in_b,
-                             hipStream_t stream, bool ballot_ranks = false);
+                             hipStream_t stream, bool ballot_ranks = false, uint32_t *final_low32 = nullptr);
 
 hipError_t gs_launch_depth_pairs(const uint32_t *depth_key, uint64_t *pairs, int64_t n, hipStream_t s);
 hipError_t gs_launch_unpack_perm(const uint64_t *pairs, uint32_t *perm, int64_t n, hipStream_t s);

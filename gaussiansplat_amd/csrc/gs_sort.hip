@@ -115,10 +115,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
 // the stable rank order is (wave, round, lane).  Ranks come from wave64 ballots (8 per round:
 // the set of lanes holding the same digit) and a per-wave running LDS counter; keys are then
 // placed digit-contiguously in LDS and written out in runs.
+// out32 != null (last pass of a (key | id) pair sort): only the low word -- the id -- is written, as 32 bits.
 template <bool ATOMIC_RANK>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                                                  int64_t n, int shift, uint32_t mask,
-                                                                 const uint32_t *__restrict__ block_hist, int nblocks) {
+                                                                 const uint32_t *__restrict__ block_hist, int nblocks,
+                                                                 uint32_t *__restrict__ out32) {
     __shared__ uint64_t skeys[RS_CHUNK];                 // 32 KiB
     __shared__ uint32_t wcnt[RS_WAVES][RS_RADIX];        // running count per (wave, digit)
     __shared__ uint32_t lpre[RS_RADIX];                  // exclusive prefix over digits in this chunk
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
         if (li < cnt) {
             const uint64_t k = skeys[li];
             const uint32_t dg = (uint32_t)(k >> shift) & mask;
-            out[(size_t)gbase[dg] + (uint32_t)(li - (int)lpre[dg])] = k;
+            const size_t o = (size_t)gbase[dg] + (uint32_t)(li - (int)lpre[dg]);
+            if (out32) out32[o] = (uint32_t)k; else out[o] = k;
         }
     }
 }
@@ -200,7 +203,8 @@ hipError_t gs_launch_radix_scan(uint32_t *block_hist, int nblocks, uint32_t *dig
 }
 
 hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
-                             uint32_t *block_hist, uint32_t *digit_total, int *result_in_b, hipStream_t stream, bool ballot_ranks) {
+                             uint32_t *block_hist, uint32_t *digit_total, int *result_in_b, hipStream_t stream, bool ballot_ranks,
+                             uint32_t *final_low32) {
     *result_in_b = 0;
     if (n <= 0) return hipSuccess;
     const int nblocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -215,8 +219,9 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
         hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, n, shift, mask, block_hist, nblocks);
         hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
-        if (ballot_ranks) hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks);
-        else hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks);
+        uint32_t *o32 = (final_low32 && shift + width >= bit_hi) ? final_low32 : nullptr;      // last pass: ids only
+        if (ballot_ranks) hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks, o32);
+        else hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks, o32);
         uint64_t *t = src; src = dst; dst = t;
         *result_in_b ^= 1;
     }
@@ -255,15 +260,17 @@ __device__ __forceinline__ uint32_t rect_area(const uint16_t *__restrict__ rect,
 }
 
 // pass 1: per-chunk totals
+// The gathered counts (rect[perm[idx]] is a random 8-byte read per gaussian) are parked in offsets[idx], so that pass 3
+// streams them back instead of gathering a second time.
 __global__ __launch_bounds__(SC_THREADS) void count_reduce_kernel(const uint16_t *__restrict__ rect, const uint32_t *__restrict__ perm,
-                                                                   int64_t n, uint32_t *__restrict__ block_sums) {
+                                                                   int64_t n, uint32_t *__restrict__ block_sums, uint32_t *__restrict__ counts) {
     __shared__ uint32_t sm[SC_THREADS / GS_WAVE];
     const int64_t base = (int64_t)blockIdx.x * SC_CHUNK;
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < SC_ITEMS; ++i) {
         const int64_t idx = base + (int64_t)i * SC_THREADS + threadIdx.x;
-        if (idx < n) s += rect_area(rect, perm ? (int64_t)perm[idx] : idx);
+        if (idx < n) { const uint32_t c = rect_area(rect, perm ? (int64_t)perm[idx] : idx); counts[idx] = c; s += c; }
     }
     s = block_reduce_u32(s, sm);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
@@ -304,8 +311,7 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t *__restr
 }
 // pass 3: per-chunk exclusive scan with the chunk base.  Thread t owns SC_ITEMS consecutive
 // gaussians so the scan order is the list order.
-__global__ __launch_bounds__(SC_THREADS) void count_scan_kernel(const uint16_t *__restrict__ rect, const uint32_t *__restrict__ perm,
-                                                                 int64_t n, const uint32_t *__restrict__ block_sums,
+__global__ __launch_bounds__(SC_THREADS) void count_scan_kernel(int64_t n, const uint32_t *__restrict__ block_sums,
                                                                  uint32_t *__restrict__ offsets) {
     __shared__ uint32_t sm[SC_THREADS / GS_WAVE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(SC_THREADS) void count_scan_kernel(const uint16_t *
 #pragma unroll
     for (int i = 0; i < SC_ITEMS; ++i) {
         const int64_t idx = base + i;
-        c[i] = (idx < n) ? rect_area(rect, perm ? (int64_t)perm[idx] : idx) : 0u;
+        c[i] = (idx < n) ? offsets[idx] : 0u;                            // the count parked by pass 1
         s += c[i];
     }
     const uint32_t incl = wave_incl_scan(s, lane);
@@ -334,9 +340,9 @@ hipError_t gs_launch_count_scan(const uint16_t *rect, const uint32_t *perm, uint
                                 int64_t n, hipStream_t s) {
     if (n <= 0) return hipMemsetAsync(offsets, 0, sizeof(uint32_t), s);
     const int nb = (int)((n + SC_CHUNK - 1) / SC_CHUNK);
-    hipLaunchKernelGGL(count_reduce_kernel, dim3(nb), dim3(SC_THREADS), 0, s, rect, perm, n, block_sums);
+    hipLaunchKernelGGL(count_reduce_kernel, dim3(nb), dim3(SC_THREADS), 0, s, rect, perm, n, block_sums, offsets);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, offsets + n);
-    hipLaunchKernelGGL(count_scan_kernel, dim3(nb), dim3(SC_THREADS), 0, s, rect, perm, n, block_sums, offsets);
+    hipLaunchKernelGGL(count_scan_kernel, dim3(nb), dim3(SC_THREADS), 0, s, n, block_sums, offsets);
     return hipGetLastError();
 }
 
