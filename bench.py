@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X Gaussian-splat hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched through torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 either arrives already launched (python -m torch.distributed.run ... bench.py --gpus N: WORLD_SIZE == N) or, from a
+bare shell, starts its N ranks itself as child processes of `python -m torch.distributed.run` BEFORE anything touches the
+GPU (never an exec of a process that initialised HIP) and exits with their return code.
 
 A step = one fwd+bwd pass of the hot path over one camera view of the synthetic scene:
 preprocess -> tile|depth keys + radix sort -> composite forward -> composite backward ->
-per-gaussian backward (+ ONE RCCL all-reduce of the flat gradient buffer when N > 1).
+per-gaussian backward (+ ONE RCCL all-reduce of the flat 59N-float gradient buffer when N > 1; the colour-factored
+exchange is timed beside it and reported under "factored_exchange").
 Weak scaling: every GPU renders its own view (one camera per GPU) of the replicated model.
 Inputs (model, dC) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
@@ -41,37 +46,63 @@ def algorithmic_bytes(stage: str, N: int, I: int, Iw_f: int, Iw_b: int, P: int, 
     }[stage]
 
 
-def _pmc_entry(kernel_stage: str, early: bool):
-    """The dominant kernel's entry in the newest committed rocprofv3 PMC summary (profiles/*pmc_summary.json, written by
-    tools/pmc_summary.py from separate --pmc passes of this same bench command: SQ/GRBM counters, FETCH_SIZE, WRITE_SIZE)."""
+def csrc_sha() -> str:
+    """Identity of the device code a profile was taken with: sha256 over gaussiansplat_amd/csrc/* and include/gsplat.h."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gaussiansplat_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "gsplat.h")]:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_entry(kernel_stage: str, early: bool, config: str):
+    """The dominant kernel's entry in a committed rocprofv3 PMC summary (profiles/*pmc_summary.json, written by
+    tools/pmc_summary.py from separate --pmc passes of this same bench command: SQ/GRBM counters, FETCH_SIZE, WRITE_SIZE)
+    -- only a summary stamped with THIS build's csrc_sha and this config counts; a stale profile gives None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as fh:
-        ks = json.load(fh)["kernels"]
-    for name, v in ks.items():
-        if kernel_stage in name and (("<true" in name) == early):
-            return v, os.path.relpath(files[-1], ROOT)
+    sha = csrc_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):
+        with open(f) as fh:
+            d = json.load(fh)
+        if d.get("csrc_sha") != sha or d.get("config", "C3") != config:
+            continue
+        for name, v in d["kernels"].items():
+            if kernel_stage in name and (("<true" in name) == early):
+                return v, os.path.relpath(f, ROOT)
     return None, None
 
 
-def measured_traffic(kernel_stage: str, config: str, t_min: float):
-    """HBM bytes per launch of the dominant kernel: FETCH_SIZE (doubled: the gfx950 correction of MI355X_MICROARCH.md)
-    + WRITE_SIZE, per launch.  None when the committed profile is not of this workload (C3, default t_min)."""
-    if config != "C3" or abs(t_min - 1e-5) > 1e-12:
-        return None
-    v, _ = _pmc_entry(kernel_stage, True)
-    return v.get("hbm_bytes_total") if v else None
+def measured_counters(kernel_stage: str, config: str, t_min: float, avg_ms: float):
+    """(traffic, valu) of the dominant kernel from the PMC summary of THIS build (else None, None).
+    traffic: HBM bytes per launch = FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE.
+    valu: the compute-side roofline -- SQ_INSTS_VALU wave-instructions per launch against the issue peak of 1024 SIMDs x
+    one wave64 VALU instruction per 2 cycles (v_fma_f32, MI355X_MICROARCH.md cycle constants)."""
+    if abs(t_min - 1e-5) > 1e-12 and t_min != 0.0:
+        return None, None
+    v, src = _pmc_entry(kernel_stage, t_min > 0, config)
+    if not v:
+        return None, None
+    valu = None
+    if "SQ_INSTS_VALU" in v and v.get("clock_GHz") and avg_ms > 0:
+        cyc = v["clock_GHz"] * 1e9 * avg_ms * 1e-3                   # kernel cycles at the clock measured under the counters
+        valu = {"valu_wave_insts": v["SQ_INSTS_VALU"], "clock_GHz": v["clock_GHz"],
+                "valu_issue_frac": v["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cyc),
+                "cycles_per_valu_inst_per_simd": 1024.0 * cyc / v["SQ_INSTS_VALU"],
+                "mean_waves_per_simd": v.get("mean_waves_per_simd"), "lds_insts": v.get("SQ_INSTS_LDS"), "source": src}
+    return v.get("hbm_bytes_total"), valu
 
 
-def measured_valu(kernel_stage: str, early: bool):
-    """VALU-pipe occupancy of the dominant kernel from the same summary: SQ_ACTIVE_INST_VALU (quad-cycles) * 4 /
-    (1024 SIMDs * kernel cycles)."""
-    v, src = _pmc_entry(kernel_stage, early)
-    if not v or "valu_busy_frac" not in v:
-        return None
-    return {"valu_busy_frac": v["valu_busy_frac"], "valu_wave_insts": v.get("SQ_INSTS_VALU"), "clock_GHz": v.get("clock_GHz"), "source": src}
+def launch_command(n: int, argv: list, port: int | None = None) -> list:
+    """The child command bench.py starts for --gpus N > 1 from a bare shell (one rank per GPU, rendezvous on 127.0.0.1)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
 
 
 def cpu_baseline(t_min: float, order: int):
@@ -100,20 +131,33 @@ def cpu_baseline(t_min: float, order: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--t-min", type=float, default=1e-5, help="transmittance early-out (0 = literal reference)")
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal (t_min=0) measurement")
-    ap.add_argument("--grad-sync", default="factored", choices=["factored", "allreduce"],
-                    help="N > 1: 'allreduce' = ONE all-reduce of the flat 59N-float gradient buffer; 'factored' (default) = the same "
-                         "gradients from an all-reduce of the 11N geometry floats + an all-gather of 3N colour-gradient floats per view "
-                         "(gaussiansplat_amd/distributed.py), 2.6x less xGMI traffic")
+    ap.add_argument("--grad-sync", default="allreduce", choices=["factored", "allreduce"],
+                    help="N > 1, the exchange of the headline number: 'allreduce' (default, the north_star collective) = ONE all-reduce "
+                         "of the flat 59N-float gradient buffer; 'factored' = the same gradients from an all-reduce of the 11N geometry "
+                         "floats + an all-gather of 3N colour-gradient floats per view (gaussiansplat_amd/distributed.py), 2.6x less "
+                         "xGMI traffic.  The other mode is timed as well and reported beside it.")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks as children of a fresh launcher process.  Nothing in THIS
+        # process has imported torch or touched HIP, and it is a child process, not an exec.
+        cmd = launch_command(args.gpus, sys.argv[1:])
+        if os.environ.get("GS_BENCH_DRY_LAUNCH") == "1":                # tests/test_host.py: show, do not start
+            print(json.dumps({"launch": cmd}))
+            return
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
@@ -149,13 +193,13 @@ def main():
                              profile_stages=profile_stages, alpha_cull=not args.no_cull)
 
     from gaussiansplat_amd import distributed as D
-    factored = world > 1 and args.grad_sync == "factored"
+    sync_mode = [args.grad_sync]                                                # the exchange `step` uses (N > 1)
     all_cams = [synthetic.scene_camera(W, view=int(os.environ.get("GS_BENCH_VIEW", k % 8))) for k in range(world)]   # rank k renders view k
     cam_records = D.view_records(all_cams, W, H)                                # host, once: the cameras of all ranks' views
 
     def step(r):
         R.resetGrads(r)
-        if not factored:
+        if not (world > 1 and sync_mode[0] == "factored"):
             tps = R.preprocess(r, cam)
             R.compactIdxs(r, (16, 16), (gx, gy))
             R.forward(r, tps, (16, 16), (gx, gy))
@@ -220,6 +264,18 @@ def main():
     wc = r.ctx.work_counters_ex()
     wf, wb = wc["walked_fwd"], wc["walked_bwd"]
     value = world * n * args.steps / dt / 1e6
+    nranks = dist.get_world_size() if world > 1 else 1
+    other = None
+    if world > 1:                                              # the other exchange, same renderer, same K steps, beside the headline
+        head = sync_mode[0]
+        sync_mode[0] = "factored" if head == "allreduce" else "allreduce"
+        dt_o = timed(r, args.steps, max(2, args.warmup // 2))
+        other = {"grad_sync": sync_mode[0], "value": world * n * args.steps / dt_o / 1e6, "unit": "Msplats/s",
+                 "ms_per_step": dt_o / args.steps * 1e3, "steps": args.steps,
+                 "note": "same gradients (tests/test_distributed_gloo.py, tests/test_gpu_api.py); factored = all-reduce of the 11N geometry "
+                         "floats + all-gather of 3N colour-gradient floats per view, rebuilt into the SH gradient locally"}
+        sync_mode[0] = head
+    factored = world > 1 and args.grad_sync == "factored"
 
     out = None
     if rank == 0:
@@ -233,18 +289,29 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {n} gaussians, {W}x{H}, SH{deg}, one camera view per GPU per step, fwd+bwd"
                                    + ((", RCCL all-reduce of 11N f32 + all-gather of 3N f32 per view (colour-factored)" if factored
-                                       else ", one RCCL all-reduce of 59N f32") if world > 1 else ""),
+                                       else ", one RCCL all-reduce of 59N f32") if world > 1 else "")
+                                   + "; synthetic scene of SURVEY 8d with the quaternions NORMALISED (8d leaves N(0,1)^4 raw: the reference "
+                                     "never normalises q and |q| scales every footprint by |q|^4; un-normalised q is parity-tested, "
+                                     "tests/test_gpu_sizes.py)",
+                       "nranks": nranks, "grad_sync": args.grad_sync if world > 1 else None, "backend": args.backend if world > 1 else None,
+                       "rank_mode": int(r.ctx.cfg.rank_mode),
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
                        "instances": I, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
                        "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "seed": seed},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_note": f"survey pass ({ka} steps, hipEvents around every stage, not the timed region)",
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(dom, args.config, args.t_min), "algorithmic_bytes": by, "avg_ms": dom_ms,
-                         "launches": dom_cnt, "valu": measured_valu(dom, args.t_min > 0),
-                         "note": "avg_ms: hipEvents around the kernel launch on the ctx stream, inside the timed region; the composite "
-                                 "kernels are VALU-bound (profiles/, DESIGN.md s5), the HBM fraction is reported as measured"},
+                         "traffic": None, "algorithmic_bytes": by, "avg_ms": dom_ms, "launches": dom_cnt, "valu": None,
+                         "csrc_sha": csrc_sha(),
+                         "note": "avg_ms: hipEvents around the kernel launch on the ctx stream, inside the timed region.  traffic (HBM "
+                                 "bytes per launch, FETCH_SIZE x2 + WRITE_SIZE) and valu (SQ_INSTS_VALU against the issue peak of 1024 "
+                                 "SIMDs x 1 wave64 instruction per 2 cycles) come from the rocprofv3 --pmc summary under profiles/ "
+                                 "stamped with this csrc_sha, else null.  The composite kernels are VALU-bound (DESIGN.md s5); the HBM "
+                                 "fraction is reported as measured"},
         }
+        out["roofline"]["traffic"], out["roofline"]["valu"] = measured_counters(dom, args.config, args.t_min, dom_ms)
+        if other:
+            out["factored_exchange" if other["grad_sync"] == "factored" else "allreduce_exchange"] = other
     if not args.no_literal and args.t_min > 0 and world == 1:      # extra measurements only at N = 1
         del r
         torch.cuda.empty_cache()

@@ -27,13 +27,15 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_synchronize", "gs_set_model", "gs_set_model_2d", "gs_set_image_size", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
-           "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite")
+           "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
+           "gs_debug_tile_clock", "gs_rank_probe_result")
 
 
 class GsConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("tile_size", C.c_int32), ("order", C.c_int32), ("t_min", C.c_float),
                 ("deterministic", C.c_int32), ("export_debug", C.c_int32), ("profile_stages", C.c_int32),
-                ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("alpha_cull", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("alpha_cull", C.c_int32), ("schedule", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class GsGrads(C.Structure):
@@ -102,6 +104,8 @@ def load():
     L.gs_sh_grads_from_views.argtypes = [vp, C.c_int32, vp, vp, vp, C.c_int]
     L.gs_get_work_counters_ex.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gs_debug_time_composite.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.gs_debug_tile_clock.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.gs_rank_probe_result.argtypes = [vp]
     _lib = L
     return L
 
@@ -117,9 +121,10 @@ class Context:
 
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
                  profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 0,
-                 alpha_cull: bool = True):
+                 alpha_cull: bool = True, schedule: int = 0):
         self.L = load()
         cfg = default_config()
+        cfg.schedule = int(schedule)
         cfg.order, cfg.t_min = int(order), float(t_min)
         cfg.export_debug, cfg.profile_stages, cfg.deterministic = int(export_debug), int(profile_stages), int(deterministic)
         cfg.bin_path, cfg.rank_mode, cfg.alpha_cull = int(bin_path), int(rank_mode), int(alpha_cull)
@@ -325,6 +330,18 @@ class Context:
         ms = C.c_float()
         self._chk(self.L.gs_debug_time_composite(self.h, which, variant, reps, C.byref(ms)))
         return float(ms.value)
+
+    def tile_clock(self, which: int, variant: int = 0) -> np.ndarray:
+        """[ntiles, 4] uint64 per tile {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, walked << 32 | evaluated} of one
+        composite launch (which: 0 forward, 1 backward)."""
+        ntiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        out = np.zeros((ntiles, 4), np.uint64)
+        self._chk(self.L.gs_debug_tile_clock(self.h, which, variant, C.c_void_p(out.ctypes.data)))
+        return out
+
+    @property
+    def rank_probe_result(self) -> int:
+        return int(self.L.gs_rank_probe_result(self.h))
 
     def stage_times(self) -> dict:
         ms = (C.c_float * len(STAGES))()

@@ -100,7 +100,11 @@ struct gs_ctx {
     bool ev_fresh[GS_STAGE_COUNT] = {};      // ... and not yet added to the accumulators
     double ev_sum[GS_STAGE_COUNT] = {};
     int64_t ev_cnt[GS_STAGE_COUNT] = {};
-    DevBuf counters;                         // 4 x u64: entries walked, evaluated by the forward; walked, evaluated by the backward
+    DevBuf counters;                         // 64 B: 4 x u64 entries walked, evaluated by the forward; walked, evaluated by the backward;
+                                             // u32 ticket counters of the forward (byte 32) and backward (byte 40) work queues
+    DevBuf tile_order_f, tile_order_b, tile_work, tile_clock;   // longest-first tile orders, per-tile evaluated entries, debug clocks
+    int waves_fwd = 0, waves_bwd = 0;        // resident waves of the persistent composite grids (occupancy x CUs)
+    int rank_probe = -1;                     // lane-order probe of the LDS atomic rank: -1 not run, 0 passed, 1 failed (ballots forced)
     DevBuf grads_flat;                       // gs_grads_alloc
     DevBuf dpc;                              // 4 x n scratch between the two backward kernels
     DevBuf loss_maps, loss_acc, loss_in[2], loss_dc, view_cams;
@@ -150,6 +154,31 @@ int bind_device(gs_ctx *c) {
     return GS_OK;
 }
 
+// Scheduling of a composite launch (gs_config.schedule): the ticket counter inside c->counters (zeroed by the caller's
+// memset of that buffer), the resident-wave grid and, for schedule 0, the longest-first tile order -- for the forward by
+// list length, for the backward by the forward's per-tile count of evaluated entries (its exact work).
+int composite_sched(gs_ctx *c, GsCompositeArgs &a, int which) {
+    const int ntiles = c->gx * c->gy;
+    HIPCHK(c, c->tile_work.ensure(sizeof(uint32_t) * (size_t)(ntiles ? ntiles : 1)));
+    if (which == 0) a.tile_work = c->tile_work.as<uint32_t>();
+    if (c->cfg.schedule == 1 || ntiles <= 0) return GS_OK;                  // one wave per tile, launch order
+    int &waves = which == 0 ? c->waves_fwd : c->waves_bwd;
+    if (waves == 0) {
+        waves = gs_composite_resident_waves(which, c->cfg.t_min > 0.0f, c->cfg.deterministic != 0, c->cfg.alpha_cull != 0);
+        if (waves <= 0) waves = 256 * 16;
+    }
+    a.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(c->counters.p) + (which == 0 ? 32 : 40));
+    a.grid_waves = waves;
+    if (c->cfg.schedule == 0) {
+        DevBuf &ord = which == 0 ? c->tile_order_f : c->tile_order_b;
+        HIPCHK(c, ord.ensure(sizeof(uint32_t) * (size_t)ntiles));
+        if (which == 0) HIPCHK(c, gs_launch_tile_order(c->ranges.as<uint32_t>(), 1, ntiles, ord.as<uint32_t>(), c->stream));
+        else HIPCHK(c, gs_launch_tile_order(c->tile_work.as<uint32_t>(), 0, ntiles, ord.as<uint32_t>(), c->stream));
+        a.tile_order = ord.as<uint32_t>();
+    }
+    return GS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -183,6 +212,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (c0.tile_size != GS_TILE) return fail(nullptr, GS_ERR_UNSUPPORTED, "gs_create: only tile_size 16 is supported (reference threads=(16,16))");
     if (c0.order < GS_ORDER_INDEX || c0.order > GS_ORDER_DEPTH_ASC) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad order");
     if (!(c0.t_min >= 0.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: t_min must be >= 0");
+    if (c0.schedule < 0 || c0.schedule > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad schedule");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -203,6 +233,14 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
         for (int k = 0; k < 2; ++k)
             if ((e = hipEventCreate(&c->ev[s][k])) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
     if ((e = hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
+    if (c->cfg.rank_mode == 0) {
+        // The one-instruction stable rank (ds_add_rtn pre-values in ascending lane order) is a measured property of
+        // gfx950's LDS, not an architectural guarantee: check it on THIS device before relying on it; ballots otherwise.
+        int bad = 0;
+        if ((e = gs_probe_lds_atomic_order(c->stream, &bad)) != hipSuccess) { (void)gs_destroy(c); return hipfail(nullptr, e, "gs_probe_lds_atomic_order"); }
+        c->rank_probe = bad ? 1 : 0;
+        if (bad) c->cfg.rank_mode = 1;
+    }
     *out = c;
     return GS_OK;
 }
@@ -215,6 +253,7 @@ int gs_destroy(gs_ctx *c) {
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
                       &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
+                      &c->tile_order_f, &c->tile_order_b, &c->tile_work, &c->tile_clock,
                       &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->model) b.release();
@@ -494,10 +533,11 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
-    HIPCHK(c, c->counters.ensure(32));
+    HIPCHK(c, c->counters.ensure(64));
     a.walked = c->counters.as<unsigned long long>();
     a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 32, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));          // work counters + both ticket counters
+    if (int rc = composite_sched(c, a, 0)) return rc;
     {
         StageTimer t(c, GS_STAGE_COMPOSITE_FWD);                       // the kernel alone
         HIPCHK(c, gs_launch_composite_fwd(a, c->stream));
@@ -540,7 +580,8 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     if (!params_only) {
         c->last_dC = dC_dev;
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
-        HIPCHK(c, hipMemsetAsync(a.walked, 0, 16, c->stream));
+        HIPCHK(c, hipMemsetAsync(a.walked, 0, 32, c->stream));              // the backward's work counters + the ticket counters
+        if (int rc = composite_sched(c, a, 1)) return rc;
         {
             StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                   // the kernel alone (what rocprof reports for it)
             HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
@@ -876,24 +917,42 @@ int gs_get_stage_stats(gs_ctx *c, double sum_ms[GS_STAGE_COUNT], int64_t count[G
     return GS_OK;
 }
 
+static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeArgs &a) {
+    a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
+    a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
+    a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
+    a.dC = c->last_dC; a.walked = nullptr;
+    a.g2d = c->cfg.deterministic ? nullptr : c->g2d.as<float>(); a.g2d_fixed = c->cfg.deterministic ? c->g2d.as<long long>() : nullptr;
+    a.variant = variant % 100; a.map_mode = (variant / 100) % 10;
+    a.cull = (c->cfg.alpha_cull != 0) != (variant >= 1000);                  // +1000: the other cull setting
+    // the queue + longest-first set-up regardless of gs_config.schedule: the variant's tens digit picks the scheduling
+    const int keep = c->cfg.schedule;
+    c->cfg.schedule = 0;
+    const int rc = composite_sched(c, a, which);
+    c->cfg.schedule = keep;
+    if (which == 0) a.tile_work = nullptr;                                   // keep the frame's per-tile work for the backward
+    return rc;
+}
+
 int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *mean_ms) {
     if (!c || !mean_ms || reps <= 0) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_debug_time_composite: gs_forward first");
     if (which == 1 && !c->did_bwd) return fail(c, GS_ERR_INVALID, "gs_debug_time_composite: gs_backward first");
     if (bind_device(c)) return GS_ERR_HIP;
     GsCompositeArgs a{};
-    a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
-    a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
-    a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
-    a.dC = c->last_dC; a.walked = nullptr;
-    a.g2d = c->cfg.deterministic ? nullptr : c->g2d.as<float>(); a.g2d_fixed = c->cfg.deterministic ? c->g2d.as<long long>() : nullptr; a.variant = variant % 100; a.map_mode = (variant / 100) % 10;
-    a.cull = (c->cfg.alpha_cull != 0) != (variant >= 1000);                  // +1000: the other cull setting
+    if (int rc = debug_composite_args(c, which, variant, a)) return rc;
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
-    HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));   // warm
+    // every launch is preceded by the 8-byte reset of its ticket counter, as in a real frame (where it rides on the
+    // memset of the work counters); the plain-launch variants pay it too, so the comparison stays fair
+    auto launch = [&]() -> hipError_t {
+        hipError_t e = hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 16, c->stream);
+        if (e != hipSuccess) return e;
+        return which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream);
+    };
+    HIPCHK(c, launch());   // warm
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    for (int i = 0; i < reps; ++i)
-        HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));
+    for (int i = 0; i < reps; ++i) HIPCHK(c, launch());
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipEventSynchronize(e1));
     float ms = 0.0f;
@@ -902,6 +961,28 @@ int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return GS_OK;
 }
+
+int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
+    if (!c || !out) return GS_ERR_INVALID;
+    if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_debug_tile_clock: gs_forward first");
+    if (which == 1 && !c->did_bwd) return fail(c, GS_ERR_INVALID, "gs_debug_tile_clock: gs_backward first");
+    if (bind_device(c)) return GS_ERR_HIP;
+    const size_t ntiles = (size_t)c->gx * c->gy;
+    GsCompositeArgs a{};
+    if (int rc = debug_composite_args(c, which, variant, a)) return rc;
+    HIPCHK(c, c->tile_clock.ensure(sizeof(uint64_t) * 4 * (ntiles ? ntiles : 1)));
+    HIPCHK(c, hipMemsetAsync(c->tile_clock.p, 0, sizeof(uint64_t) * 4 * ntiles, c->stream));
+    a.tile_clock = c->tile_clock.as<unsigned long long>();
+    for (int rep = 0; rep < 2; ++rep) {                                       // the second launch (warm) is the one kept
+        HIPCHK(c, hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 16, c->stream));
+        HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(out, c->tile_clock.p, sizeof(uint64_t) * 4 * ntiles, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int gs_rank_probe_result(const gs_ctx *c) { return c ? c->rank_probe : -1; }
 
 int gs_get_work_counters(gs_ctx *c, int64_t *walked_fwd, int64_t *walked_bwd) {
     if (!c) return GS_ERR_INVALID;

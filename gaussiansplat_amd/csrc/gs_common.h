@@ -79,6 +79,8 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
                              uint32_t *block_hist, uint32_t *digit_total, int *result_in_b,
                              hipStream_t stream, bool ballot_ranks = false, uint32_t *final_low32 = nullptr);
 
+// checks on the current device that one ds_add_rtn_u32 hands same-address lanes their pre-values in ascending lane order
+hipError_t gs_probe_lds_atomic_order(hipStream_t s, int *mismatches);
 hipError_t gs_launch_depth_pairs(const uint32_t *depth_key, uint64_t *pairs, int64_t n, hipStream_t s);
 hipError_t gs_launch_unpack_perm(const uint64_t *pairs, uint32_t *perm, int64_t n, hipStream_t s);
 // counts[s] = tiles of gaussian perm[s] (perm may be null = identity), then exclusive scan
@@ -111,6 +113,7 @@ struct GsBin2Args {
 };
 hipError_t gs_bin2_build_lists(const GsBin2Args &b, hipStream_t s);
 
+#define GS_G2D_STRIDE 10   // floats (or fixed-point words) per gaussian row of the composite backward's sums
 struct GsCompositeArgs {
     int W, H, gx, gy;
     float t_min;
@@ -121,14 +124,23 @@ struct GsCompositeArgs {
     float *trans;              // W*H
     // backward only
     const float *dC;           // W*H*3
-    float *g2d;                // 10 x n (atomic accumulate): drgb3 dsig dmu2 dinv4
-    long long *g2d_fixed;      // deterministic mode: the same sums as 2^-40 fixed point (integer atomics commute)
+    float *g2d;                // GS_G2D_STRIDE x n (atomic accumulate): drgb3 | S0 Sx Sy Sxx Sxy - Syy (raw moments, see below)
+    long long *g2d_fixed;      // deterministic mode: the same sums as fixed point (integer atomics commute)
     unsigned long long *walked; // [0] list entries walked (staged) by this launch, [1] entries evaluated per pixel
                                 // after the no-op cull (one atomic each per tile); may be null
     int cull;                  // 1: drop (tile, splat) entries that are provably no-ops while staging (gs_config.alpha_cull)
     int variant;               // kernel variant (A/B testing; 0 = default)
-    int map_mode;              // 0: XCD-banded tile order, 1: plain blockIdx order
+    int map_mode;              // block -> tile map of the non-queued launch (0 plain; 1, 2: XCD bands, A/B only)
+    // work queue (persistent waves pull tiles from an atomic ticket counter, longest first)
+    uint32_t *queue;           // ticket counter, zeroed before the launch; null: one wave per tile, blockIdx order
+    const uint32_t *tile_order; // ticket -> tile (tiles sorted by decreasing work estimate); null: identity
+    uint32_t *tile_work;       // forward: evaluated entries per tile (the backward's exact work measure); may be null
+    unsigned long long *tile_clock; // debug: per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated}
+    int grid_waves;            // waves to launch in queue mode
 };
+// tiles in decreasing order of work[] (a 256-bucket counting sort of work / max; one workgroup)
+hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s);
+int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body = 0);   // occupancy x CUs (body: A/B variant)
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);
 

@@ -14,16 +14,30 @@
 // splatGrads (splat.jl:271-396), which is not a valid adjoint of the 3-D forward:
 // it is the derived adjoint, walking the list in the SAME order with the suffix colour obtained
 // as D - prefix (D = C_final . dC), so T is recomputed exactly as in the forward and never divided
-// back; the nine per-splat sums are reduced by a reduce-scatter tree on the LDS crossbar and written
-// with one 9-lane atomic per (tile, splat).
+// back.
+//
+// Scheduling.  Tiles differ a lot in work (the early-out point, the share of no-op entries, ragged image edges), and a
+// wave lives as long as its tile: with one wave per tile in blockIdx order the last third of the kernel runs at a
+// fraction of the occupancy (profiles/: 3.6 of 6 waves per SIMD on average at C3).  So the kernels are persistent: a
+// grid of exactly the resident waves pulls tiles from an atomic ticket counter, heaviest tile first (tile_order: for
+// the backward the forward's per-tile count of evaluated entries, its exact work; for the forward the list length).
+// Every wave drains (ticket >= tiles ends the loop), no wave waits on another, so no residency assumption is made.
+//
+// Per-splat gradient sums (backward).  Nine sums over the tile's 256 pixels are needed per (tile, splat).  Each lane
+// first adds its four pixels, then the 64 x 9 partials are transposed through LDS: nine conflict-free ds_write_b32 rows
+// [component][lane], then lane (c, s) = (l >> 2, l & 3), l < 36, reads the sixteen partials of quarter s of component
+// c with four ds_read_b128 and adds them; two quad-permute DPP adds finish, and nine lanes issue ONE atomic
+// instruction covering the gaussian's row.  That is 17 adds per entry on the VALU -- the unit these kernels are bound
+// by -- against 7 select-select-add folds + 9 butterfly adds (37 instructions, 15 of them 4-cycle v_cndmask) for the
+// reduce-scatter tree on ds_swizzle/ds_bpermute it replaces (kept as variant 1), and its one LDS round trip is taken
+// off the critical path: the reads of entry k are consumed after the pixel arithmetic of entry k+1.
 //
 // While staging a 64-entry batch each lane also bounds the largest alpha its entry can reach on this
 // tile (rect_can_contribute); entries that are no-ops in fp32 are dropped and the batch is compacted in
-// LDS, so the per-pixel loops only see entries that matter (gs_config.alpha_cull; 44 % of the walked
+// LDS, so the per-pixel loops only see entries that matter (gs_config.alpha_cull; 56 % of the walked
 // entries at C3).  The lists themselves and the batch boundaries of the early-out rule are untouched.
 //
-// Both kernels are VALU bound (50 / 150 VALU wave-instructions per evaluated entry, VALU pipe ~90 % busy;
-// profiles/), not HBM bound; see DESIGN.md section 5 for the roofline accounting and the measured
+// Both kernels are VALU bound, not HBM bound; see DESIGN.md section 5 for the roofline accounting and the measured
 // instruction costs that shaped the inner loops.
 #include "gs_common.h"
 
@@ -36,10 +50,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float vgpr_const(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// Workgroup -> tile map.  Measured on MI355X at C3 (tools/abtest.py, variants +100/+200): the plain
-// order (neighbouring tiles run at the same time on DIFFERENT XCDs and share their splat payloads
-// through the Infinity Cache) is 5 % faster than giving each XCD a contiguous band of tiles or
-// whole tile rows -- L2 affinity buys less here than it costs in balance.  Speed only, never correctness.
+// Workgroup -> tile map of the non-queued launch (A/B only).  Measured on MI355X at C3 (tools/abtest.py): the plain
+// order is 5 % faster than giving each XCD a contiguous band of tiles or whole tile rows.  Speed only, never correctness.
 __device__ __forceinline__ int tile_of_block(int b, int ntiles, int gx, int mode) {
     if (mode == 0) return b;                       // plain order (default)
     if (mode == 2) {                               // tile rows dealt round-robin to the XCDs
@@ -50,7 +62,28 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles, int gx, int mode
     return (b & 7) * per + (b >> 3);
 }
 
-// ---------------------------------------------------------------- forward
+// Next tile of this wave: a ticket from the queue (persistent launch) or the block's own tile (first call only).
+__device__ __forceinline__ int next_tile(const GsCompositeArgs &a, int ntiles, bool first) {
+    if (a.queue) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(a.queue, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= (uint32_t)ntiles) return -1;
+        return a.tile_order ? (int)a.tile_order[t] : (int)t;
+    }
+    if (!first) return -1;
+    const int tile = tile_of_block(blockIdx.x, ntiles, a.gx, a.map_mode);
+    return tile < ntiles ? tile : -1;
+}
+
+__device__ __forceinline__ unsigned long long wave_hw_id() {
+    // HW_REG_HW_ID (4): wave, simd, cu, sh, se ids; HW_REG_XCC_ID (20): the XCD
+    const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
+    return (unsigned long long)hw | ((unsigned long long)xcc << 32);
+}
+
+// ---------------------------------------------------------------- staging
 // The pixel-box test is arithmetic: v_cmp / v_cndmask cost ~4 cycles each on
 // gfx950 (fma: 2), so the box is applied as an exponent penalty
 //     pw' = pw - BIG * |d - med3(d, lo, hi)|        (d = pixel - mu on that axis)
@@ -88,9 +121,9 @@ __device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2
     const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
     const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
     const bool empty = xmax < xmin || ymax < ymin;
-    // log2(sig), capped one ulp below 0 so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic is PSD); only
-    // matters when sigmoid(o) rounds to exactly 1.0f (o > 16.6): relative change 6e-8
-    const float l2s = fminf(__builtin_amdgcn_logf(n0.z), -8.6e-8f);
+    // log2(sig), capped three ulps below 0 so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic is PSD) even when
+    // v_exp_f32 returns a value one ulp high; only matters when sigmoid(o) > 1 - 1.8e-7 (o > 15.5): relative change 1.8e-7
+    const float l2s = fminf(__builtin_amdgcn_logf(n0.z), -2.6e-7f);
     // an empty box (near/far-culled splat) gets lo = hi = +BIG: every pixel is "outside"
     const float xlo = empty ? GS_BIG : ((float)xmin - n0.x) - 0.25f, xhi = empty ? GS_BIG : ((float)xmax - n0.x) + 0.25f;
     const float ylo = empty ? GS_BIG : ((float)ymin - n0.y) - 0.25f, yhi = empty ? GS_BIG : ((float)ymax - n0.y) + 0.25f;
@@ -112,21 +145,25 @@ __device__ __forceinline__ int slot_of(uint64_t m) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-template <bool EARLY, int UNROLL, int MINW, bool CULL>
-__global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
-    __shared__ float4 sp[CB * 3];
-    __shared__ float syhi[CB];
-    const int ntiles = a.gx * a.gy;
-    const int tile = tile_of_block(blockIdx.x, ntiles, a.gx, a.map_mode);
-    if (tile >= ntiles) return;
+// one staged entry as the per-pixel loops read it back from LDS (13 dwords, wave-uniform addresses: broadcasts)
+struct Entry { float4 q0, q1, q2; float yhi; };
+__device__ __forceinline__ Entry load_entry(const float4 *sp, const float *syhi, int k) {
+    Entry e;
+    e.q0 = sp[3 * k]; e.q1 = sp[3 * k + 1]; e.q2 = sp[3 * k + 2]; e.yhi = syhi[k];
+    return e;
+}
+
+// ---------------------------------------------------------------- forward
+template <bool EARLY, bool CULL>
+__device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
     const float fx = (float)px;
-    const float nbig = vgpr_const(-GS_BIG);
     const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
-
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);     // first pixel of the tile (1-based)
+    unsigned long long clk0 = 0;
+    if (a.tile_clock) clk0 = __builtin_amdgcn_s_memrealtime();
 
     float Cr[4], Cg[4], Cb[4], T[4], Tdead[4], fy[4];
     bool dead[4];
@@ -171,29 +208,31 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
         __syncthreads();
         pos = base + CB + lane;
         if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
-#pragma unroll UNROLL
+#pragma unroll 2
         for (int k = 0; k < nk; ++k) {
-            const float4 q0k = sp[3 * k], q1k = sp[3 * k + 1], q2k = sp[3 * k + 2];
-            const float yhi = syhi[k];
-            const float dX = fx - q0k.x;
-            const float ex = dX - __builtin_amdgcn_fmed3f(dX, q0k.w, q1k.w);          // 0 inside the box columns
-            const float A0 = fmaf(nbig, fabsf(ex), fmaf(q1k.x * dX, dX, q0k.z));  // k i0 dX^2 + log2 sig - penalty
-            const float B0 = q1k.y * dX;
+            const Entry e = load_entry(sp, syhi, k);
+            const float dX = fx - e.q0.x;
+            const float ex = dX - __builtin_amdgcn_fmed3f(dX, e.q0.w, e.q1.w);            // 0 inside the box columns
+            const float A0 = fmaf(nbig, fabsf(ex), fmaf(e.q1.x * dX, dX, e.q0.z));  // k i0 dX^2 + log2 sig - penalty
+            const float B0 = e.q1.y * dX;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const float dY = fy[p] - q0k.y;
-                const float ey = dY - __builtin_amdgcn_fmed3f(dY, q2k.w, yhi);
-                const float pw = fmaf(dY, fmaf(q1k.z, dY, B0), A0);
+                const float dY = fy[p] - e.q0.y;
+                const float ey = dY - __builtin_amdgcn_fmed3f(dY, e.q2.w, e.yhi);
+                const float pw = fmaf(dY, fmaf(e.q1.z, dY, B0), A0);
                 const float w = fast_exp2(fmaf(nbig, fabsf(ey), pw)) * T[p];
-                Cr[p] = fmaf(q2k.x, w, Cr[p]);
-                Cg[p] = fmaf(q2k.y, w, Cg[p]);
-                Cb[p] = fmaf(q2k.z, w, Cb[p]);
+                Cr[p] = fmaf(e.q2.x, w, Cr[p]);
+                Cg[p] = fmaf(e.q2.y, w, Cg[p]);
+                Cb[p] = fmaf(e.q2.z, w, Cb[p]);
                 T[p] = T[p] - w;
             }
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
     }
-    if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
+    if (lane == 0) {
+        if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
+        if (a.tile_work) a.tile_work[tile] = evaluated;
+    }
     if (px <= a.W) {
         const size_t plane = (size_t)a.W * a.H;
 #pragma unroll
@@ -206,26 +245,35 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
             }
         }
     }
+    if (a.tile_clock && lane == 0) {
+        unsigned long long *c = a.tile_clock + 4 * (size_t)tile;
+        c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
+        c[3] = ((unsigned long long)walked << 32) | evaluated;
+    }
+}
+
+template <bool EARLY, int MINW, bool CULL>
+__global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
+    __shared__ float4 sp[CB * 3];
+    __shared__ float syhi[CB];
+    const int ntiles = a.gx * a.gy;
+    const float nbig = vgpr_const(-GS_BIG);
+    for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
+        forward_tile<EARLY, CULL>(a, tile, sp, syhi, nbig);
+        __syncthreads();                                                // the next tile restages sp[]
+    }
 }
 
 // ---------------------------------------------------------------- wave64 reductions
-// Nine per-splat sums are needed per (tile, splat).  Eight go through a reduce-scatter tree over the six lane bits:
-// a fold pairs two registers, so one add sums BOTH across one lane bit and leaves value A in the lower lanes and
-// value B in the upper ones -- 4 + 2 + 1 folds bring eight registers down to one whose 8-lane groups each hold one
-// value, three butterfly steps finish inside the groups.  The ninth sum is a plain six-step butterfly.
-//
-// Every exchange runs on the LDS crossbar (ds_swizzle inside 32 lanes, ds_bpermute across the halves), because the
-// VALU is the unit these kernels are bound by: a fold costs it two selects and one add (10.7 cycles per wave64) and
-// a butterfly step one add (2.3), against 14.3 for a v_permlane32/16_swap fold and 4.9 for a DPP add (measured,
-// tools/valu_ubench2.hip, valu_ubench3.hip).  RED = 1 keeps the lane-swap / DPP form for re-measurement; at C3 the
-// LDS form is 6 % faster (tools/abtest.py).
-typedef unsigned int gs_u2 __attribute__((ext_vector_type(2)));
-
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
-    return v + __int_as_float(t);
-}
+// (a) the transposed reduction through LDS (default): see the header comment.  RS floats per component row: 64 lanes
+// + 4 of padding, so that the sixteen-float quarters read with ds_read_b128 by lanes (c, s) fall on distinct banks
+// (start bank (4 c + 16 s) mod 64 inside every 16-lane service group).
+#define RS 68
+#define RED_FLOATS (9 * RS)
+// (b) the reduce-scatter tree on the LDS crossbar (variant 1, kept for A/B): eight of the nine sums go through a tree over
+// the six lane bits -- a fold pairs two registers, so one add sums BOTH across one lane bit and leaves value A in the
+// lower lanes and value B in the upper ones; 4 + 2 + 1 folds bring eight registers down to one whose 8-lane groups each
+// hold one value, three butterfly steps finish inside the groups.  The ninth sum is a plain six-step butterfly.
 template <int PATTERN>
 __device__ __forceinline__ float swz_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN));
@@ -242,7 +290,7 @@ __device__ __forceinline__ float fold32_lds(float a, float b, bool upper, int xa
 }
 // every lane of the 8-lane group (16r .. 16r+7) ends with the wave total of (v0, v2, v1, v3)[r], of group
 // (16r+8 .. 16r+15) with that of (v4, v6, v5, v7)[r]
-__device__ __forceinline__ float reduce8_lds(const float (&v)[8], int lane, int xaddr) {
+__device__ __forceinline__ float reduce8_lds(const float (&v)[9], int lane, int xaddr) {
     const bool u32 = (lane & 32) != 0, u16 = (lane & 16) != 0, u8 = (lane & 8) != 0;
     const float b0 = fold32_lds(v[0], v[1], u32, xaddr), b1 = fold32_lds(v[2], v[3], u32, xaddr);
     const float b2 = fold32_lds(v[4], v[5], u32, xaddr), b3 = fold32_lds(v[6], v[7], u32, xaddr);
@@ -255,47 +303,7 @@ __device__ __forceinline__ float wave_sum_lds(float v, int xaddr) {
     v = swz_add<0x041F>(v); v = swz_add<0x081F>(v); v = swz_add<0x101F>(v); v = swz_add<0x201F>(v); v = swz_add<0x401F>(v);
     return v + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v)));
 }
-
-// The same tree on the VALU's own cross-lane paths: v_permlane32_swap / v_permlane16_swap folds, one bank-masked
-// DPP fold (lanes of a disabled bank keep their value), row_shr adds.  Totals land in lanes 16r+7 and 16r+15.
-__device__ __forceinline__ float fold32(float a, float b) {
-    const gs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ float fold16(float a, float b) {
-    const gs_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// Inline asm: the hazard recogniser does not see the DPP reads, hence the leading s_nop (VALU write -> DPP read).
-__device__ __forceinline__ float fold8(float a, float b) {
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-                 "v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3"
-                 : "+v"(b) : "v"(a));
-    return b;
-}
-__device__ __forceinline__ float reduce8_swap(const float (&v)[8]) {
-    const float b0 = fold32(v[0], v[1]), b1 = fold32(v[2], v[3]), b2 = fold32(v[4], v[5]), b3 = fold32(v[6], v[7]);
-    float d = fold8(fold16(b0, b1), fold16(b2, b3));
-    d = dpp_add<0x114, 0xF, 0xF>(d);      // row_shr:4
-    d = dpp_add<0x112, 0xF, 0xF>(d);      // row_shr:2
-    d = dpp_add<0x111, 0xF, 0xF>(d);      // row_shr:1
-    return d;
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add<0x111, 0xF, 0xF>(v);      // row_shr:1
-    v = dpp_add<0x112, 0xF, 0xF>(v);      // row_shr:2
-    v = dpp_add<0x114, 0xF, 0xF>(v);      // row_shr:4
-    v = dpp_add<0x118, 0xF, 0xF>(v);      // row_shr:8   -> lane 15 of each row = row sum
-    v = dpp_add<0x142, 0xA, 0xF>(v);      // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xC, 0xF>(v);      // row_bcast:31 into rows 2,3 -> lane 63 = total
-    return v;
-}
-
-// g2d row of a gaussian: [dr dg db | S0 Sx Sy Sxx Sxy (unused) Syy] -- the colour gradient and the raw moments
-// S.. = sum over pixels of dd * {1, dX, dY, dX^2, dX dY, dY^2}, dd = d L / d(log alpha); gs_g2d_to_grads (gs_common.h)
-// turns them into d{sig, mu, conic} once per gaussian.  Nine lanes of the wave issue the one atomic: lane 16r+7 adds
-// (dr, db, dg, S0)[r], lane 16r+15 adds (Sx, Sxx, Sy, Sxy)[r], lane 62 Syy.
+// tree variant: lane 16r+7 adds (v0, v2, v1, v3)[r], lane 16r+15 adds (v4, v6, v5, v7)[r], lane 62 v8 -> g2d columns
 __device__ __forceinline__ int out_component_tree(int lane) {
     const int row = lane >> 4, pos = lane & 15;
     if (pos == 7) return row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
@@ -304,32 +312,98 @@ __device__ __forceinline__ int out_component_tree(int lane) {
     return -1;
 }
 
+// g2d row of a gaussian: [dr dg db | S0 Sx Sy Sxx Sxy (unused) Syy] -- the colour gradient and the raw moments
+// S.. = sum over pixels of dd * {1, dX, dY, dX^2, dX dY, dY^2}, dd = d L / d(log alpha); gs_g2d_to_grads (gs_common.h)
+// turns them into d{sig, mu, conic} once per gaussian.
+template <bool DET>
+__device__ __forceinline__ void add_to_row(const GsCompositeArgs &a, uint32_t gid, int ocomp, float v) {
+    if (DET) {     // 2^-40 (2^-28 for the second moments) fixed point, saturating; integer atomics are order independent
+        const float sc = fminf(fmaxf(v * (ocomp >= 6 ? GS_FIXED_SCALE2 : GS_FIXED_SCALE), -9.0e18f), 9.0e18f);
+        char *rowp = reinterpret_cast<char *>(a.g2d_fixed) + (size_t)gid * (8 * GS_G2D_STRIDE);
+        atomicAdd(reinterpret_cast<unsigned long long *>(rowp + 8u * (uint32_t)ocomp), (unsigned long long)__float2ll_rn(sc));
+    } else {       // row base in SGPRs, per-lane byte offset in one VGPR
+        char *rowp = reinterpret_cast<char *>(a.g2d) + (size_t)gid * (4 * GS_G2D_STRIDE);
+        atomicAdd(reinterpret_cast<float *>(rowp + 4u * (uint32_t)ocomp), v);
+    }
+}
+
+// quad-permute DPP moves (no LDS round trip at the end of the chain)
+__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }
+
 // ---------------------------------------------------------------- backward
 // Same staging and arithmetic pixel-box penalty as the forward; per-batch freeze of saturated pixels
 // (T = S = 0 makes every later contribution exactly zero); alpha < 1 strictly (stage_record), so
 // 1/(1-alpha) needs no guard; d sig = -(1/sig) * sum(dd) needs no accumulator of its own.
-// DET: the per-(tile, splat) sums are added as 2^-40 fixed-point integers (64-bit integer atomics are
+// DET: the per-(tile, splat) sums are added as fixed-point integers (64-bit integer atomics are
 // order independent, so the gradients are bitwise reproducible run to run); otherwise float atomics.
-template <bool EARLY, int MINW, bool DET, int RED, bool CULL>      // RED: 0 reduction tree on the LDS crossbar, 1 on lane swaps + DPP
-__global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
-    __shared__ float4 sp[CB * 3];
-    __shared__ float syhi[CB];
-    __shared__ uint32_t sid[CB];
-    const int ntiles = a.gx * a.gy;
-    const int tile = tile_of_block(blockIdx.x, ntiles, a.gx, a.map_mode);
-    if (tile >= ntiles) return;
+
+// per-pixel arithmetic of one entry: updates T, S; returns the lane's nine partial sums
+// v = {dr, dg, db, S0, Sx, Sy, Sxx, Sxy, Syy}
+__device__ __forceinline__ void backward_entry(const Entry &e, const float fx, const float (&fy)[4], const float nbig,
+                                               const float (&dCr)[4], const float (&dCg)[4], const float (&dCb)[4],
+                                               float (&T)[4], float (&S)[4], float (&v)[9], bool &any) {
+    const float dX = fx - e.q0.x;
+    const float ex = dX - __builtin_amdgcn_fmed3f(dX, e.q0.w, e.q1.w);
+    const float A0 = fmaf(nbig, fabsf(ex), fmaf(e.q1.x * dX, dX, e.q0.z));
+    const float B0 = e.q1.y * dX;
+    float al[4], dY[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        dY[p] = fy[p] - e.q0.y;
+        const float ey = dY[p] - __builtin_amdgcn_fmed3f(dY[p], e.q2.w, e.yhi);
+        al[p] = fast_exp2(fmaf(nbig, fabsf(ey), fmaf(dY[p], fmaf(e.q1.z, dY[p], B0), A0)));
+    }
+    any = ((al[0] + al[1]) + (al[2] + al[3])) != 0.0f;
+    float ar, ag, ab, q0s, q1s, q2s;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float w = al[p] * T[p];
+        const float cdot = fmaf(e.q2.x, dCr[p], fmaf(e.q2.y, dCg[p], e.q2.z * dCb[p]));
+        S[p] = fmaf(-cdot, w, S[p]);
+        const float inv = fast_rcp(1.0f - al[p]);
+        const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));
+        const float dd = -(al[p] * dalpha);
+        const float ddy = dd * dY[p];
+        if (p == 0) {                                             // plain products: no fma against a zero
+            ar = w * dCr[0]; ag = w * dCg[0]; ab = w * dCb[0];
+            q0s = dd; q1s = ddy; q2s = ddy * dY[0];
+        } else {
+            ar = fmaf(w, dCr[p], ar); ag = fmaf(w, dCg[p], ag); ab = fmaf(w, dCb[p], ab);
+            q0s += dd; q1s += ddy; q2s = fmaf(ddy, dY[p], q2s);
+        }
+        T[p] = T[p] - w;
+    }
+    // raw moments of dd = d L / d(log alpha) about the splat's mean; the factors that are constant per gaussian
+    // (1/sig, the conic, 1/2) are applied once per gaussian by the parameter kernels, not once per (tile, splat)
+    const float qx = dX * q0s;
+    v[0] = ar; v[1] = ag; v[2] = ab; v[3] = q0s;
+    v[4] = qx; v[5] = q1s;
+    v[6] = dX * qx; v[7] = dX * q1s; v[8] = q2s;
+}
+
+// RED: 2 transposed LDS reduction, software pipelined (default); 1 reduce-scatter tree on ds_swizzle / ds_bpermute
+template <bool EARLY, bool DET, int RED, bool CULL>
+__device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, uint32_t *sid, float *red,
+                                              const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
     const float fx = (float)px;
-    const float nbig = vgpr_const(-GS_BIG);
     const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
     const size_t plane = (size_t)a.W * a.H;
-    const int ocomp = out_component_tree(lane);
-    const int xaddr = (lane ^ 32) << 2;                                  // ds_bpermute address of the partner lane
-    const uint32_t ooff = ocomp >= 0 ? 4u * (uint32_t)ocomp : 0u;        // byte offset inside the gaussian's g2d row
-
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);
+    unsigned long long clk0 = 0;
+    if (a.tile_clock) clk0 = __builtin_amdgcn_s_memrealtime();
+    // tree variant
+    const int ocomp_tree = out_component_tree(lane);
+    const int xaddr = (lane ^ 32) << 2;                                  // ds_bpermute address of the partner lane
+    // transposed variant: lane (c, s) = (rl >> 2, rl & 3) sums quarter s of component c; lanes >= 36 mirror lanes 0..27
+    // (same addresses: broadcasts, no bank conflicts), their sums are not used
+    const int rl = lane < 36 ? lane : lane - 36;
+    const float *rrow = red + (rl >> 2) * RS + (rl & 3) * 16;
+    float *wrow = red + lane;
+    const int ocomp_t = (lane < 36 && (lane & 3) == 0) ? ((lane >> 2) < 8 ? (lane >> 2) : 9) : -1;
 
     float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
     bool dead[4];
@@ -352,6 +426,17 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     uint32_t nid = 0;
     uint32_t pos = s0 + lane;
     if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+    // pipeline state of the transposed reduction: the sixteen partials read back for the previous entry
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+    uint32_t pend_gid = 0;
+    bool pend = false;
+    auto finish = [&]() {                                                // sums of the pending entry -> one atomic
+        float s = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
+        s += ((r2.x + r2.y) + (r2.z + r2.w)) + ((r3.x + r3.y) + (r3.z + r3.w));
+        s += dpp_xor1(s);
+        s += dpp_xor2(s);
+        if (ocomp_t >= 0) add_to_row<DET>(a, pend_gid, ocomp_t, s);
+    };
     for (uint32_t base = s0; base < s1; base += CB) {
         const int cnt = (int)min((uint32_t)CB, s1 - base);
         if (EARLY) {
@@ -381,109 +466,208 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
         __syncthreads();
         pos = base + CB + lane;
         if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
-        for (int k = 0; k < nk; ++k) {
-            const float4 q0k = sp[3 * k], q1k = sp[3 * k + 1], q2k = sp[3 * k + 2];
-            const float yhi = syhi[k];
-            const float dX = fx - q0k.x;
-            const float ex = dX - __builtin_amdgcn_fmed3f(dX, q0k.w, q1k.w);
-            const float A0 = fmaf(nbig, fabsf(ex), fmaf(q1k.x * dX, dX, q0k.z));
-            const float B0 = q1k.y * dX;
-            float al[4], dY[4];
+        if (RED == 2) {
+            // software pipeline: arithmetic of entry k | loads of entry k+1 | sums + atomic of entry k-1 (its sixteen
+            // partials were read back during the arithmetic) | partials of entry k -> LDS, read back transposed
+            // (two named entry sets alternate, so the loop carries no register copies)
+            auto step = [&](const Entry &cur, const uint32_t gcur, Entry &nxt, uint32_t &gnxt, const int k) {
+                float v[9];
+                bool any;
+                backward_entry(cur, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any);
+                const uint32_t gid_k = (uint32_t)__builtin_amdgcn_readfirstlane((int)gcur);
+                __builtin_amdgcn_sched_barrier(0);
+                nxt = load_entry(sp, syhi, k + 1);                       // slot nk <= CB exists (one spare slot), value unused
+                gnxt = sid[k + 1];
+                if (!CULL && __ballot(any) == 0ull) return;              // nobody in the tile touched it
+                if (pend) finish();
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                dY[p] = fy[p] - q0k.y;
-                const float ey = dY[p] - __builtin_amdgcn_fmed3f(dY[p], q2k.w, yhi);
-                al[p] = fast_exp2(fmaf(nbig, fabsf(ey), fmaf(dY[p], fmaf(q1k.z, dY[p], B0), A0)));
-            }
-            if (!CULL && __ballot(((al[0] + al[1]) + (al[2] + al[3])) != 0.0f) == 0ull) continue;   // nobody in the tile touched it
-            float ar, ag, ab, q0s, q1s, q2s;
+                for (int c = 0; c < 9; ++c) wrow[c * RS] = v[c];         // LDS serves one wave's accesses in order: these
+                const float4 *rr = reinterpret_cast<const float4 *>(rrow);   // stores precede the loads below, and follow
+                r0 = rr[0]; r1 = rr[1]; r2 = rr[2]; r3 = rr[3];          // the previous entry's loads
+                pend_gid = gid_k; pend = true;
+            };
+            Entry eA = load_entry(sp, syhi, 0), eB;
+            uint32_t gA = sid[0], gB;
+            int k = 0;
+            for (; k + 1 < nk; k += 2) { step(eA, gA, eB, gB, k); step(eB, gB, eA, gA, k + 1); }
+            if (k < nk) step(eA, gA, eB, gB, k);
+        } else if (RED == 3) {                                           // transposed reduction, summed in the same iteration
+            for (int k = 0; k < nk; ++k) {
+                const Entry e = load_entry(sp, syhi, k);
+                const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
+                float v[9];
+                bool any;
+                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any);
+                if (!CULL && __ballot(any) == 0ull) continue;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float w = al[p] * T[p];
-                const float cdot = fmaf(q2k.x, dCr[p], fmaf(q2k.y, dCg[p], q2k.z * dCb[p]));
-                S[p] = fmaf(-cdot, w, S[p]);
-                const float inv = fast_rcp(1.0f - al[p]);
-                const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));
-                const float dd = -(al[p] * dalpha);
-                const float ddy = dd * dY[p];
-                if (p == 0) {                                             // plain products: no fma against a zero
-                    ar = w * dCr[0]; ag = w * dCg[0]; ab = w * dCb[0];
-                    q0s = dd; q1s = ddy; q2s = ddy * dY[0];
-                } else {
-                    ar = fmaf(w, dCr[p], ar); ag = fmaf(w, dCg[p], ag); ab = fmaf(w, dCb[p], ab);
-                    q0s += dd; q1s += ddy; q2s = fmaf(ddy, dY[p], q2s);
-                }
-                T[p] = T[p] - w;
+                for (int c = 0; c < 9; ++c) wrow[c * RS] = v[c];
+                const float4 *rr = reinterpret_cast<const float4 *>(rrow);
+                r0 = rr[0]; r1 = rr[1]; r2 = rr[2]; r3 = rr[3];
+                pend_gid = gid;
+                finish();
             }
-            // raw moments of dd = d L / d(log alpha) about the splat's mean; the factors that are constant per gaussian
-            // (1/sig, the conic, 1/2) are applied once per gaussian by the parameter kernels, not once per (tile, splat)
-            const float qx = dX * q0s;
-            float v[8];
-            v[0] = ar; v[1] = ag; v[2] = ab; v[3] = q0s;
-            v[4] = qx; v[5] = q1s;
-            v[6] = dX * qx; v[7] = dX * q1s;
-            float outv;
-            if (RED == 0) {
+        } else {
+            for (int k = 0; k < nk; ++k) {
+                const Entry e = load_entry(sp, syhi, k);
+                const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
+                float v[9];
+                bool any;
+                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any);
+                if (!CULL && __ballot(any) == 0ull) continue;            // nobody in the tile touched it
                 const float d = reduce8_lds(v, lane, xaddr);
-                const float t9 = wave_sum_lds(q2s, xaddr);
-                outv = lane == 62 ? t9 : d;
-            } else {
-                const float d = reduce8_swap(v);
-                const float t9 = wave_sum_to_lane63(q2s);
-                // lane 62 <- t9(63): row_shl:1 into row 3 / bank 3 only; lane 63 has no source and keeps d
-                outv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d), __float_as_int(t9), 0x101, 0x8, 0x8, false));
-            }
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
-            if (ocomp >= 0) {                                            // row base in SGPRs, per-lane byte offset in one VGPR
-                if (DET) {
-                    const float sc = fminf(fmaxf(outv * (ocomp >= 6 ? GS_FIXED_SCALE2 : GS_FIXED_SCALE), -9.0e18f), 9.0e18f);      // saturate, never wrap
-                    char *rowp = reinterpret_cast<char *>(a.g2d_fixed) + (size_t)gid * 80;
-                    atomicAdd(reinterpret_cast<unsigned long long *>(rowp + 2u * ooff), (unsigned long long)__float2ll_rn(sc));
-                } else {
-                    char *rowp = reinterpret_cast<char *>(a.g2d) + (size_t)gid * 40;
-                    atomicAdd(reinterpret_cast<float *>(rowp + ooff), outv);
-                }
+                const float t9 = wave_sum_lds(v[8], xaddr);
+                if (ocomp_tree >= 0) add_to_row<DET>(a, gid, ocomp_tree, lane == 62 ? t9 : d);
             }
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
     }
+    if (RED == 2 && pend) finish();
     if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
+    if (a.tile_clock && lane == 0) {
+        unsigned long long *c = a.tile_clock + 4 * (size_t)tile;
+        c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
+        c[3] = ((unsigned long long)walked << 32) | evaluated;
+    }
 }
 
+template <bool EARLY, int MINW, bool DET, int RED, bool CULL>
+__global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
+    __shared__ float4 sp[(CB + 1) * 3];                                  // one spare slot: the pipelined loop loads entry k+1
+    __shared__ float syhi[CB + 1];
+    __shared__ uint32_t sid[CB + 1];
+    __shared__ __attribute__((aligned(16))) float red[RED >= 2 ? RED_FLOATS : 4];
+    const int ntiles = a.gx * a.gy;
+    const float nbig = vgpr_const(-GS_BIG);
+    for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
+        backward_tile<EARLY, DET, RED, CULL>(a, tile, sp, syhi, sid, red, nbig);
+        __syncthreads();
+    }
+}
 
-// Launch configurations were chosen by A/B timing on MI355X at C3 (tools/abtest.py):
-// forward <unroll 2, 8 waves/SIMD> for literal lists, <unroll 2, unconstrained> with early-out;
-// backward <8 waves/SIMD> literal, <unconstrained> with early-out.  `variant` selects the other
-// instantiations for re-measurement.
-hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s) {
+// ---------------------------------------------------------------- tile order (longest first)
+// One workgroup: work[t] (or the list length ranges[2t+1] - ranges[2t]) -> 256 buckets of work / max, counted from the
+// heaviest bucket down; tiles inside a bucket keep no particular order (a speed hint only, never correctness).
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles,
+                                                           uint32_t *__restrict__ order) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wmax;
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) wmax = 1;
+    __syncthreads();
+    auto work = [&](int t) -> uint32_t { return ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t]; };
+    uint32_t m = 0;
+    for (int t = tid; t < ntiles; t += 1024) m = max(m, work(t));
+    atomicMax(&wmax, m);
+    __syncthreads();
+    const float scale = 255.0f / (float)wmax;
+    for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[255 - (int)((float)work(t) * scale)], 1u);     // bucket 0 = heaviest
+    __syncthreads();
+    if (tid < 64) {                                                      // exclusive scan of 256 counters by one wave
+        uint32_t c[4], s = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c[i] = hist[4 * tid + i]; s += c[i]; }
+        uint32_t incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (tid >= d) incl += u; }
+        uint32_t run = incl - s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { hist[4 * tid + i] = run; run += c[i]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += 1024) order[atomicAdd(&hist[255 - (int)((float)work(t) * scale)], 1u)] = (uint32_t)t;
+}
+
+hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s) {
+    if (ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, work_or_ranges, ranges_mode, ntiles, order);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- launchers
+// variant (A/B, tools/abtest.py; 0 = default): units digit = kernel body (backward: 2 transposed LDS reduction, software pipelined;
+// 3 the same, summed in the iteration; 1 reduce-scatter tree; forward: 1), tens digit = scheduling (0 as the caller set it up: queue + order when given; 1 one wave per tile in
+// blockIdx order; 2 queue in tile order, no longest-first).
+static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {
+    if (a.queue) return dim3((unsigned)max(1, min(a.grid_waves > 0 ? a.grid_waves : ntiles, ntiles)));
+    return dim3(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8);
+}
+
+static GsCompositeArgs apply_sched_variant(const GsCompositeArgs &a0) {
+    GsCompositeArgs a = a0;
+    const int sched = (a.variant / 10) % 10;
+    if (sched == 1) { a.queue = nullptr; a.tile_order = nullptr; }
+    else if (sched == 2) a.tile_order = nullptr;
+    return a;
+}
+
+hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
+    const GsCompositeArgs a = apply_sched_variant(a0);
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
-    const dim3 grid(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8), block(64);
+    const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
-    const int v = a.variant == 0 ? (early ? 1 : 2) : a.variant;
-#define GS_F(E, U, M) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, U, M, true>), grid, block, 0, s, a); \
-                           else hipLaunchKernelGGL((composite_fwd_kernel<E, U, M, false>), grid, block, 0, s, a); } while (0)
-    if (v == 1) { if (early) GS_F(true, 2, 1); else GS_F(false, 2, 1); }
-    else if (v == 2) { if (early) GS_F(true, 2, 8); else GS_F(false, 2, 8); }
-    else { if (early) GS_F(true, 1, 8); else GS_F(false, 1, 8); }
+#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 1, true>), grid, block, 0, s, a); \
+                     else hipLaunchKernelGGL((composite_fwd_kernel<E, 1, false>), grid, block, 0, s, a); } while (0)
+    if (early) GS_F(true); else GS_F(false);
 #undef GS_F
     return hipGetLastError();
 }
 
-hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s) {
+hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
+    GsCompositeArgs a = apply_sched_variant(a0);
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
-    const dim3 grid(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8), block(64);
     const bool early = a.t_min > 0.0f;
-    const int v = a.variant == 0 ? 1 : a.variant;      // measured best: LDS-crossbar reduction, registers unconstrained
+    if (a.queue && a.variant % 10 != 0 && a.variant % 10 != 2) {           // A/B body: its own resident-wave count
+        const int w = gs_composite_resident_waves(1, early, a.g2d_fixed != nullptr, a.cull != 0, a.variant % 10);
+        if (w > 0) a.grid_waves = w;
+    }
+    const dim3 grid = composite_grid(a, ntiles), block(64);
+    const int body = (a.variant % 10 == 1 || a.variant % 10 == 3) ? a.variant % 10 : 2;
 #define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, 0, s, a); \
                                else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, 0, s, a); } while (0)
 #define GS_B(E, M, Z) do { if (a.g2d_fixed) GS_B2(E, M, true, Z); else GS_B2(E, M, false, Z); } while (0)
-    if (v == 1) { if (early) GS_B(true, 1, 0); else GS_B(false, 1, 0); }
-    else if (v == 2) { if (early) GS_B(true, 8, 0); else GS_B(false, 8, 0); }
-    else if (v == 3) { if (early) GS_B(true, 1, 1); else GS_B(false, 1, 1); }
-    else { if (early) GS_B(true, 8, 1); else GS_B(false, 8, 1); }
+    // body 2 (default) holds the sixteen partials of the previous entry across the pixel arithmetic: 96 VGPRs, 5 waves/SIMD
+    if (body == 2) { if (early) GS_B(true, 5, 2); else GS_B(false, 5, 2); }
+    else if (body == 3) { if (early) GS_B(true, 1, 3); else GS_B(false, 1, 3); }
+    else { if (early) GS_B(true, 1, 1); else GS_B(false, 1, 1); }
 #undef GS_B
 #undef GS_B2
     return hipGetLastError();
+}
+
+// Resident waves of a kernel on this device: occupancy (waves of 64 per CU) x CUs.  The persistent grid is exactly this
+// size, so every launched wave is resident from the start and the queue is the only scheduler.  body: 0 = default.
+typedef void (*CompositeKernel)(GsCompositeArgs);
+template <bool E, bool D, bool C>
+static CompositeKernel bwd_kernel_of(int body) {
+    if (body == 1) return composite_bwd_kernel<E, 1, D, 1, C>;
+    if (body == 3) return composite_bwd_kernel<E, 1, D, 3, C>;
+    return composite_bwd_kernel<E, 5, D, 2, C>;
+}
+int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    CompositeKernel f = nullptr;
+    if (which == 0) {
+        f = early ? (cull ? composite_fwd_kernel<true, 1, true> : composite_fwd_kernel<true, 1, false>)
+                  : (cull ? composite_fwd_kernel<false, 1, true> : composite_fwd_kernel<false, 1, false>);
+    } else {
+        const int k = (early ? 4 : 0) | (det ? 2 : 0) | (cull ? 1 : 0);
+        switch (k) {
+            case 0: f = bwd_kernel_of<false, false, false>(body); break;
+            case 1: f = bwd_kernel_of<false, false, true>(body); break;
+            case 2: f = bwd_kernel_of<false, true, false>(body); break;
+            case 3: f = bwd_kernel_of<false, true, true>(body); break;
+            case 4: f = bwd_kernel_of<true, false, false>(body); break;
+            case 5: f = bwd_kernel_of<true, false, true>(body); break;
+            case 6: f = bwd_kernel_of<true, true, false>(body); break;
+            default: f = bwd_kernel_of<true, true, true>(body); break;
+        }
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(f), 64, 0) != hipSuccess || per_cu <= 0) return 0;
+    return per_cu * cus;
 }

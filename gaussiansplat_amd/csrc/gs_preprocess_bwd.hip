@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
     if (g < a.n) {
         float g2[10];
         load_g2(a, g, g2);
+        // a gaussian no pixel touched (off screen, or skipped by the composite because its per-view payload is not finite:
+        // tz == 0, exp(scale) overflow, singular covariance) has an all-zero row: its gradient is exactly zero, and the
+        // recomputed direction may be NaN, so zeros are substituted for the basis instead of forming 0 * NaN
+        const bool live = g2[0] != 0.0f || g2[1] != 0.0f || g2[2] != 0.0f;
         const float grgb[3] = {g2[0], g2[1], g2[2]};
         const float *T = cam.T, *P = cam.P;
         const float m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
@@ -78,8 +82,8 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
         const float v0 = p[0] - (cam.lookAt[0] - cam.eye[0]);
         const float v1 = p[1] - (cam.lookAt[1] - cam.eye[1]);
         const float v2 = p[2] - (cam.lookAt[2] - cam.eye[2]);
-        const float inrm = rsqrtf(v0 * v0 + v1 * v1 + v2 * v2);
-        const float X = v0 * inrm, Y = v1 * inrm, Z = v2 * inrm;
+        const float inrm = live ? rsqrtf(v0 * v0 + v1 * v1 + v2 * v2) : 0.0f;
+        const float X = live ? v0 * inrm : 0.0f, Y = live ? v1 * inrm : 0.0f, Z = live ? v2 * inrm : 0.0f;
         float bs[K], cs[K];
         bs[0] = SH_C0;
         if constexpr (DEG >= 1) { bs[1] = -Y * SH_C1; bs[2] = Z * SH_C1; bs[3] = -X * SH_C1; }
@@ -154,6 +158,12 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
 #pragma unroll
     for (int i = 0; i < 4; ++i) p[i] = P[i] * t[0] + P[i + 4] * t[1] + P[i + 8] * t[2] + P[i + 12] * t[3];
     const float4 dpc = reinterpret_cast<const float4 *>(a.dpc)[g];
+    // all-zero moments and colour path: the forward skipped this gaussian (payload not finite) or no pixel touched it.
+    // Its gradient is exactly zero; the recomputed J, cov, M below may hold Inf/NaN (tz == 0, exp overflow, singular
+    // covariance), and 0 * NaN must not reach the parameter gradients.
+    bool live = dpc.x != 0.0f || dpc.y != 0.0f || dpc.z != 0.0f;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) live = live || g2[i] != 0.0f;
     float dt[4] = {0, 0, 0, 0}, dp[4] = {dpc.x, dpc.y, dpc.z, 0.0f};
     const float tx = t[0], ty = t[1], tz = t[2], fx = cam.fx, fy = cam.fy;
     const float itz = 1.0f / tz, itz2 = itz * itz;
@@ -267,22 +277,25 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
     if (a.d_means) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const float v = T[4 * j] * dt[0] + T[1 + 4 * j] * dt[1] + T[2 + 4 * j] * dt[2] + T[3 + 4 * j] * dt[3];
+            const float v = live ? T[4 * j] * dt[0] + T[1 + 4 * j] * dt[1] + T[2 + 4 * j] * dt[2] + T[3 + 4 * j] * dt[3] : 0.0f;
             if (OVERWRITE) a.d_means[3 * g + j] = v; else a.d_means[3 * g + j] += v;
         }
     }
     if (a.d_scales) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { if (OVERWRITE) a.d_scales[3 * g + j] = de[j] * e[j]; else a.d_scales[3 * g + j] += de[j] * e[j]; }
+        for (int j = 0; j < 3; ++j) {
+            const float v = live ? de[j] * e[j] : 0.0f;
+            if (OVERWRITE) a.d_scales[3 * g + j] = v; else a.d_scales[3 * g + j] += v;
+        }
     }
     if (a.d_quats) {
         float4 *q = reinterpret_cast<float4 *>(a.d_quats) + g;
         float4 o = OVERWRITE ? make_float4(0.f, 0.f, 0.f, 0.f) : *q;
-        o.x += dw; o.y += dx; o.z += dy; o.w += dz;
+        if (live) { o.x += dw; o.y += dx; o.z += dy; o.w += dz; }
         *q = o;
     }
     if (a.d_opac) {
-        const float v = gsig * sg * (1.0f - sg);
+        const float v = live ? gsig * sg * (1.0f - sg) : 0.0f;
         if (OVERWRITE) a.d_opac[g] = v; else a.d_opac[g] += v;
     }
 }

@@ -196,6 +196,47 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     }
 }
 
+// ---------------------------------------------------------------- lane-order probe of the LDS atomic rank
+// 256 workgroups x 32 rounds: every wave draws digits from a hash (all-distinct, few-valued, constant and 32-valued
+// patterns, ~6 % inactive lanes), takes atomicAdd-return on an LDS counter row and compares the value with the ballot
+// rank (number of lower active lanes with the same digit).  Any mismatch makes gs_create fall back to ballot ranks.
+__global__ __launch_bounds__(256) void lds_atomic_order_probe_kernel(unsigned *__restrict__ bad) {
+    __shared__ unsigned cnt[4][RS_RADIX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned nbad = 0;
+    for (int r = 0; r < 32; ++r) {
+        for (int i = lane; i < RS_RADIX; i += 64) cnt[w][i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        unsigned h = (unsigned)(((blockIdx.x * 4 + w) * 32 + r) * 64 + lane) * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const int mode = (r + w) & 3;
+        const unsigned d = mode == 0 ? (h >> 24) : mode == 1 ? ((h >> 24) & 7u) : mode == 2 ? 5u : ((h >> 24) & 31u);
+        const bool active = ((h >> 8) & 15u) != 0u;
+        unsigned got = 0;
+        if (active) got = atomicAdd(&cnt[w][d], 1u);
+        unsigned long long peers = __ballot(active);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const unsigned long long bal = __ballot((d >> b) & 1u); peers &= ((d >> b) & 1u) ? bal : ~bal; }
+        const unsigned want = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+        if (active && got != want) ++nbad;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+hipError_t gs_probe_lds_atomic_order(hipStream_t s, int *mismatches) {
+    unsigned *d = nullptr, h = 0;
+    hipError_t e = hipMalloc(&d, sizeof(unsigned));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d, 0, sizeof(unsigned), s);
+    if (e == hipSuccess) { hipLaunchKernelGGL(lds_atomic_order_probe_kernel, dim3(256), dim3(256), 0, s, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    *mismatches = (int)h;
+    return e;
+}
+
 hipError_t gs_launch_radix_scan(uint32_t *block_hist, int nblocks, uint32_t *digit_total, hipStream_t stream) {
     hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
     hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);

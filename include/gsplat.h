@@ -80,13 +80,17 @@ typedef struct {
                                  2 + s: around stage s (gs_stage) only; 0: none */
     int32_t bin_path;         /* 0: generate-in-pass binning on 32-bit words (default); 1: explicit
                                  64-bit tile|id instances + two radix passes (fallback, same result) */
-    int32_t rank_mode;        /* radix-sort stable ranks: 0 = one LDS atomic-add-return per key (lane-ordered on
-                                 gfx950, measured), 1 = wave64 ballots (portable); same lists either way   */
+    int32_t rank_mode;        /* radix-sort stable ranks: 0 = one LDS atomic-add-return per key -- its pre-values come back in
+                                 ascending lane order on gfx950, which gs_create CHECKS on the device with a probe kernel and
+                                 falls back to 1 if the check fails; 1 = wave64 ballots (portable); same lists either way   */
     int32_t alpha_cull;       /* 1 (default): while staging a tile's list the composite kernels drop every
                                  (tile, splat) entry whose largest alpha over that tile's pixels is below 2^-27
                                  -- a no-op in the reference's own fp32 arithmetic (T*(1-alpha) == T, colour term
                                  < 7.5e-9*|rgb|).  The lists (gs_bin) are unchanged.  0: evaluate every entry. */
-    int32_t reserved[6];
+    int32_t schedule;         /* composite kernels: 0 (default) persistent waves pull tiles from an atomic ticket counter,
+                                 heaviest tile first; 1 one wave per tile in launch order; 2 ticket counter in tile order.
+                                 Speed only: every mode gives the same image and (up to atomic order) gradients           */
+    int32_t reserved[5];
 } gs_config;
 
 typedef struct gs_ctx gs_ctx;
@@ -273,6 +277,15 @@ int gs_get_work_counters_ex(gs_ctx *ctx, int64_t out[4]);
  * current frame `reps` times with kernel variant `variant` and return the mean hipEvent time.
  * Backward gradients of these launches go to the internal 2-D gradient scratch only. */
 int gs_debug_time_composite(gs_ctx *ctx, int which, int variant, int reps, float *mean_ms);
+
+/* Profiling aid: one launch of the composite forward (which=0) or backward (which=1) kernel of the current frame with
+ * per-tile clocks.  out (HOST): 4 x gx*gy uint64 per tile {start, end (100 MHz s_memrealtime ticks), HW_ID | XCC_ID << 32,
+ * walked << 32 | evaluated}.  tools/tile_tail.py turns it into the occupancy-over-time and tail summary under profiles/. */
+int gs_debug_tile_clock(gs_ctx *ctx, int which, int variant, uint64_t *out);
+
+/* 0: the LDS-atomic rank passed the lane-order probe at gs_create (or rank_mode = 1 was asked for: -1); 1: the probe
+ * failed on this device and ballots were forced. */
+int gs_rank_probe_result(const gs_ctx *ctx);
 
 #ifdef __cplusplus
 }

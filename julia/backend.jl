@@ -29,7 +29,8 @@ mutable struct GsConfig                      # must mirror gs_config (64 bytes)
     bin_path::Int32
     rank_mode::Int32
     alpha_cull::Int32
-    reserved::NTuple{6, Int32}
+    schedule::Int32
+    reserved::NTuple{5, Int32}
 end
 
 struct GsGrads                               # gs_grads: device pointers, may be C_NULL
@@ -55,7 +56,7 @@ function check(r::HipRenderer, rc::Cint)
 end
 
 function defaultConfig()
-    cfg = GsConfig(0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, ntuple(_ -> Int32(0), 6))
+    cfg = GsConfig(0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, ntuple(_ -> Int32(0), 5))
     ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
     return cfg
 end
@@ -160,5 +161,80 @@ hip_shGradsFromViews!(r::HipRenderer, camRecords::Matrix{Float32}, drgbAll::Ptr{
 # resetGrads(renderer.splatGrads)  (src/splat.jl:158-173)
 hip_resetGrads!(r::HipRenderer, grads::GsGrads) =
     check(r, ccall((:gs_reset_grads, libgs), Cint, (Ptr{Cvoid}, Ref{GsGrads}), r.ctx, grads))
+
+# ---- the step after backward (src/train.jl:39-46, src/loss.jl:62-72) ---------------------------------------------
+
+# backward with flags: GS_BWD_OVERWRITE (first backward after a reset: store instead of accumulate), GS_BWD_COMPOSITE_ONLY /
+# GS_BWD_PARAMS_ONLY (split backward of the colour-factored multi-GPU step).  ΔC and grads are DEVICE pointers here.
+const GS_BWD_OVERWRITE = Cint(1)
+const GS_BWD_COMPOSITE_ONLY = Cint(2)
+const GS_BWD_PARAMS_ONLY = Cint(4)
+hip_backwardEx!(r::HipRenderer, ΔC::Ptr{Float32}, grads::GsGrads, flags::Integer) =
+    check(r, ccall((:gs_backward_ex, libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}, Cint, Ref{GsGrads}, Cint),
+                   r.ctx, ΔC, GS_MEM_DEVICE, grads, flags))
+
+# loss = 0.9 L1/2 + 0.1 DSSIM/2 (src/loss.jl:62-72, lam = 0.1) and its gradient ΔC w.r.t. the rendered image; host arrays W x H x C
+function hip_lossL1Dssim!(r::HipRenderer, img::Array{Float32, 3}, gt::Array{Float32, 3}, ΔC::Array{Float32, 3}; lam = 0.1f0)
+    loss = Ref{Cdouble}(0.0)
+    check(r, ccall((:gs_loss_l1_dssim, libgs), Cint,
+                   (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int32, Int32, Int32, Cfloat, Ptr{Float32}, Ref{Cdouble}, Cint),
+                   r.ctx, img, gt, size(img, 1), size(img, 2), size(img, 3), lam, ΔC, loss, GS_MEM_HOST))
+    return loss[]
+end
+
+# params .-= lr .* grads on the resident model (src/train.jl:42-46)
+hip_sgdStep!(r::HipRenderer, lr::Real, grads::GsGrads) =
+    check(r, ccall((:gs_sgd_step, libgs), Cint, (Ptr{Cvoid}, Cfloat, Ref{GsGrads}), r.ctx, lr, grads))
+
+# ---- plumbing and introspection -----------------------------------------------------------------------------------
+
+# enqueue on an existing hipStream_t (C_NULL: the ctx's own stream)
+hip_setStream(r::HipRenderer, stream::Ptr{Cvoid}) =
+    check(r, ccall((:gs_set_stream, libgs), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), r.ctx, stream))
+hip_synchronize(r::HipRenderer) = check(r, ccall((:gs_synchronize, libgs), Cint, (Ptr{Cvoid},), r.ctx))
+hip_commDestroy(r::HipRenderer) = check(r, ccall((:gs_comm_destroy, libgs), Cint, (Ptr{Cvoid},), r.ctx))
+
+hip_numGaussians(r::HipRenderer) = ccall((:gs_num_gaussians, libgs), Int64, (Ptr{Cvoid},), r.ctx)
+hip_numInstances(r::HipRenderer) = ccall((:gs_num_instances, libgs), Int64, (Ptr{Cvoid},), r.ctx)
+hip_abiVersion() = ccall((:gs_abi_version, libgs), Cint, ())
+
+# renderer scratch arrays (gs_array ids of include/gsplat.h; e.g. 11 = sortIdxs, 12 = tile ranges, 13 = sorted ids) into a host array
+function hip_getArray!(r::HipRenderer, which::Integer, dst::Array)
+    check(r, ccall((:gs_get_array, libgs), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), r.ctx, which, dst, sizeof(dst)))
+    return dst
+end
+
+# per-stage hipEvent times of the last frame (gs_config.profile_stages = 1), GS_STAGE_COUNT = 9 entries, milliseconds
+function hip_stageTimes(r::HipRenderer)
+    ms = zeros(Float32, 9)
+    check(r, ccall((:gs_get_stage_times, libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}), r.ctx, ms))
+    return ms
+end
+function hip_stageStats(r::HipRenderer; reset = false)
+    sums = zeros(Float64, 9); counts = zeros(Int64, 9)
+    check(r, ccall((:gs_get_stage_stats, libgs), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Cint), r.ctx, sums, counts, reset ? 1 : 0))
+    return sums, counts
+end
+function hip_workCounters(r::HipRenderer)
+    out = zeros(Int64, 4)           # walked_fwd, walked_bwd, evaluated_fwd, evaluated_bwd
+    check(r, ccall((:gs_get_work_counters_ex, libgs), Cint, (Ptr{Cvoid}, Ptr{Int64}), r.ctx, out))
+    return out
+end
+function hip_workCountersWalked(r::HipRenderer)
+    f = Ref{Int64}(0); b = Ref{Int64}(0)
+    check(r, ccall((:gs_get_work_counters, libgs), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), r.ctx, f, b))
+    return f[], b[]
+end
+function hip_debugTimeComposite(r::HipRenderer, which::Integer, variant::Integer, reps::Integer)
+    ms = Ref{Cfloat}(0f0)
+    check(r, ccall((:gs_debug_time_composite, libgs), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ref{Cfloat}), r.ctx, which, variant, reps, ms))
+    return ms[]
+end
+function hip_debugTileClock(r::HipRenderer, which::Integer, variant::Integer, ntiles::Integer)
+    out = zeros(UInt64, 4, ntiles)
+    check(r, ccall((:gs_debug_tile_clock, libgs), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), r.ctx, which, variant, out))
+    return out
+end
+hip_rankProbeResult(r::HipRenderer) = ccall((:gs_rank_probe_result, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 
 end # module

@@ -1,0 +1,296 @@
+"""Oracle parity at the sizes BASELINE.json states (run on the MI355X box: pytest -m gpu).
+
+  C3  1 M gaussians, 1920x1080, SH3: lists bit-exact, pixels and all five gradient arrays against the oracle's
+      OpenMP fwd+bwd (the 13 s computation bench.py's cpu_baseline leg also does).
+  C4  the eight camera views of the 8-GPU batch, rendered one after the other on ONE GPU at the full size: lists
+      bit-exact per view, pixels per view, summed gradient == sum of the single-view gradients.
+  C5  5 M gaussians, 3840x2160: one full backward (finite), and pixels + gradients against the oracle restricted to
+      a fixed sample of tiles (the oracle walks only those tiles' lists; the HIP path gets dC zeroed elsewhere, which
+      restricts its sums to the same tiles exactly).
+  un-normalised quaternions (SURVEY 8d draws N(0,1)^4 and the reference never normalises, projection.jl:126).
+
+Measured errors are written to gpurun_out/parity_sizes.json (quoted in DESIGN.md).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import hip_context, rel_l2, scene_and_cameras
+
+pytestmark = pytest.mark.gpu
+
+PIX_ATOL, PIX_RTOL = 1e-4, 1e-4
+GRAD_REL_L2 = 1e-3
+GRADS = ("means", "scales", "quats", "opacities", "shs")
+_REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_sizes.json")
+
+
+def _report(key, value):
+    os.makedirs(os.path.dirname(_REPORT), exist_ok=True)
+    d = {}
+    if os.path.exists(_REPORT):
+        try:
+            with open(_REPORT) as fh:
+                d = json.load(fh)
+        except Exception:
+            d = {}
+    d[key] = value
+    with open(_REPORT, "w") as fh:
+        json.dump(d, fh, indent=1, sort_keys=True)
+
+
+def _pix_err(got, want):
+    """largest |d| / (atol + rtol |x|): <= 1 passes."""
+    return float(np.max(np.abs(got - want) / (PIX_ATOL + PIX_RTOL * np.abs(want))))
+
+
+def test_c3_full_size_pixels_and_gradients_against_oracle(oracle):
+    """The headline configuration end to end: default early-out, float-atomic AND deterministic gradient modes."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = synthetic.CONFIGS["C3"]
+    seed = 1234 + list(synthetic.CONFIGS).index("C3")
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+    dC = synthetic.make_dC(W, H, seed + 1)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC,
+                      t_min=1e-5, omp=True)
+    rep = {}
+    for det in (False, True):
+        ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5, deterministic=det)
+        ctx.preprocess(); ctx.bin()
+        assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ref["ranges"])
+        assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ref["ids"])
+        img, tr = ctx.forward_host()
+        e_img, e_tr = _pix_err(img, ref["image"]), _pix_err(tr, ref["trans"])
+        assert e_img <= 1.0 and e_tr <= 1.0, (e_img, e_tr)
+        g = ctx.grads_alloc(); ctx.backward(dC, g)
+        got = ctx.grads_read(g, deg)
+        errs = {k: rel_l2(got[k].reshape(-1), gref[k].reshape(-1)) for k in GRADS}
+        errs["g2d_rgb"] = rel_l2(ctx.get_array(B.ARR_GRAD2D)[:, :3], gref["g2d"][:, :3])
+        rep["deterministic" if det else "float_atomics"] = dict(pixel_err_over_tol=e_img, trans_err_over_tol=e_tr, grad_rel_l2=errs)
+        for k in GRADS:
+            assert np.isfinite(got[k]).all(), k
+            assert errs[k] <= GRAD_REL_L2, (k, errs[k], det)
+        ctx.close()
+    _report("C3", rep)
+
+
+def test_c3_linearity_in_deterministic_mode():
+    """g(2 dC) == 2 g(dC): with the fixed-point accumulation the only difference left is the rounding of each
+    per-(tile, splat) sum to 2^-40 / 2^-28, so the tolerance is 1e-6, not an atomics-order noise level."""
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg = synthetic.CONFIGS["C3"]
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1236)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, deterministic=True)
+    ctx.preprocess(); ctx.bin(); ctx.forward_host()
+    dC = synthetic.make_dC(W, H, 3)
+    outs = []
+    for scale in (1.0, 2.0, 1.0):
+        g = ctx.grads_alloc()
+        ctx.backward((scale * dC).astype(np.float32), g)
+        got = ctx.grads_read(g, deg)
+        outs.append(np.concatenate([got[k].reshape(-1) for k in GRADS]).astype(np.float64))
+    assert np.array_equal(outs[0], outs[2])                                  # bitwise reproducible
+    e = np.linalg.norm(outs[1] - 2 * outs[0]) / np.linalg.norm(outs[1])
+    _report("C3_linearity_deterministic", e)
+    assert e <= 1e-6, e
+    ctx.close()
+
+
+def test_c4_eight_views_at_full_size_on_one_gpu(oracle):
+    """BASELINE config C4 without the 8-GPU node: the eight views (eye rotated about +y by k*45 degrees) at
+    1 M / 1080p, sequentially on one GPU.  Per view: lists bit-exact, pixels within tolerance.  Gradients accumulate
+    over the views (reference contract); in deterministic mode the accumulated buffer must equal the sum of the
+    eight single-view gradients and be reproducible bit for bit; views 0 and 5 are also compared with the oracle."""
+    from gaussiansplat_amd import backend as B, camera as gcam, synthetic
+    O = oracle
+    n, W, H, deg = synthetic.CONFIGS["C4"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    sc = synthetic.make_scene(n, W, H, deg, seed=1234 + list(synthetic.CONFIGS).index("C4"))
+    ctx = B.Context(order=1, t_min=1e-5, deterministic=True)
+    ctx.set_model_host(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"].reshape(n, 3 * (deg + 1) ** 2), deg)
+    acc = ctx.grads_alloc()                                                  # zeroed flat buffer owned by the ctx
+    single_sum = None
+    rep = {}
+    import torch
+    K3 = 3 * (deg + 1) ** 2
+    tmp = torch.zeros(n * (11 + K3), dtype=torch.float32, device="cuda")
+    ptrs, o = [], 0
+    for w in (3, 3, 4, 1, K3):
+        ptrs.append(tmp[o:o + n * w].data_ptr()); o += n * w
+    tmp_g = B.GsGrads(*ptrs)
+    torch.cuda.synchronize()
+    for view in range(8):
+        cam = synthetic.scene_camera(W, view=view)
+        T = gcam.compute_transform(cam); P = gcam.compute_projection(cam, W, H)
+        ocam = O.camera_from_arrays(T, P, np.float32(cam.fx), np.float32(cam.fy), np.float32(cam.near), np.float32(cam.far),
+                                    cam.eye, cam.lookAt, W, H)
+        ctx.set_camera(T, P, float(np.float32(cam.fx)), float(np.float32(cam.fy)), float(np.float32(cam.near)),
+                       float(np.float32(cam.far)), cam.eye, cam.lookAt, W, H)
+        ctx.preprocess(); ctx.bin()
+        pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, omp=True)
+        oranges, oids, okeys = O.bin_lists(pre["bbs"], pre["tps"], 1, 16, gx, gy)
+        assert ctx.num_instances == len(oids), view
+        assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), oranges), view
+        assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), oids), view
+        assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), okeys), view
+        del okeys
+        img, tr = ctx.forward_host()
+        oimg, otr = O.composite_forward(pre, oranges, oids, ocam, 16, gx, gy, t_min=1e-5, omp=True)
+        e_img, e_tr = _pix_err(img, oimg), _pix_err(tr, otr)
+        assert e_img <= 1.0 and e_tr <= 1.0, (view, e_img, e_tr)
+        dC = synthetic.make_dC(W, H, 100 + view)
+        ctx.backward(dC, acc)                                                # accumulates over the views
+        ctx.backward(dC, tmp_g, overwrite=True); ctx.synchronize()           # this view alone
+        one = tmp.cpu().numpy().astype(np.float64)
+        assert np.isfinite(one).all(), view
+        single_sum = one if single_sum is None else single_sum + one
+        rep[f"view{view}"] = dict(instances=int(ctx.num_instances), pixel_err_over_tol=e_img, trans_err_over_tol=e_tr)
+        if view in (0, 5):
+            gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, oranges, oids, dC,
+                              t_min=1e-5, omp=True)
+            want = np.concatenate([gref[k].reshape(-1) for k in GRADS])
+            e = rel_l2(one, want)
+            rep[f"view{view}"]["grad_rel_l2"] = e
+            assert e <= GRAD_REL_L2, (view, e)
+            del gref, want
+        del oids, oranges, pre
+    got = ctx.grads_read(acc, deg)
+    total = np.concatenate([got[k].reshape(-1) for k in GRADS]).astype(np.float64)
+    assert np.isfinite(total).all()
+    e = np.linalg.norm(total - single_sum) / np.linalg.norm(single_sum)      # fp32 accumulation of eight addends
+    rep["sum_vs_single_views_rel_l2"] = e
+    assert e <= 1e-6, e
+    _report("C4_views_on_one_gpu", rep)
+    ctx.close()
+
+
+def test_c5_backward_and_sampled_tiles_against_oracle(oracle):
+    """BASELINE config C5 (5 M, 3840x2160, SH3; 507 M instances).  One full backward must be finite; pixels and
+    gradients are compared with the oracle on a fixed sample of 384 tiles."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = synthetic.CONFIGS["C5"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1234 + list(synthetic.CONFIGS).index("C5"))
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5)
+    ctx.preprocess(); ctx.bin()
+    img, tr = ctx.forward_host()
+    assert np.isfinite(img).all()
+    dC = synthetic.make_dC(W, H, 55)
+    g = ctx.grads_alloc()
+    ctx.backward(dC, g)                                                      # the full C5 backward
+    full = ctx.grads_read(g, deg)
+    for k in GRADS:
+        assert np.isfinite(full[k]).all(), k
+        assert float(np.abs(full[k]).max()) > 0.0, k
+    wc = ctx.work_counters_ex()
+    assert wc["walked_bwd"] == wc["walked_fwd"] > 0
+    del full
+    # ---- the oracle on a sample of tiles: corners, edges and 376 random tiles
+    rng = np.random.default_rng(5)
+    sel = set(int(t) for t in rng.choice(gx * gy, 376, replace=False))
+    sel |= {0, gx - 1, (gy - 1) * gx, gx * gy - 1, gx // 2, (gy - 1) * gx + gx // 2, (gy // 2) * gx, (gy // 2) * gx + gx - 1}
+    sel = np.array(sorted(sel), np.int64)
+    pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, omp=True)
+    ranges = ctx.get_array(B.ARR_TILE_RANGES)                                # bit-exact against the oracle's (test_gpu_properties)
+    ids = ctx.get_array(B.ARR_SORTED_IDS)
+    masked = np.zeros_like(ranges)
+    masked[sel] = ranges[sel]
+    pm = np.zeros((H, W), bool)
+    for t in sel:
+        ty, tx = divmod(int(t), gx)
+        pm[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+    oimg, otr = O.composite_forward(pre, masked, ids, ocam, 16, gx, gy, t_min=1e-5, omp=True)
+    e_img, e_tr = _pix_err(img[:, pm], oimg[:, pm]), _pix_err(tr[pm], otr[pm])
+    assert e_img <= 1.0 and e_tr <= 1.0, (e_img, e_tr)
+    dCm = (dC * pm[None]).astype(np.float32)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, masked, ids, dCm, t_min=1e-5, omp=True)
+    g = ctx.grads_alloc()
+    ctx.backward(dCm, g)
+    got = ctx.grads_read(g, deg)
+    errs = {k: rel_l2(got[k].reshape(-1), gref[k].reshape(-1)) for k in GRADS}
+    _report("C5_sampled_tiles", dict(tiles=int(len(sel)), entries=int((masked[:, 1] - masked[:, 0]).sum()), pixel_err_over_tol=e_img,
+                                     trans_err_over_tol=e_tr, grad_rel_l2=errs, walked_fwd=wc["walked_fwd"], instances=int(ctx.num_instances)))
+    for k in GRADS:
+        assert float(np.abs(gref[k]).max()) > 0.0, k
+        assert errs[k] <= GRAD_REL_L2, (k, errs[k])
+    ctx.close()
+
+
+@pytest.mark.parametrize("order,t_min", [(1, 0.0), (1, 1e-5), (0, 0.0)])
+def test_unnormalised_quaternions(oracle, order, t_min):
+    """|q| in [0.5, 2]: the reference never normalises q (projection.jl:126) and R enters the footprint four times, so
+    |q| scales it by |q|^4 and dL/dq has a radial part.  Preprocess and lists bit-exact, pixels and gradients within
+    the stated tolerances; the radial component of dL/dq is checked to be non-trivial and to match."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = 3500, 176, 120, 3
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 77)
+    rng = np.random.default_rng(78)
+    norm = np.exp(rng.uniform(np.log(0.5), np.log(2.0), n)).astype(np.float32)
+    sc["quats"] = (sc["quats"] * norm[:, None]).astype(np.float32)
+    sc["scales"] = (sc["scales"] - np.float32(1.0)).astype(np.float32)      # keep the inflated footprints moderate
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=order, t_min=t_min)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=t_min, export_debug=True)
+    ctx.preprocess()
+    for name, which in (("cov3d", B.ARR_COV3D), ("cov2d", B.ARR_COV2D), ("invcov", B.ARR_INVCOV), ("bbs", B.ARR_BBS)):
+        got = ctx.get_array(which)
+        assert np.array_equal(got, ref["pre"][name].reshape(got.shape), equal_nan=True), name
+    ctx.bin()
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ref["ranges"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ref["ids"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), ref["keys"])
+    img, tr = ctx.forward_host()
+    assert _pix_err(img, ref["image"]) <= 1.0 and _pix_err(tr, ref["trans"]) <= 1.0
+    dC = synthetic.make_dC(W, H, 79)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC, t_min=t_min)
+    g = ctx.grads_alloc(); ctx.backward(dC, g)
+    got = ctx.grads_read(g, deg)
+    for k in GRADS:
+        assert rel_l2(got[k].reshape(-1), gref[k].reshape(-1)) <= GRAD_REL_L2, (k, rel_l2(got[k].reshape(-1), gref[k].reshape(-1)))
+    q = sc["quats"].astype(np.float64)
+    rad_ref = (q * gref["quats"]).sum(1) / np.linalg.norm(q, axis=1)
+    rad_got = (q * got["quats"].astype(np.float64)).sum(1) / np.linalg.norm(q, axis=1)
+    assert np.linalg.norm(rad_ref) > 0.05 * np.linalg.norm(gref["quats"])      # the radial part is really there
+    assert rel_l2(rad_got, rad_ref) <= GRAD_REL_L2
+    ctx.close()
+
+
+def test_degenerate_splats_give_finite_gradients():
+    """gaussians the forward skips (tz == 0, exp(scale) overflow) and a saturated opaque splat centred on
+    a pixel must not put NaN/Inf into any gradient array (0 * Inf in the recomputed chain, 1/(1-alpha) at alpha -> 1)."""
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg = 600, 96, 64, 3
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 91)
+    # (a) scale logit 50: exp overflows to Inf in the covariance
+    sc["scales"][0] = (50.0, 50.0, 50.0)
+    # (b) mean exactly on the camera plane: tz = T[2,:] . [m;1] = 0 -> 1/tz = Inf
+    eye = np.asarray(cam.eye, np.float32)
+    sc["means"][1] = eye
+    # (c) opacity logit 20 (sigmoid rounds to 1.0f), small footprint centred exactly on a pixel centre
+    sc["opacities"][2] = 20.0
+    sc["scales"][2] = (-6.0, -6.0, -6.0)
+    # (d) a NaN mean
+    sc["means"][3] = (np.nan, 0.0, 0.0)
+    # (the literal oracle would put NaN into the whole pixel box of (a), as the reference does -- its example scrubs NaNs
+    # afterwards, examples/main.jl:35; the HIP composite skips splats whose per-view payload is not finite)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5)
+    ctx.preprocess(); ctx.bin()
+    img, tr = ctx.forward_host()
+    assert np.isfinite(img).all() and np.isfinite(tr).all()
+    dC = synthetic.make_dC(W, H, 92)
+    for overwrite in (True, False):
+        g = ctx.grads_alloc()
+        ctx.backward(dC, g, overwrite=overwrite)
+        got = ctx.grads_read(g, deg)
+        for k in GRADS:
+            assert np.isfinite(got[k]).all(), (k, overwrite, np.argwhere(~np.isfinite(got[k]))[:4])
+        for bad in (0, 1, 3):                                               # skipped by the forward: exactly zero gradient
+            for k in GRADS:
+                assert not np.any(got[k][bad]), (k, bad)
+    ctx.close()

