@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgsplat_hip.so")
+LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(_HERE, "lib", "libgsplat_hip.so")   # override: diagnostic builds
 
 GS_MEM_HOST, GS_MEM_DEVICE = 0, 1
 ORDER_INDEX, ORDER_DEPTH_DESC, ORDER_DEPTH_ASC = 0, 1, 2
@@ -121,7 +121,7 @@ class Context:
 
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
                  profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 0,
-                 alpha_cull: bool = True, schedule: int = 0):
+                 alpha_cull: bool = True, schedule: int = 1):
         self.L = load()
         cfg = default_config()
         cfg.schedule = int(schedule)

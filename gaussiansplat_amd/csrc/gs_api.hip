@@ -100,9 +100,9 @@ struct gs_ctx {
     bool ev_fresh[GS_STAGE_COUNT] = {};      // ... and not yet added to the accumulators
     double ev_sum[GS_STAGE_COUNT] = {};
     int64_t ev_cnt[GS_STAGE_COUNT] = {};
-    DevBuf counters;                         // 64 B: 4 x u64 entries walked, evaluated by the forward; walked, evaluated by the backward;
-                                             // u32 ticket counters of the forward (byte 32) and backward (byte 40) work queues
-    DevBuf tile_order_f, tile_order_b, tile_work, tile_clock;   // longest-first tile orders, per-tile evaluated entries, debug clocks
+    DevBuf counters;                         // 128 B: 4 x u64 entries walked, evaluated by the forward; walked, evaluated by the backward;
+                                             // then 8 u32 per-XCD ticket counters of the forward (byte 32) and 8 of the backward (byte 64)
+    DevBuf tile_order_f, tile_order_b, tile_order_p, tile_work, tile_clock;   // longest-first tile orders (+ 9 segment bounds each), per-tile work, debug clocks
     int waves_fwd = 0, waves_bwd = 0;        // resident waves of the persistent composite grids (occupancy x CUs)
     int rank_probe = -1;                     // lane-order probe of the LDS atomic rank: -1 not run, 0 passed, 1 failed (ballots forced)
     DevBuf grads_flat;                       // gs_grads_alloc
@@ -167,15 +167,15 @@ int composite_sched(gs_ctx *c, GsCompositeArgs &a, int which) {
         waves = gs_composite_resident_waves(which, c->cfg.t_min > 0.0f, c->cfg.deterministic != 0, c->cfg.alpha_cull != 0);
         if (waves <= 0) waves = 256 * 16;
     }
-    a.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(c->counters.p) + (which == 0 ? 32 : 40));
+    a.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(c->counters.p) + (which == 0 ? 32 : 64));
     a.grid_waves = waves;
-    if (c->cfg.schedule == 0) {
-        DevBuf &ord = which == 0 ? c->tile_order_f : c->tile_order_b;
-        HIPCHK(c, ord.ensure(sizeof(uint32_t) * (size_t)ntiles));
-        if (which == 0) HIPCHK(c, gs_launch_tile_order(c->ranges.as<uint32_t>(), 1, ntiles, ord.as<uint32_t>(), c->stream));
-        else HIPCHK(c, gs_launch_tile_order(c->tile_work.as<uint32_t>(), 0, ntiles, ord.as<uint32_t>(), c->stream));
-        a.tile_order = ord.as<uint32_t>();
-    }
+    // order buffers: ntiles tile ids followed by the 9 segment bounds
+    DevBuf &ord = which == 0 ? c->tile_order_f : c->tile_order_b;
+    HIPCHK(c, ord.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
+    const uint32_t *src = c->cfg.schedule == 2 ? nullptr : which == 0 ? c->ranges.as<uint32_t>() : c->tile_work.as<uint32_t>();
+    HIPCHK(c, gs_launch_tile_order(src, which == 0 ? 1 : 0, ntiles, ord.as<uint32_t>(), ord.as<uint32_t>() + ntiles, c->stream));
+    a.tile_order = ord.as<uint32_t>();
+    a.queue_seg = ord.as<uint32_t>() + ntiles;
     return GS_OK;
 }
 
@@ -194,6 +194,7 @@ void gs_default_config(gs_config *cfg) {
     cfg->export_debug = 0;
     cfg->profile_stages = 0;
     cfg->alpha_cull = 1;
+    cfg->schedule = 1;
 }
 
 int gs_abi_version(void) { return GS_ABI_VERSION; }
@@ -253,7 +254,7 @@ int gs_destroy(gs_ctx *c) {
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
                       &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
-                      &c->tile_order_f, &c->tile_order_b, &c->tile_work, &c->tile_clock,
+                      &c->tile_order_f, &c->tile_order_b, &c->tile_order_p, &c->tile_work, &c->tile_clock,
                       &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->model) b.release();
@@ -533,10 +534,10 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
-    HIPCHK(c, c->counters.ensure(64));
+    HIPCHK(c, c->counters.ensure(128));
     a.walked = c->counters.as<unsigned long long>();
     a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));          // work counters + both ticket counters
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 128, c->stream));         // work counters + both sets of ticket counters
     if (int rc = composite_sched(c, a, 0)) return rc;
     {
         StageTimer t(c, GS_STAGE_COMPOSITE_FWD);                       // the kernel alone
@@ -580,7 +581,7 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     if (!params_only) {
         c->last_dC = dC_dev;
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
-        HIPCHK(c, hipMemsetAsync(a.walked, 0, 32, c->stream));              // the backward's work counters + the ticket counters
+        HIPCHK(c, hipMemsetAsync(a.walked, 0, 112, c->stream));             // the backward's work counters + the ticket counters
         if (int rc = composite_sched(c, a, 1)) return rc;
         {
             StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                   // the kernel alone (what rocprof reports for it)
@@ -930,8 +931,13 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     c->cfg.schedule = 0;
     const int rc = composite_sched(c, a, which);
     c->cfg.schedule = keep;
+    if (rc) return rc;
     if (which == 0) a.tile_work = nullptr;                                   // keep the frame's per-tile work for the backward
-    return rc;
+    const int ntiles = c->gx * c->gy;                                        // the same segments without longest-first (variant tens digit 2)
+    HIPCHK(c, c->tile_order_p.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
+    HIPCHK(c, gs_launch_tile_order(nullptr, 0, ntiles, c->tile_order_p.as<uint32_t>(), c->tile_order_p.as<uint32_t>() + ntiles, c->stream));
+    a.tile_order_plain = c->tile_order_p.as<uint32_t>();
+    return GS_OK;
 }
 
 int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *mean_ms) {
@@ -946,7 +952,7 @@ int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *
     // every launch is preceded by the 8-byte reset of its ticket counter, as in a real frame (where it rides on the
     // memset of the work counters); the plain-launch variants pay it too, so the comparison stays fair
     auto launch = [&]() -> hipError_t {
-        hipError_t e = hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 16, c->stream);
+        hipError_t e = hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 96, c->stream);
         if (e != hipSuccess) return e;
         return which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream);
     };
@@ -974,7 +980,7 @@ int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
     HIPCHK(c, hipMemsetAsync(c->tile_clock.p, 0, sizeof(uint64_t) * 4 * ntiles, c->stream));
     a.tile_clock = c->tile_clock.as<unsigned long long>();
     for (int rep = 0; rep < 2; ++rep) {                                       // the second launch (warm) is the one kept
-        HIPCHK(c, hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 16, c->stream));
+        HIPCHK(c, hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 96, c->stream));
         HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(out, c->tile_clock.p, sizeof(uint64_t) * 4 * ntiles, hipMemcpyDeviceToHost, c->stream));

@@ -132,14 +132,16 @@ struct GsCompositeArgs {
     int variant;               // kernel variant (A/B testing; 0 = default)
     int map_mode;              // block -> tile map of the non-queued launch (0 plain; 1, 2: XCD bands, A/B only)
     // work queue (persistent waves pull tiles from an atomic ticket counter, longest first)
-    uint32_t *queue;           // ticket counter, zeroed before the launch; null: one wave per tile, blockIdx order
-    const uint32_t *tile_order; // ticket -> tile (tiles sorted by decreasing work estimate); null: identity
+    uint32_t *queue;           // 8 ticket counters (one per XCD), zeroed before the launch; null: one wave per tile, blockIdx order
+    const uint32_t *queue_seg; // 9 bounds of the per-XCD segments of tile_order
+    const uint32_t *tile_order; // segment x: the tiles with tile % 8 == x, heaviest first
+    const uint32_t *tile_order_plain; // A/B: the same segments in tile order (no longest-first)
     uint32_t *tile_work;       // forward: evaluated entries per tile (the backward's exact work measure); may be null
     unsigned long long *tile_clock; // debug: per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated}
     int grid_waves;            // waves to launch in queue mode
 };
 // tiles in decreasing order of work[] (a 256-bucket counting sort of work / max; one workgroup)
-hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s);
+hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s);
 int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body = 0);   // occupancy x CUs (body: A/B variant)
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);
@@ -165,12 +167,13 @@ hipError_t gs_launch_sh_from_views(int64_t n, int sh_degree, const float *means,
 // about the splat's 2-D mean: row = [dr dg db | S0 Sx Sy Sxx Sxy - Syy].  With the view's sig and conic M (column
 // major i0 i1 i2 i3, mc = (i1 + i2)/2):  dL/dsig = -S0/sig,  dL/dmu = -(i0 Sx + mc Sy, mc Sx + i3 Sy),
 // dL/dM = 1/2 [Sxx Sxy; Sxy Syy].  In place: row becomes [dr dg db dsig dmx dmy d00 d01 d10 d11].
-__host__ __device__ inline void gs_g2d_to_grads(float (&g2)[10], float sig, float i0, float mc, float i3) {
-    const float S0 = g2[3], Sx = g2[4], Sy = g2[5], Sxx = g2[6], Sxy = g2[7], Syy = g2[9];
-    g2[3] = sig > 0.0f ? -S0 / sig : 0.0f;
+template <typename R>
+__host__ __device__ inline void gs_g2d_to_grads(R (&g2)[10], R sig, R i0, R mc, R i3) {
+    const R S0 = g2[3], Sx = g2[4], Sy = g2[5], Sxx = g2[6], Sxy = g2[7], Syy = g2[9];
+    g2[3] = sig > R(0) ? -S0 / sig : R(0);
     g2[4] = -(i0 * Sx + mc * Sy);
     g2[5] = -(mc * Sx + i3 * Sy);
-    g2[6] = 0.5f * Sxx; g2[7] = 0.5f * Sxy; g2[8] = 0.5f * Sxy; g2[9] = 0.5f * Syy;
+    g2[6] = R(0.5) * Sxx; g2[7] = R(0.5) * Sxy; g2[8] = R(0.5) * Sxy; g2[9] = R(0.5) * Syy;
 }
 
 // deterministic mode: fixed-point scale of g2d component c.  2^-40 for the colour gradient and the moments of order

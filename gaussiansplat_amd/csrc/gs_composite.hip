@@ -41,6 +41,17 @@
 // instruction costs that shaped the inner loops.
 #include "gs_common.h"
 
+// Only the fmaf() calls written below fuse: with the compiler free to contract, T - alpha*T came out as one fma in one
+// template instantiation and as mul + sub in another, so "cull on" and "cull off" differed in the last bit of T.
+#pragma clang fp contract(off)
+
+#ifndef GS_ABL
+#define GS_ABL 0
+#endif
+#ifndef GS_BWD3_MINW
+#define GS_BWD3_MINW 1              // __launch_bounds__ waves/SIMD of backward body 3 (diagnostic builds raise it)
+#endif
+#include <cstdlib>
 #define CB 64                       // splats staged per batch
 #define NEG_HALF_LOG2E (-0.72134752044448170368f)
 
@@ -62,14 +73,26 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles, int gx, int mode
     return (b & 7) * per + (b >> 3);
 }
 
-// Next tile of this wave: a ticket from the queue (persistent launch) or the block's own tile (first call only).
+// Next tile of this wave: a ticket from the work queue (persistent launch) or the block's own tile (first call only).
+// The queue is eight ticket counters, one per XCD, over eight segments of tile_order: segment x holds the tiles with
+// tile % 8 == x, heaviest first.  A wave pulls from the segment of the XCD it runs on (HW_REG_XCC_ID), so vertically
+// adjacent tiles (tile + gx: same residue for the 8-aligned grids of 1080p and 4K) share their splat payloads in that
+// XCD's L2 -- the placement the plain launch gets from the round-robin dispatch, and worth 13 % of the forward at C3
+// (profiles/: one shared counter vs plain launch).  When its segment is exhausted it steals from the next ones, so the
+// kernel ends balanced across the chip.  Placement is a speed matter only: any wave may process any tile.
 __device__ __forceinline__ int next_tile(const GsCompositeArgs &a, int ntiles, bool first) {
     if (a.queue) {
-        uint32_t t = 0;
-        if (threadIdx.x == 0) t = atomicAdd(a.queue, 1u);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= (uint32_t)ntiles) return -1;
-        return a.tile_order ? (int)a.tile_order[t] : (int)t;
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 7u;       // HW_REG_XCC_ID
+        for (uint32_t i = 0; i < 8; ++i) {
+            const uint32_t x = (xcc + i) & 7u;
+            const uint32_t lo = a.queue_seg[x], hi = a.queue_seg[x + 1];
+            if (lo >= hi) continue;
+            uint32_t t = 0;
+            if (threadIdx.x == 0) t = atomicAdd(a.queue + x, 1u);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + lo;
+            if (t < hi) return a.tile_order ? (int)a.tile_order[t] : (int)t;
+        }
+        return -1;
     }
     if (!first) return -1;
     const int tile = tile_of_block(blockIdx.x, ntiles, a.gx, a.map_mode);
@@ -344,15 +367,28 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
                                                const float (&dCr)[4], const float (&dCg)[4], const float (&dCb)[4],
                                                float (&T)[4], float (&S)[4], float (&v)[9], bool &any) {
     const float dX = fx - e.q0.x;
+#if GS_ABL & 16
+    const float A0 = fmaf(e.q1.x * dX, dX, e.q0.z);
+#else
     const float ex = dX - __builtin_amdgcn_fmed3f(dX, e.q0.w, e.q1.w);
     const float A0 = fmaf(nbig, fabsf(ex), fmaf(e.q1.x * dX, dX, e.q0.z));
+#endif
     const float B0 = e.q1.y * dX;
     float al[4], dY[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         dY[p] = fy[p] - e.q0.y;
+#if GS_ABL & 16
+        const float xp = fmaf(dY[p], fmaf(e.q1.z, dY[p], B0), A0);
+#else
         const float ey = dY[p] - __builtin_amdgcn_fmed3f(dY[p], e.q2.w, e.yhi);
-        al[p] = fast_exp2(fmaf(nbig, fabsf(ey), fmaf(dY[p], fmaf(e.q1.z, dY[p], B0), A0)));
+        const float xp = fmaf(nbig, fabsf(ey), fmaf(dY[p], fmaf(e.q1.z, dY[p], B0), A0));
+#endif
+#if GS_ABL & 8
+        al[p] = xp * 1.0e-3f;
+#else
+        al[p] = fast_exp2(xp);
+#endif
     }
     any = ((al[0] + al[1]) + (al[2] + al[3])) != 0.0f;
     float ar, ag, ab, q0s, q1s, q2s;
@@ -361,7 +397,11 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
         const float w = al[p] * T[p];
         const float cdot = fmaf(e.q2.x, dCr[p], fmaf(e.q2.y, dCg[p], e.q2.z * dCb[p]));
         S[p] = fmaf(-cdot, w, S[p]);
+#if GS_ABL & 8
+        const float inv = (1.0f - al[p]) * 0.5f;
+#else
         const float inv = fast_rcp(1.0f - al[p]);
+#endif
         const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));
         const float dd = -(al[p] * dalpha);
         const float ddy = dd * dY[p];
@@ -382,6 +422,11 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
     v[6] = dX * qx; v[7] = dX * q1s; v[8] = q2s;
 }
 
+// Diagnostic builds (tools/ablate.sh, never shipped; run with t_min = 0 so that the walked and evaluated entries do not depend
+// on the arithmetic).  -DGS_ABL is a bit mask: 1 drops the cross-lane reduction and the atomic of body 3 (the nine partials are
+// kept alive by an empty asm), 2 drops only the atomic, 8 replaces v_exp_f32 / v_rcp_f32 by one multiply each, 16 drops the
+// pixel-box penalty (v_med3 + sub + fma per axis), 32 reuses one staged entry (no LDS reads of the payload).  Outputs are wrong
+// by construction.
 // RED: 2 transposed LDS reduction, software pipelined (default); 1 reduce-scatter tree on ds_swizzle / ds_bpermute
 template <bool EARLY, bool DET, int RED, bool CULL>
 __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, uint32_t *sid, float *red,
@@ -435,7 +480,11 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         s += ((r2.x + r2.y) + (r2.z + r2.w)) + ((r3.x + r3.y) + (r3.z + r3.w));
         s += dpp_xor1(s);
         s += dpp_xor2(s);
+#if GS_ABL & 2
+        asm volatile("" :: "v"(s));
+#else
         if (ocomp_t >= 0) add_to_row<DET>(a, pend_gid, ocomp_t, s);
+#endif
     };
     for (uint32_t base = s0; base < s1; base += CB) {
         const int cnt = (int)min((uint32_t)CB, s1 - base);
@@ -493,19 +542,33 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             for (; k + 1 < nk; k += 2) { step(eA, gA, eB, gB, k); step(eB, gB, eA, gA, k + 1); }
             if (k < nk) step(eA, gA, eB, gB, k);
         } else if (RED == 3) {                                           // transposed reduction, summed in the same iteration
+#if GS_ABL & 32
+            Entry e = load_entry(sp, syhi, 0);
+#endif
             for (int k = 0; k < nk; ++k) {
+#if GS_ABL & 32
+                asm volatile("" : "+v"(e.q0.x), "+v"(e.q0.y), "+v"(e.q1.x), "+v"(e.q2.x));     // opaque: no hoisting out of the loop
+                const uint32_t gid = 0;
+#else
                 const Entry e = load_entry(sp, syhi, k);
                 const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
+#endif
                 float v[9];
-                bool any;
+                bool any = true;
                 backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any);
                 if (!CULL && __ballot(any) == 0ull) continue;
+#if GS_ABL & 1
+#pragma unroll
+                for (int c = 0; c < 9; ++c) asm volatile("" :: "v"(v[c]));
+                (void)gid;
+#else
 #pragma unroll
                 for (int c = 0; c < 9; ++c) wrow[c * RS] = v[c];
                 const float4 *rr = reinterpret_cast<const float4 *>(rrow);
                 r0 = rr[0]; r1 = rr[1]; r2 = rr[2]; r3 = rr[3];
                 pend_gid = gid;
                 finish();
+#endif
             }
         } else {
             for (int k = 0; k < nk; ++k) {
@@ -545,50 +608,65 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     }
 }
 
-// ---------------------------------------------------------------- tile order (longest first)
-// One workgroup: work[t] (or the list length ranges[2t+1] - ranges[2t]) -> 256 buckets of work / max, counted from the
-// heaviest bucket down; tiles inside a bucket keep no particular order (a speed hint only, never correctness).
+// ---------------------------------------------------------------- tile order (per XCD, longest first)
+// One workgroup: tiles are keyed by (tile % 8, work / max in 256 steps, descending) and counting-sorted; seg[0..8] are the
+// bounds of the eight per-XCD segments of `order`.  work = work[t], or the list length ranges[2t+1] - ranges[2t]
+// (ranges_mode), or 0 for every tile (src == null: tile order inside each segment).  Tiles inside a bucket keep no
+// particular order (a speed hint only, never correctness).
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles,
-                                                           uint32_t *__restrict__ order) {
-    __shared__ uint32_t hist[256];
+                                                           uint32_t *__restrict__ order, uint32_t *__restrict__ seg) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t wsum[16];
     __shared__ uint32_t wmax;
-    const int tid = threadIdx.x;
-    if (tid < 256) hist[tid] = 0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    hist[tid] = 0; hist[tid + 1024] = 0;
     if (tid == 0) wmax = 1;
     __syncthreads();
-    auto work = [&](int t) -> uint32_t { return ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t]; };
+    auto work = [&](int t) -> uint32_t { return !src ? 0u : ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t]; };
     uint32_t m = 0;
     for (int t = tid; t < ntiles; t += 1024) m = max(m, work(t));
     atomicMax(&wmax, m);
     __syncthreads();
     const float scale = 255.0f / (float)wmax;
-    for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[255 - (int)((float)work(t) * scale)], 1u);     // bucket 0 = heaviest
+    auto bucket = [&](int t) -> int { return (t & 7) * 256 + 255 - (int)((float)work(t) * scale); };         // bucket 0 of a segment = heaviest
+    for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[bucket(t)], 1u);
     __syncthreads();
-    if (tid < 64) {                                                      // exclusive scan of 256 counters by one wave
-        uint32_t c[4], s = 0;
+    {                                                                    // exclusive scan of 2048 counters: thread t owns [2t, 2t+2)
+        const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1], sm = c0 + c1;
+        uint32_t incl = sm;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { c[i] = hist[4 * tid + i]; s += c[i]; }
-        uint32_t incl = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (tid >= d) incl += u; }
-        uint32_t run = incl - s;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { hist[4 * tid + i] = run; run += c[i]; }
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int k = 0; k < w; ++k) off += wsum[k];
+        const uint32_t run = off + incl - sm;
+        hist[2 * tid] = run; hist[2 * tid + 1] = run + c0;
+        if ((tid & 127) == 0) seg[tid >> 7] = run;                       // bucket 256 x: start of segment x
+        if (tid == 1023) seg[8] = run + sm;
     }
     __syncthreads();
-    for (int t = tid; t < ntiles; t += 1024) order[atomicAdd(&hist[255 - (int)((float)work(t) * scale)], 1u)] = (uint32_t)t;
+    for (int t = tid; t < ntiles; t += 1024) order[atomicAdd(&hist[bucket(t)], 1u)] = (uint32_t)t;
 }
 
-hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s) {
+hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, work_or_ranges, ranges_mode, ntiles, order);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, work_or_ranges, ranges_mode, ntiles, order, seg);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- launchers
-// variant (A/B, tools/abtest.py; 0 = default): units digit = kernel body (backward: 2 transposed LDS reduction, software pipelined;
-// 3 the same, summed in the iteration; 1 reduce-scatter tree; forward: 1), tens digit = scheduling (0 as the caller set it up: queue + order when given; 1 one wave per tile in
+// variant (A/B, tools/abtest.py; 0 = default): units digit = kernel body (backward: 3 transposed LDS reduction (default); 2 the same,
+// software pipelined at 96 VGPRs; 1 reduce-scatter tree; forward: 1), tens digit = scheduling (0 as the caller set it up: queue + order when given; 1 one wave per tile in
 // blockIdx order; 2 queue in tile order, no longest-first).
+// Profiling aid: GS_DEBUG_EXTRA_LDS=<bytes> adds that much dynamic LDS to every composite launch, which lowers the
+// waves resident per CU (160 KiB / (static + extra)) without touching the code -- the occupancy sweep of tools/ablate.sh.
+static size_t debug_extra_lds() {
+    static long v = -1;
+    if (v < 0) { const char *e = getenv("GS_DEBUG_EXTRA_LDS"); v = e ? atol(e) : 0; if (v < 0) v = 0; }
+    return (size_t)v;
+}
+
 static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {
     if (a.queue) return dim3((unsigned)max(1, min(a.grid_waves > 0 ? a.grid_waves : ntiles, ntiles)));
     return dim3(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8);
@@ -598,7 +676,7 @@ static GsCompositeArgs apply_sched_variant(const GsCompositeArgs &a0) {
     GsCompositeArgs a = a0;
     const int sched = (a.variant / 10) % 10;
     if (sched == 1) { a.queue = nullptr; a.tile_order = nullptr; }
-    else if (sched == 2) a.tile_order = nullptr;
+    else if (sched == 2 && a.tile_order_plain) a.tile_order = a.tile_order_plain;      // per-XCD segments in tile order
     return a;
 }
 
@@ -608,8 +686,8 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
-#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 1, true>), grid, block, 0, s, a); \
-                     else hipLaunchKernelGGL((composite_fwd_kernel<E, 1, false>), grid, block, 0, s, a); } while (0)
+#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 1, true>), grid, block, debug_extra_lds(), s, a); \
+                     else hipLaunchKernelGGL((composite_fwd_kernel<E, 1, false>), grid, block, debug_extra_lds(), s, a); } while (0)
     if (early) GS_F(true); else GS_F(false);
 #undef GS_F
     return hipGetLastError();
@@ -620,18 +698,19 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
     const bool early = a.t_min > 0.0f;
-    if (a.queue && a.variant % 10 != 0 && a.variant % 10 != 2) {           // A/B body: its own resident-wave count
+    if (a.queue && a.variant % 10 != 0 && a.variant % 10 != 3) {           // A/B body: its own resident-wave count
         const int w = gs_composite_resident_waves(1, early, a.g2d_fixed != nullptr, a.cull != 0, a.variant % 10);
         if (w > 0) a.grid_waves = w;
     }
     const dim3 grid = composite_grid(a, ntiles), block(64);
-    const int body = (a.variant % 10 == 1 || a.variant % 10 == 3) ? a.variant % 10 : 2;
-#define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, 0, s, a); \
-                               else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, 0, s, a); } while (0)
+    const int body = (a.variant % 10 == 1 || a.variant % 10 == 2) ? a.variant % 10 : 3;
+#define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, debug_extra_lds(), s, a); \
+                               else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, debug_extra_lds(), s, a); } while (0)
 #define GS_B(E, M, Z) do { if (a.g2d_fixed) GS_B2(E, M, true, Z); else GS_B2(E, M, false, Z); } while (0)
-    // body 2 (default) holds the sixteen partials of the previous entry across the pixel arithmetic: 96 VGPRs, 5 waves/SIMD
+    // body 2 holds the sixteen partials of the previous entry across the pixel arithmetic: 96 VGPRs, 5 waves/SIMD (measured slower
+    // than body 3 at 78 VGPRs / 6 waves: the kernel gains more from the sixth wave than from the hidden LDS round trip)
     if (body == 2) { if (early) GS_B(true, 5, 2); else GS_B(false, 5, 2); }
-    else if (body == 3) { if (early) GS_B(true, 1, 3); else GS_B(false, 1, 3); }
+    else if (body == 3) { if (early) GS_B(true, GS_BWD3_MINW, 3); else GS_B(false, GS_BWD3_MINW, 3); }
     else { if (early) GS_B(true, 1, 1); else GS_B(false, 1, 1); }
 #undef GS_B
 #undef GS_B2
@@ -644,8 +723,8 @@ typedef void (*CompositeKernel)(GsCompositeArgs);
 template <bool E, bool D, bool C>
 static CompositeKernel bwd_kernel_of(int body) {
     if (body == 1) return composite_bwd_kernel<E, 1, D, 1, C>;
-    if (body == 3) return composite_bwd_kernel<E, 1, D, 3, C>;
-    return composite_bwd_kernel<E, 5, D, 2, C>;
+    if (body == 2) return composite_bwd_kernel<E, 5, D, 2, C>;
+    return composite_bwd_kernel<E, GS_BWD3_MINW, D, 3, C>;
 }
 int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body) {
     int dev = 0, cus = 0, per_cu = 0;

@@ -15,7 +15,11 @@
 //                       HBM) go through an LDS tile [256][3K+1]: coalesced block loads, conflict-free
 //                       per-thread rows (odd stride), gradients written back into the same tile and
 //                       stored/added to d_shs with coalesced accesses.
-//   gs_geom_bwd_kernel  d{mu', invCov2d, sig} -> d{means, scales, quaternions, opacities}.
+//   gs_geom_bwd_kernel  d{mu', invCov2d, sig} -> d{means, scales, quaternions, opacities}.  The chain (3x3 / 2x3 / 2x2
+//                       products, the 2x2 inverse and the quaternion terms) is evaluated in fp64 from the fp32 inputs:
+//                       in fp32 its cancellations put the quaternion gradient at 2e-4 .. 2e-3 relative L2 of the fp64
+//                       adjoint (C3, C5 tile samples) while every other array sits at 2e-5 .. 1e-4; ~400 flops per
+//                       gaussian, so the kernel stays HBM-bound.
 // Splitting keeps both under 128 VGPRs (the fused version needed 168 + spills).
 // `overwrite` stores instead of accumulating: used for the first backward after resetGrads, so
 // the reset needs no 4(11+3K)-byte/gaussian zero fill and this pass no read of the old gradients.
@@ -142,17 +146,24 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
     }
 }
 
+// old + v as one rounded add that the compiler may not fuse with the products v came from: the accumulating and the
+// overwriting instantiation must produce the SAME v (accumulating eight views == the sum of eight single-view gradients)
+__device__ __forceinline__ float add_exact(float old, float v) {
+#pragma clang fp contract(off)
+    return old + v;
+}
+
 template <bool OVERWRITE>
 __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n) return;
-    float g2[10];
-    load_g2(a, g, g2);                                  // colour gradient + raw moments (gs_common.h: gs_g2d_to_grads)
+    float g2f[10];
+    load_g2(a, g, g2f);                                  // colour gradient + raw moments (gs_common.h: gs_g2d_to_grads)
     const float *T = cam.T, *P = cam.P;
 
     // ---- forward recompute (same formulas as gs_preprocess.hip)
-    const float m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
-    float t[4], p[4];
+    const double m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
+    double t[4], p[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i] = T[i] * m1 + T[i + 4] * m2 + T[i + 8] * m3 + T[i + 12];
 #pragma unroll
@@ -161,19 +172,22 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
     // all-zero moments and colour path: the forward skipped this gaussian (payload not finite) or no pixel touched it.
     // Its gradient is exactly zero; the recomputed J, cov, M below may hold Inf/NaN (tz == 0, exp overflow, singular
     // covariance), and 0 * NaN must not reach the parameter gradients.
-    bool live = dpc.x != 0.0f || dpc.y != 0.0f || dpc.z != 0.0f;
+    bool live = dpc.x != 0.0 || dpc.y != 0.0 || dpc.z != 0.0;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) live = live || g2[i] != 0.0f;
-    float dt[4] = {0, 0, 0, 0}, dp[4] = {dpc.x, dpc.y, dpc.z, 0.0f};
-    const float tx = t[0], ty = t[1], tz = t[2], fx = cam.fx, fy = cam.fy;
-    const float itz = 1.0f / tz, itz2 = itz * itz;
-    const float J[2][3] = {{fx * itz, 0.0f, -fx * tx * itz2}, {0.0f, fy * itz, -fy * ty * itz2}};
-    const float w = a.quats[4 * g], x = a.quats[4 * g + 1], y = a.quats[4 * g + 2], z = a.quats[4 * g + 3];
-    const float R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+    for (int i = 0; i < 10; ++i) live = live || g2f[i] != 0.0;
+    double g2[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) g2[i] = (double)g2f[i];
+    double dt[4] = {0, 0, 0, 0}, dp[4] = {dpc.x, dpc.y, dpc.z, 0.0};
+    const double tx = t[0], ty = t[1], tz = t[2], fx = cam.fx, fy = cam.fy;
+    const double itz = 1.0 / tz, itz2 = itz * itz;
+    const double J[2][3] = {{fx * itz, 0.0, -fx * tx * itz2}, {0.0, fy * itz, -fy * ty * itz2}};
+    const double w = a.quats[4 * g], x = a.quats[4 * g + 1], y = a.quats[4 * g + 2], z = a.quats[4 * g + 3];
+    const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
                            {2 * (x * y + w * z), 1 - 2 * (x * x - z * z), 2 * (y * z - w * x)},
                            {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
-    const float e[3] = {__expf(a.scales[3 * g]), __expf(a.scales[3 * g + 1]), __expf(a.scales[3 * g + 2])};
-    float Wm[3][3], Sg[3][3], A[2][3], ASg[2][3], cov[2][2];
+    const double e[3] = {exp((double)a.scales[3 * g]), exp((double)a.scales[3 * g + 1]), exp((double)a.scales[3 * g + 2])};
+    double Wm[3][3], Sg[3][3], A[2][3], ASg[2][3], cov[2][2];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -193,17 +207,17 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) cov[i][j] = ASg[i][0] * A[j][0] + ASg[i][1] * A[j][1] + ASg[i][2] * A[j][2] + 0.3f;
-    const float idet = 1.0f / (cov[0][0] * cov[1][1] - cov[0][1] * cov[1][0]);
-    const float M[2][2] = {{cov[1][1] * idet, -cov[0][1] * idet}, {-cov[1][0] * idet, cov[0][0] * idet}};
-    const float ez = __expf(a.opac[g]);
-    const float sg = ez / (1.0f + ez);
-    gs_g2d_to_grads(g2, sg, M[0][0], 0.5f * (M[0][1] + M[1][0]), M[1][1]);
-    const float gsig = g2[3], gmx = g2[4], gmy = g2[5];
-    const float G[2][2] = {{g2[6], g2[7]}, {g2[8], g2[9]}};           // G[r][c] = dL/dM[r][c]
+        for (int j = 0; j < 2; ++j) cov[i][j] = ASg[i][0] * A[j][0] + ASg[i][1] * A[j][1] + ASg[i][2] * A[j][2] + 0.3;
+    const double idet = 1.0 / (cov[0][0] * cov[1][1] - cov[0][1] * cov[1][0]);
+    const double M[2][2] = {{cov[1][1] * idet, -cov[0][1] * idet}, {-cov[1][0] * idet, cov[0][0] * idet}};
+    const double ez = exp((double)a.opac[g]);
+    const double sg = ez / (1.0 + ez);
+    gs_g2d_to_grads(g2, sg, M[0][0], 0.5 * (M[0][1] + M[1][0]), M[1][1]);
+    const double gsig = g2[3], gmx = g2[4], gmy = g2[5];
+    const double G[2][2] = {{g2[6], g2[7]}, {g2[8], g2[9]}};           // G[r][c] = dL/dM[r][c]
 
     // ---- M = cov^-1  =>  dcov = -M^T G M^T
-    float t1[2][2], dcov[2][2];
+    double t1[2][2], dcov[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -213,9 +227,9 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
 #pragma unroll
         for (int j = 0; j < 2; ++j) dcov[i][j] = -(t1[i][0] * M[j][0] + t1[i][1] * M[j][1]);
     // ---- cov = A Sg A^T (+0.3): dA = (dcov + dcov^T) A Sg ; dSg = A^T dcov A
-    const float off = dcov[0][1] + dcov[1][0];
-    const float ds2[2][2] = {{2 * dcov[0][0], off}, {off, 2 * dcov[1][1]}};
-    float dA[2][3], dSg[3][3], dJ[2][3], dR[3][3], dWm[3][3];
+    const double off = dcov[0][1] + dcov[1][0];
+    const double ds2[2][2] = {{2 * dcov[0][0], off}, {off, 2 * dcov[1][1]}};
+    double dA[2][3], dSg[3][3], dJ[2][3], dR[3][3], dWm[3][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -235,12 +249,12 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
 #pragma unroll
         for (int j = 0; j < 3; ++j) dR[i][j] = J[0][i] * dA[0][j] + J[1][i] * dA[1][j];
     // ---- Sg = Wm Wm^T, Wm = R diag(e)
-    float de[3] = {0.0f, 0.0f, 0.0f};
+    double de[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float s = 0.0f;
+            double s = 0.0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) s += (dSg[i][k] + dSg[k][i]) * Wm[k][j];
             dWm[i][j] = s;
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
             de[j] += R[i][j] * s;
         }
     // ---- R(q), with the reference's R22
-    float dw = 0, dx = 0, dy = 0, dz = 0;
+    double dw = 0, dx = 0, dy = 0, dz = 0;
     dy += -4 * y * dR[0][0]; dz += -4 * z * dR[0][0];
     dx += 2 * y * dR[1][0]; dy += 2 * x * dR[1][0]; dw += 2 * z * dR[1][0]; dz += 2 * w * dR[1][0];
     dx += 2 * z * dR[2][0]; dz += 2 * x * dR[2][0]; dw += -2 * y * dR[2][0]; dy += -2 * w * dR[2][0];
@@ -259,16 +273,16 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
     dy += 2 * z * dR[1][2]; dz += 2 * y * dR[1][2]; dw += -2 * x * dR[1][2]; dx += -2 * w * dR[1][2];
     dx += -4 * x * dR[2][2]; dy += -4 * y * dR[2][2];
     // ---- J(t)
-    const float itz3 = itz2 * itz;
+    const double itz3 = itz2 * itz;
     dt[0] += dJ[0][2] * (-fx * itz2);
     dt[1] += dJ[1][2] * (-fy * itz2);
     dt[2] += dJ[0][0] * (-fx * itz2) + dJ[1][1] * (-fy * itz2) + dJ[0][2] * (2 * fx * tx * itz3) + dJ[1][2] * (2 * fy * ty * itz3);
     // ---- mu(p): mu = (W p0/p3 + 1)/2 + W/2
-    const float ip3 = 1.0f / p[3];
-    const float Wd = (float)cam.W, Hd = (float)cam.H;
-    dp[0] += gmx * 0.5f * Wd * ip3;
-    dp[1] += gmy * 0.5f * Hd * ip3;
-    dp[3] += -(gmx * 0.5f * Wd * p[0] + gmy * 0.5f * Hd * p[1]) * ip3 * ip3;
+    const double ip3 = 1.0 / p[3];
+    const double Wd = (double)cam.W, Hd = (double)cam.H;
+    dp[0] += gmx * 0.5 * Wd * ip3;
+    dp[1] += gmy * 0.5 * Hd * ip3;
+    dp[3] += -(gmx * 0.5 * Wd * p[0] + gmy * 0.5 * Hd * p[1]) * ip3 * ip3;
     // ---- p = P t ; t = T [m;1]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -277,26 +291,26 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
     if (a.d_means) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const float v = live ? T[4 * j] * dt[0] + T[1 + 4 * j] * dt[1] + T[2 + 4 * j] * dt[2] + T[3 + 4 * j] * dt[3] : 0.0f;
-            if (OVERWRITE) a.d_means[3 * g + j] = v; else a.d_means[3 * g + j] += v;
+            const float v = live ? (float)(T[4 * j] * dt[0] + T[1 + 4 * j] * dt[1] + T[2 + 4 * j] * dt[2] + T[3 + 4 * j] * dt[3]) : 0.0f;
+            if (OVERWRITE) a.d_means[3 * g + j] = v; else a.d_means[3 * g + j] = add_exact(a.d_means[3 * g + j], v);
         }
     }
     if (a.d_scales) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const float v = live ? de[j] * e[j] : 0.0f;
-            if (OVERWRITE) a.d_scales[3 * g + j] = v; else a.d_scales[3 * g + j] += v;
+            const float v = live ? (float)(de[j] * e[j]) : 0.0f;
+            if (OVERWRITE) a.d_scales[3 * g + j] = v; else a.d_scales[3 * g + j] = add_exact(a.d_scales[3 * g + j], v);
         }
     }
     if (a.d_quats) {
         float4 *q = reinterpret_cast<float4 *>(a.d_quats) + g;
         float4 o = OVERWRITE ? make_float4(0.f, 0.f, 0.f, 0.f) : *q;
-        if (live) { o.x += dw; o.y += dx; o.z += dy; o.w += dz; }
+        if (live) { o.x = add_exact(o.x, (float)dw); o.y = add_exact(o.y, (float)dx); o.z = add_exact(o.z, (float)dy); o.w = add_exact(o.w, (float)dz); }
         *q = o;
     }
     if (a.d_opac) {
-        const float v = live ? gsig * sg * (1.0f - sg) : 0.0f;
-        if (OVERWRITE) a.d_opac[g] = v; else a.d_opac[g] += v;
+        const float v = live ? (float)(gsig * sg * (1.0 - sg)) : 0.0f;
+        if (OVERWRITE) a.d_opac[g] = v; else a.d_opac[g] = add_exact(a.d_opac[g], v);
     }
 }
 

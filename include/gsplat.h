@@ -87,9 +87,12 @@ typedef struct {
                                  (tile, splat) entry whose largest alpha over that tile's pixels is below 2^-27
                                  -- a no-op in the reference's own fp32 arithmetic (T*(1-alpha) == T, colour term
                                  < 7.5e-9*|rgb|).  The lists (gs_bin) are unchanged.  0: evaluate every entry. */
-    int32_t schedule;         /* composite kernels: 0 (default) persistent waves pull tiles from an atomic ticket counter,
-                                 heaviest tile first; 1 one wave per tile in launch order; 2 ticket counter in tile order.
-                                 Speed only: every mode gives the same image and (up to atomic order) gradients           */
+    int32_t schedule;         /* composite kernels: 1 (default) one wave per tile in launch order -- tiles in flight are spatial
+                                 neighbours, so they share splat payloads in L2; 0 persistent waves pull tiles from per-XCD ticket
+                                 counters, heaviest tile first; 2 the same in arbitrary order.  Measured at C3 (profiles/): modes 0
+                                 and 2 balance the SIMDs (work max/mean 1.04 vs 1.17) but scatter the tiles in flight over the
+                                 image, and the lost L2 reuse costs far more (forward 0.72 vs 0.37 ms).  Speed only: every mode
+                                 gives the same image and (up to atomic order) gradients                                  */
     int32_t reserved[5];
 } gs_config;
 

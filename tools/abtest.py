@@ -12,7 +12,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
 # variant = body + 10 * scheduling (gs_composite.hip launchers): body bwd 2 pipelined transposed reduction (default), 3 transposed,
 # 1 reduce-scatter tree; scheduling 0 ticket queue heaviest first (default), 1 one wave per tile, 2 ticket queue in tile order
 variants_f = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "10", "20"])]
-variants_b = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "10", "20", "3", "13", "1", "11"])]
+variants_b = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "10", "20", "2", "12", "1", "11"])]
 n, W, H, deg = synthetic.CONFIGS[cfg]
 sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1234 + list(synthetic.CONFIGS).index(cfg))
 dC = synthetic.make_dC(W, H, 1)

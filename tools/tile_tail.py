@@ -74,7 +74,7 @@ def main():
     ctx.preprocess(); ctx.bin(); ctx.forward_host()
     g = ctx.grads_alloc(); ctx.backward(dC, g); ctx.synchronize()
     res = {"config": cfg, "instances": ctx.num_instances, "work": ctx.work_counters_ex()}
-    variants = {"fwd": [0, 10, 20], "bwd": [0, 10, 20, 3, 13, 1, 11]}
+    variants = {"fwd": [0, 10, 20], "bwd": [0, 10, 20, 2, 12, 1, 11]}
     for which, name in ((0, "fwd"), (1, "bwd")):
         for v in variants[name]:
             a = analyse(ctx.tile_clock(which, v))
