@@ -294,7 +294,7 @@ def main():
                                      "never normalises q and |q| scales every footprint by |q|^4; un-normalised q is parity-tested, "
                                      "tests/test_gpu_sizes.py)",
                        "nranks": nranks, "grad_sync": args.grad_sync if world > 1 else None, "backend": args.backend if world > 1 else None,
-                       "rank_mode": int(r.ctx.cfg.rank_mode),
+                       "rank_mode": int(r.ctx.cfg.rank_mode), "binning_rounds": r.ctx.num_rounds,
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
                        "instances": I, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
                        "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "seed": seed},

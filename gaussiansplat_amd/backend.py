@@ -28,14 +28,14 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
-           "gs_debug_tile_clock", "gs_rank_probe_result")
+           "gs_debug_tile_clock", "gs_rank_probe_result", "gs_num_rounds")
 
 
 class GsConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("tile_size", C.c_int32), ("order", C.c_int32), ("t_min", C.c_float),
                 ("deterministic", C.c_int32), ("export_debug", C.c_int32), ("profile_stages", C.c_int32),
                 ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("alpha_cull", C.c_int32), ("schedule", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("slab_mode", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class GsGrads(C.Structure):
@@ -106,6 +106,7 @@ def load():
     L.gs_debug_time_composite.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.gs_debug_tile_clock.argtypes = [vp, C.c_int, C.c_int, vp]
     L.gs_rank_probe_result.argtypes = [vp]
+    L.gs_num_rounds.argtypes = [vp]
     _lib = L
     return L
 
@@ -121,10 +122,11 @@ class Context:
 
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
                  profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 0,
-                 alpha_cull: bool = True, schedule: int = 1):
+                 alpha_cull: bool = True, schedule: int = 1, slab_mode: int = 1):
         self.L = load()
         cfg = default_config()
         cfg.schedule = int(schedule)
+        cfg.slab_mode = int(slab_mode)
         cfg.order, cfg.t_min = int(order), float(t_min)
         cfg.export_debug, cfg.profile_stages, cfg.deterministic = int(export_debug), int(profile_stages), int(deterministic)
         cfg.bin_path, cfg.rank_mode, cfg.alpha_cull = int(bin_path), int(rank_mode), int(alpha_cull)
@@ -291,6 +293,11 @@ class Context:
     @property
     def num_instances(self) -> int:
         return int(self.L.gs_num_instances(self.h))
+
+    @property
+    def num_rounds(self) -> int:
+        """binning rounds of the last bin(): 1 = classic full lists, 2..4 = depth slabs"""
+        return int(self.L.gs_num_rounds(self.h))
 
     def get_array(self, which: int, gx: int | None = None, gy: int | None = None) -> np.ndarray:
         n, ni = self.num_gaussians, self.num_instances

@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -105,6 +106,20 @@ struct gs_ctx {
     DevBuf tile_order_f, tile_order_b, tile_order_p, tile_work, tile_clock;   // longest-first tile orders (+ 9 segment bounds each), per-tile work, debug clocks
     int waves_fwd = 0, waves_bwd = 0;        // resident waves of the persistent composite grids (occupancy x CUs)
     int rank_probe = -1;                     // lane-order probe of the LDS atomic rank: -1 not run, 0 passed, 1 failed (ballots forced)
+    // ---- binning in depth slabs (gs_config.slab_mode)
+    int n_rounds = 1;                        // binning rounds of the current frame
+    int64_t slab_lo[GS_MAX_ROUNDS + 1] = {}; // round r covers the list positions [slab_lo[r], slab_lo[r+1]) of the depth order
+    int64_t round_gen[GS_MAX_ROUNDS] = {};   // generated instance positions of the round (>= the instances it lists)
+    size_t round_ids_off[GS_MAX_ROUNDS] = {};// where the round's ids start inside `ids`
+    DevBuf ranges_r[GS_MAX_ROUNDS];          // tile ranges of rounds 1.. (round 0 uses `ranges`)
+    DevBuf tile_pos, tile_done, live2d, rect_r, offsets_r, live_total;
+    uint32_t *perm_all = nullptr;            // the whole depth order (perm_ptr)
+    int tile_bits = 0, gid_bits = 0, lo_bits = 0, hi_bits = 0;
+    bool fast_bin = false;
+    double walked_ratio = -1.0;              // entries walked / instances of the last completed frame (-1: none yet)
+    int64_t prev_n_inst = 0;
+    bool prev_counters_valid = false;        // `counters` holds the walked count of a completed forward
+    int64_t frame_id = 0, ev_frame[GS_STAGE_COUNT] = {};   // a stage may run once per binning round: ev_cnt counts frames, not launches
     DevBuf grads_flat;                       // gs_grads_alloc
     DevBuf dpc;                              // 4 x n scratch between the two backward kernels
     DevBuf loss_maps, loss_acc, loss_in[2], loss_dc, view_cams;
@@ -131,7 +146,10 @@ int hipfail(gs_ctx *c, hipError_t e, const char *what) {
 struct StageTimer {
     gs_ctx *c; int st; bool on;
     StageTimer(gs_ctx *c_, int st_) : c(c_), st(st_), on(c_->cfg.profile_stages == 1 || c_->cfg.profile_stages == 2 + st_) {
-        if (on) (void)hipEventRecord(c->ev[st][0], c->stream);
+        if (on) {
+            if (c->ev_frame[st] != c->frame_id) { c->ev_frame[st] = c->frame_id; c->ev_cnt[st] += 1; }      // one count per frame
+            (void)hipEventRecord(c->ev[st][0], c->stream);
+        }
     }
     ~StageTimer() {
         if (on) { (void)hipEventRecord(c->ev[st][1], c->stream); c->ev_valid[st] = true; c->ev_fresh[st] = true; }
@@ -144,7 +162,7 @@ void harvest_events(gs_ctx *c, int skip_stage = -1) {
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
         if (c->ev_fresh[s] && s != skip_stage) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) { c->ev_sum[s] += ms; c->ev_cnt[s] += 1; }
+            if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) c->ev_sum[s] += ms;
             c->ev_fresh[s] = false;
         }
 }
@@ -195,6 +213,7 @@ void gs_default_config(gs_config *cfg) {
     cfg->profile_stages = 0;
     cfg->alpha_cull = 1;
     cfg->schedule = 1;
+    cfg->slab_mode = 1;
 }
 
 int gs_abi_version(void) { return GS_ABI_VERSION; }
@@ -214,6 +233,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (c0.order < GS_ORDER_INDEX || c0.order > GS_ORDER_DEPTH_ASC) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad order");
     if (!(c0.t_min >= 0.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: t_min must be >= 0");
     if (c0.schedule < 0 || c0.schedule > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad schedule");
+    if (c0.slab_mode < 0 || c0.slab_mode > 1) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad slab_mode");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -255,6 +275,8 @@ int gs_destroy(gs_ctx *c) {
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
                       &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
                       &c->tile_order_f, &c->tile_order_b, &c->tile_order_p, &c->tile_work, &c->tile_clock,
+                      &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
+                      &c->ranges_r[0], &c->ranges_r[1], &c->ranges_r[2], &c->ranges_r[3],
                       &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->model) b.release();
@@ -379,6 +401,7 @@ int gs_preprocess(gs_ctx *c) {
     if (!c) return GS_ERR_INVALID;
     if (!c->have_cam) return fail(c, GS_ERR_INVALID, "gs_preprocess: gs_set_camera first");
     if (bind_device(c)) return GS_ERR_HIP;
+    c->frame_id += 1;
     const size_t n = (size_t)c->n, n1 = n ? n : 1;
     HIPCHK(c, c->payload.ensure(sizeof(GsPayload) * n1));
     HIPCHK(c, c->depth_key.ensure(sizeof(uint32_t) * n1));
@@ -426,6 +449,90 @@ int gs_preprocess(gs_ctx *c) {
     return GS_OK;
 }
 
+// ---------------------------------------------------------------- binning in depth slabs
+// A dense scene walks only the front of every tile's list before the transmittance early-out stops it (C3: 28 % of the
+// 30 M instances, C5: 6 % of 507 M), yet the classic path sorts all of them.  With gs_config.slab_mode the frame is binned
+// in rounds over slabs of the depth order: round 0 lists the front slab for every tile and composites it; a tile whose
+// 256 pixels are all frozen is complete; round r lists the next slab only for the tiles still open (a gaussian whose
+// rectangle holds no open tile drops out, instances of completed tiles inside the other rectangles are dropped while they
+// are generated) and the forward resumes each open tile where it stopped -- same entries, same order, same 64-entry batch
+// boundaries as the single list, so image, transmittance and (deterministic mode) gradients are bit-identical to the
+// classic path.  The slab bounds come from the share of the instances the previous frame walked; a first frame, a sparse
+// scene (share >= GS_SLAB_MAX_RATIO) or t_min = 0 take the classic single round.
+// Measured on MI355X: at C3 (share 0.28) two rounds cost more than they save (two forward launches with their tails, the second
+// count pass; 2.16 vs 1.97 ms), at C5 (share 0.06) three rounds cut the frame from 10.4 to 7.7 ms: slabs below a share of 0.15.
+#define GS_SLAB_MAX_RATIO 0.15
+static int plan_rounds(gs_ctx *c) {
+    c->n_rounds = 1;
+    c->slab_lo[0] = 0; c->slab_lo[1] = c->n;
+    if (!c->fast_bin || c->cfg.t_min <= 0.0f || c->n < 1024 || c->order() == GS_ORDER_INDEX) return 1;
+    double f[GS_MAX_ROUNDS] = {1.0, 1.0, 1.0, 1.0};
+    int R = 1;
+    if (const char *e = std::getenv("GS_SLABS")) {                          // experiments: explicit fractions "f1[,f2[,f3]]", "" = classic
+        const char *p = e;
+        while (*p && R < GS_MAX_ROUNDS) { char *q = nullptr; const double v = std::strtod(p, &q); if (q == p) break; f[R - 1] = v; ++R; p = *q == ',' ? q + 1 : q; }
+    } else if (c->cfg.slab_mode == 1 && c->walked_ratio >= 0.0 && c->walked_ratio < GS_SLAB_MAX_RATIO) {
+        const double rho = c->walked_ratio;
+        f[0] = std::min(0.9, std::max(0.02, 2.0 * rho + 0.02));
+        f[1] = std::min(0.95, std::max(f[0] + 0.05, 6.0 * rho + 0.05));
+        R = 3;
+    }
+    if (R == 1) return 1;
+    int64_t prev = 0;
+    int r = 0;
+    for (int k = 0; k + 1 < R; ++k) {
+        int64_t b = (int64_t)(f[k] * (double)c->n);
+        b = std::min(c->n, std::max(prev, b));
+        if (b > prev && b < c->n) { c->slab_lo[++r] = b; prev = b; }
+    }
+    c->slab_lo[++r] = c->n;
+    c->n_rounds = r;
+    return r;
+}
+
+// Lists of round r (r >= 1) for the tiles still open; called from gs_forward after the forward of round r - 1.
+static int bin_round(gs_ctx *c, int r) {
+    const int64_t lo = c->slab_lo[r], nr = c->slab_lo[r + 1] - lo;
+    const int64_t ntiles = (int64_t)c->gx * c->gy;
+    const uint32_t *perm = c->perm_all + lo;
+    HIPCHK(c, c->live2d.ensure(sizeof(uint32_t) * 2 * (size_t)(c->gx + 1) * (c->gy + 1)));      // the table + the row-pass scratch
+    HIPCHK(c, c->rect_r.ensure(sizeof(uint16_t) * 4 * (size_t)(c->n ? c->n : 1)));
+    HIPCHK(c, c->offsets_r.ensure(sizeof(uint32_t) * ((size_t)nr + 1)));
+    HIPCHK(c, c->live_total.ensure(sizeof(uint32_t) * GS_MAX_ROUNDS));
+    HIPCHK(c, c->ranges_r[r].ensure(sizeof(uint32_t) * 2 * (size_t)ntiles));
+    {
+        StageTimer t(c, GS_STAGE_COUNT_SCAN);
+        HIPCHK(c, gs_launch_live_prefix(c->tile_done.as<uint8_t>(), c->gx, c->gy, c->live2d.as<uint32_t>(),
+                                        c->live2d.as<uint32_t>() + (size_t)(c->gx + 1) * (c->gy + 1), c->stream));
+        HIPCHK(c, gs_launch_count_scan_live(c->rect.as<uint16_t>(), perm, c->live2d.as<uint32_t>(), c->gx, c->rect_r.as<uint16_t>(),
+                                            c->offsets_r.as<uint32_t>(), c->block_sums.as<uint32_t>(), nr, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets_r.as<uint32_t>() + nr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
+    {
+        StageTimer t(c, GS_STAGE_RANGES);                               // does not need the count: keeps the GPU busy while the host waits
+        HIPCHK(c, gs_launch_tile_ranges(c->rect_r.as<uint16_t>(), perm, nr, c->diff.as<int>(), c->gx, c->gy, c->ranges_r[r].as<uint32_t>(),
+                                        c->tile_done.as<uint8_t>(), c->stream));
+    }
+    HIPCHK(c, hipEventSynchronize(c->ev_count));
+    harvest_events(c, GS_STAGE_RANGES);
+    c->round_gen[r] = (int64_t)c->pinned[0];
+    c->round_ids_off[r] = c->round_ids_off[r - 1] + (size_t)c->round_gen[r - 1];
+    if (c->round_gen[r] == 0) return GS_OK;
+    if (c->round_ids_off[r] + (size_t)c->round_gen[r] > (size_t)c->n_inst) return fail(c, GS_ERR_HIP, "gs_forward: slab instance accounting out of range");
+    {
+        StageTimer t(c, GS_STAGE_TILE_SORT);
+        GsBin2Args b{};
+        b.n = nr; b.n_inst = c->round_gen[r]; b.gx = c->gx; b.lo_bits = c->lo_bits; b.hi_bits = c->hi_bits; b.gid_bits = c->gid_bits;
+        b.offsets = c->offsets_r.as<uint32_t>(); b.perm = perm; b.rect = c->rect_r.as<uint16_t>();
+        b.cs = c->cs.as<uint32_t>(); b.block_hist = c->table.as<uint32_t>(); b.digit_total = c->digit_total.as<uint32_t>();
+        b.buf_a = c->words.as<uint32_t>(); b.ids_out = c->ids.as<uint32_t>() + c->round_ids_off[r]; b.ballot_ranks = c->cfg.rank_mode != 0;
+        b.done = c->tile_done.as<uint8_t>(); b.live_total = c->live_total.as<uint32_t>() + r;
+        HIPCHK(c, gs_bin2_build_lists(b, c->stream));
+    }
+    return GS_OK;
+}
+
 int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_pre) return fail(c, GS_ERR_INVALID, "gs_bin: gs_preprocess first");
@@ -448,7 +555,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
         HIPCHK(c, gs_radix_sort_u64(c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, 32, 64, c->table.as<uint32_t>(),
                                     c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0, perm));
     }
-    c->perm_ptr = perm;
+    c->perm_ptr = perm; c->perm_all = perm;
     {
         StageTimer t(c, GS_STAGE_COUNT_SCAN);
         HIPCHK(c, c->offsets.ensure(sizeof(uint32_t) * (n + 1)));
@@ -462,22 +569,39 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     const int passes = (tile_bits + 7) / 8;
     const int lo_bits = passes <= 1 ? tile_bits : (tile_bits + 1) / 2, hi_bits = tile_bits - lo_bits;
     const bool fast = c->cfg.bin_path == 0 && passes <= 2 && hi_bits + gid_bits <= 32 && gs_tile_ranges_supported(c->gx, c->gy);
+    c->tile_bits = tile_bits; c->gid_bits = gid_bits; c->lo_bits = lo_bits; c->hi_bits = hi_bits; c->fast_bin = fast;
     HIPCHK(c, c->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)(ntiles ? ntiles : 1)));
-    // the one host read-back of the frame (the reference reads maxHits back, forward.jl:139).  Work that
-    // does not need the count (the tile ranges) is enqueued BEFORE the host waits, so the GPU stays busy
-    // while the host wakes up and launches the instance passes.
+    HIPCHK(c, c->counters.ensure(128));
+    // the slab plan needs the previous frame's walked share, which the read-back below delivers: the plan of THIS frame uses
+    // the share known so far (one frame of lag; only speed depends on it)
+    const int R = plan_rounds(c);
+    const int64_t n0 = c->slab_lo[1];                                       // list positions of round 0
+    // the one host read-back of the frame (the reference reads maxHits back, forward.jl:139): the instance count, the
+    // generated positions of round 0 and the previous frame's walked count.  Work that does not need the count (the tile
+    // ranges) is enqueued BEFORE the host waits, so the GPU stays busy while the host wakes up and launches the instance passes.
     HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pinned + 1, c->offsets.as<uint32_t>() + n0, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->prev_counters_valid) HIPCHK(c, hipMemcpyAsync(c->pinned + 2, c->counters.p, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
     if (fast) {
         HIPCHK(c, c->diff.ensure(sizeof(int) * gs_tile_ranges_scratch_ints(c->gx, c->gy)));
         StageTimer t(c, GS_STAGE_RANGES);
-        HIPCHK(c, gs_launch_tile_ranges(c->rect.as<uint16_t>(), c->n, c->diff.as<int>(), c->gx, c->gy, c->ranges.as<uint32_t>(), c->stream));
+        HIPCHK(c, gs_launch_tile_ranges(c->rect.as<uint16_t>(), R > 1 ? perm : nullptr, R > 1 ? n0 : c->n, c->diff.as<int>(), c->gx, c->gy,
+                                        c->ranges.as<uint32_t>(), nullptr, c->stream));
     }
     HIPCHK(c, hipEventSynchronize(c->ev_count));
     harvest_events(c, fast ? GS_STAGE_RANGES : -1);
     if (c->pinned[0] == 0xFFFFFFFFu)
         return fail(c, GS_ERR_UNSUPPORTED, "gs_bin: more than 2^32 - 2 tile instances (32-bit list offsets); reduce the scene or the image");
+    if (c->prev_counters_valid && c->prev_n_inst > 0) {
+        unsigned long long w = 0;
+        std::memcpy(&w, c->pinned + 2, sizeof(w));
+        c->walked_ratio = (double)w / (double)c->prev_n_inst;
+    }
+    c->prev_counters_valid = false;
     c->n_inst = (int64_t)c->pinned[0];
+    c->round_gen[0] = R > 1 ? (int64_t)c->pinned[1] : c->n_inst;
+    c->round_ids_off[0] = 0;
     const size_t ni1 = c->n_inst ? (size_t)c->n_inst : 1;
     HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
     HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 256));
@@ -490,7 +614,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
         {
             StageTimer t(c, GS_STAGE_TILE_SORT);
             GsBin2Args b{};
-            b.n = c->n; b.n_inst = c->n_inst; b.gx = c->gx; b.lo_bits = lo_bits; b.hi_bits = hi_bits; b.gid_bits = gid_bits;
+            b.n = n0; b.n_inst = c->round_gen[0]; b.gx = c->gx; b.lo_bits = lo_bits; b.hi_bits = hi_bits; b.gid_bits = gid_bits;
             b.offsets = c->offsets.as<uint32_t>(); b.perm = perm; b.rect = c->rect.as<uint16_t>();
             b.cs = c->cs.as<uint32_t>(); b.block_hist = c->table.as<uint32_t>(); b.digit_total = c->digit_total.as<uint32_t>();
             b.buf_a = c->words.as<uint32_t>(); b.ids_out = c->ids.as<uint32_t>(); b.ballot_ranks = c->cfg.rank_mode != 0;
@@ -528,26 +652,41 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(c, GS_ERR_INVALID, "gs_forward: bad mem");
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t px = (size_t)c->cam.W * c->cam.H;
+    const size_t ntiles = (size_t)c->gx * c->gy;
     HIPCHK(c, c->image.ensure(sizeof(float) * 3 * px));
     HIPCHK(c, c->trans.ensure(sizeof(float) * px));
-    GsCompositeArgs a{};
-    a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
-    a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
-    a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     HIPCHK(c, c->counters.ensure(128));
-    a.walked = c->counters.as<unsigned long long>();
-    a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
     HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 128, c->stream));         // work counters + both sets of ticket counters
-    if (int rc = composite_sched(c, a, 0)) return rc;
-    {
-        StageTimer t(c, GS_STAGE_COMPOSITE_FWD);                       // the kernel alone
-        HIPCHK(c, gs_launch_composite_fwd(a, c->stream));
+    const int R = c->n_rounds;
+    if (R > 1) {
+        HIPCHK(c, c->tile_pos.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
+        HIPCHK(c, c->tile_done.ensure(ntiles ? ntiles : 1));
+        HIPCHK(c, hipMemsetAsync(c->tile_pos.p, 0, sizeof(uint32_t) * ntiles, c->stream));
+    }
+    for (int r = 0; r < R; ++r) {
+        if (r > 0) { if (int rc = bin_round(c, r)) return rc; }
+        GsCompositeArgs a{};
+        a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
+        a.ranges = r == 0 ? c->ranges.as<uint32_t>() : c->ranges_r[r].as<uint32_t>();
+        a.ids = c->ids.as<uint32_t>() + c->round_ids_off[r]; a.payload = c->payload.as<GsPayload>();
+        a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
+        a.walked = c->counters.as<unsigned long long>();
+        a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
+        a.resume = r > 0; a.final_round = r == R - 1;
+        if (R > 1) { a.tile_pos = c->tile_pos.as<uint32_t>(); a.tile_done = c->tile_done.as<uint8_t>(); }
+        if (r > 0) HIPCHK(c, hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 32, c->stream));      // the forward's ticket counters
+        if (int rc = composite_sched(c, a, 0)) return rc;
+        {
+            StageTimer t(c, GS_STAGE_COMPOSITE_FWD);                       // the kernel alone
+            HIPCHK(c, gs_launch_composite_fwd(a, c->stream));
+        }
     }
     const hipMemcpyKind kind = mem == GS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     if (image) HIPCHK(c, hipMemcpyAsync(image, c->image.p, sizeof(float) * 3 * px, kind, c->stream));
     if (transmittance) HIPCHK(c, hipMemcpyAsync(transmittance, c->trans.p, sizeof(float) * px, kind, c->stream));
     if (mem == GS_MEM_HOST && (image || transmittance)) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->did_fwd = true; c->did_bwd = false; c->did_bwd_composite = false;
+    c->prev_counters_valid = true; c->prev_n_inst = c->n_inst;
     return GS_OK;
 }
 
@@ -575,6 +714,13 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
+    a.nseg = 0;
+    for (int r = 0; r < c->n_rounds; ++r) {
+        if (r > 0 && c->round_gen[r] == 0) continue;                       // a round that listed nothing
+        a.seg_ranges[a.nseg] = r == 0 ? c->ranges.as<uint32_t>() : c->ranges_r[r].as<uint32_t>();
+        a.seg_ids[a.nseg] = c->ids.as<uint32_t>() + c->round_ids_off[r];
+        ++a.nseg;
+    }
     a.dC = dC_dev; a.g2d = det ? nullptr : c->g2d.as<float>(); a.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
     a.walked = c->counters.as<unsigned long long>() + 2;
     a.variant = c->variant_bwd; a.cull = c->cfg.alpha_cull != 0;
@@ -795,6 +941,7 @@ int gs_grads_read(gs_ctx *c, const gs_grads *g, float *h_means, float *h_scales,
 
 int64_t gs_num_gaussians(const gs_ctx *c) { return c ? c->n : 0; }
 int64_t gs_num_instances(const gs_ctx *c) { return c ? c->n_inst : 0; }
+int gs_num_rounds(const gs_ctx *c) { return c ? c->n_rounds : 0; }
 
 int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
     if (!c || !dst) return GS_ERR_INVALID;
@@ -808,6 +955,8 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
     };
     if (which <= GS_ARR_TILE_RECT && !c->did_pre) return fail(c, GS_ERR_INVALID, "gs_get_array: gs_preprocess first");
     if (which >= GS_ARR_SORT_IDXS && which <= GS_ARR_SORTED_KEYS && !c->did_bin) return fail(c, GS_ERR_INVALID, "gs_get_array: gs_bin first");
+    if (which >= GS_ARR_TILE_RANGES && which <= GS_ARR_SORTED_KEYS && c->n_rounds > 1)
+        return fail(c, GS_ERR_INVALID, "gs_get_array: this frame was binned in depth slabs (lists spread over rounds); use gs_config.slab_mode = 0");
     switch (which) {
         case GS_ARR_TS: if (int r = need_dbg(0, 4)) return r; break;
         case GS_ARR_TPS: if (int r = need_dbg(1, 4)) return r; break;
@@ -923,6 +1072,14 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
     a.dC = c->last_dC; a.walked = nullptr;
+    a.final_round = 1;
+    a.nseg = 0;
+    for (int r = 0; r < c->n_rounds; ++r) {
+        if (r > 0 && c->round_gen[r] == 0) continue;
+        a.seg_ranges[a.nseg] = r == 0 ? c->ranges.as<uint32_t>() : c->ranges_r[r].as<uint32_t>();
+        a.seg_ids[a.nseg] = c->ids.as<uint32_t>() + c->round_ids_off[r];
+        ++a.nseg;
+    }
     a.g2d = c->cfg.deterministic ? nullptr : c->g2d.as<float>(); a.g2d_fixed = c->cfg.deterministic ? c->g2d.as<long long>() : nullptr;
     a.variant = variant % 100; a.map_mode = (variant / 100) % 10;
     a.cull = (c->cfg.alpha_cull != 0) != (variant >= 1000);                  // +1000: the other cull setting

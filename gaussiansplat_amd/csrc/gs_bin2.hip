@@ -33,14 +33,15 @@
 // the array into counts (2-D prefix sums in LDS) and the counts into [start,end) ranges.
 // (Global atomics on the ~8 K shared cells serialise: 4 M adds took 257 us on MI355X.)
 #define DIFF_BLOCKS 128
-__global__ __launch_bounds__(256) void rect_diff_kernel(const uint16_t *__restrict__ rect, int64_t n, int *__restrict__ partial, int pitch,
-                                                         int cells) {
+__global__ __launch_bounds__(256) void rect_diff_kernel(const uint16_t *__restrict__ rect, const uint32_t *__restrict__ perm, int64_t n,
+                                                         int *__restrict__ partial, int pitch, int cells) {
     extern __shared__ int ldiff[];
     for (int i = threadIdx.x; i < cells; i += 256) ldiff[i] = 0;
     __syncthreads();
     const int64_t per = (n + DIFF_BLOCKS - 1) / DIFF_BLOCKS;
     const int64_t g0 = (int64_t)blockIdx.x * per, g1 = min(n, g0 + per);
-    for (int64_t g = g0 + threadIdx.x; g < g1; g += 256) {
+    for (int64_t s = g0 + threadIdx.x; s < g1; s += 256) {
+        const int64_t g = perm ? (int64_t)perm[s] : s;               // a slab of the list: positions -> gaussian ids
         const uint2 r = reinterpret_cast<const uint2 *>(rect)[g];
         const int x0 = (int)(r.x & 0xFFFFu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xFFFFu), y1 = (int)(r.y >> 16);
         if (x0 == 0) continue;
@@ -65,7 +66,7 @@ __global__ void diff_sum_kernel(const int *__restrict__ partial, int *__restrict
 
 // one workgroup: 2-D prefix sums of the difference array (in LDS), then the exclusive scan over tile ids
 __global__ __launch_bounds__(1024) void ranges_from_diff_kernel(const int *__restrict__ diff, int pitch, int gx, int gy,
-                                                                 uint32_t *__restrict__ ranges) {
+                                                                 uint32_t *__restrict__ ranges, const uint8_t *__restrict__ done) {
     extern __shared__ int ld[];
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(1024) void ranges_from_diff_kernel(const int *__res
     const int ntiles = gx * gy;
     for (int b0 = 0; b0 < ntiles; b0 += 1024) {
         const int t = b0 + tid;
-        const uint32_t v = t < ntiles ? (uint32_t)ld[(t / gx) * pitch + (t % gx)] : 0u;
+        uint32_t v = t < ntiles ? (uint32_t)ld[(t / gx) * pitch + (t % gx)] : 0u;
+        if (done && t < ntiles && done[t]) v = 0u;                     // completed tiles take no instances in this round
         uint32_t incl = v;
 #pragma unroll
         for (int d = 1; d < GS_WAVE; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
@@ -106,7 +108,8 @@ __global__ __launch_bounds__(1024) void ranges_from_diff_kernel(const int *__res
 size_t gs_tile_ranges_scratch_ints(int gx, int gy) { return (size_t)(gx + 1) * (gy + 1) * (DIFF_BLOCKS + 1); }
 bool gs_tile_ranges_supported(int gx, int gy) { return (size_t)(gx + 1) * (gy + 1) * sizeof(int) <= 150 * 1024; }
 
-hipError_t gs_launch_tile_ranges(const uint16_t *rect, int64_t n, int *scratch, int gx, int gy, uint32_t *ranges, hipStream_t s) {
+hipError_t gs_launch_tile_ranges(const uint16_t *rect, const uint32_t *perm, int64_t n, int *scratch, int gx, int gy, uint32_t *ranges,
+                                 const uint8_t *done, hipStream_t s) {
     const int pitch = gx + 1, cells = pitch * (gy + 1);
     int *partial = scratch, *diff = scratch + (size_t)cells * DIFF_BLOCKS;
     const size_t lds = sizeof(int) * (size_t)cells;
@@ -115,9 +118,9 @@ hipError_t gs_launch_tile_ranges(const uint16_t *rect, int64_t n, int *scratch, 
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ranges_from_diff_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(rect_diff_kernel, dim3(DIFF_BLOCKS), dim3(256), lds, s, rect, n, partial, pitch, cells);
+    hipLaunchKernelGGL(rect_diff_kernel, dim3(DIFF_BLOCKS), dim3(256), lds, s, rect, perm, n, partial, pitch, cells);
     hipLaunchKernelGGL(diff_sum_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, partial, diff, cells);
-    hipLaunchKernelGGL(ranges_from_diff_kernel, dim3(1), dim3(1024), lds, s, diff, pitch, gx, gy, ranges);
+    hipLaunchKernelGGL(ranges_from_diff_kernel, dim3(1), dim3(1024), lds, s, diff, pitch, gx, gy, ranges, done);
     return hipGetLastError();
 }
 
@@ -146,6 +149,7 @@ struct ExpandArgs {
     int64_t n_inst;
     int gx, nchunks;
     int lo_bits, gid_bits;
+    const uint8_t *done;           // per tile: 1 = the tile completed in an earlier round, its instances are dropped (null: none)
 };
 
 #define EXP_RCAP 1024     // gaussians of a chunk whose records are staged in LDS (else: global loads)
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(RS_THREADS) void gen_hist_kernel(ExpandArgs a, uint
         if (li < cnt) {
             uint32_t tile, gid;
             expand_item(a, own, rec, staged, base, li, s_lo, tile, gid);
-            atomicAdd(&h[tile & mask], 1u);
+            if (!a.done || !a.done[tile]) atomicAdd(&h[tile & mask], 1u);
         }
     }
     __syncthreads();
@@ -273,7 +277,8 @@ __device__ __forceinline__ void rank_round(uint32_t dg, bool valid, int lane, vo
 }
 
 // per-wave exclusive offsets (wcnt), chunk digit prefix (lpre); call with all 256 threads
-__device__ __forceinline__ void digit_prefixes(uint32_t (*wcnt)[RS_RADIX], uint32_t *lpre, uint32_t *sm) {
+// returns the number of ranked keys of the chunk (== the chunk's key count unless instances were dropped)
+__device__ __forceinline__ uint32_t digit_prefixes(uint32_t (*wcnt)[RS_RADIX], uint32_t *lpre, uint32_t *sm) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint32_t tot = 0;
 #pragma unroll
@@ -283,10 +288,11 @@ __device__ __forceinline__ void digit_prefixes(uint32_t (*wcnt)[RS_RADIX], uint3
     for (int d = 1; d < GS_WAVE; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
     if (lane == 63) sm[w] = incl;
     __syncthreads();
-    uint32_t woff = 0;
-    for (int k = 0; k < w; ++k) woff += sm[k];
+    uint32_t woff = 0, all = 0;
+    for (int k = 0; k < RS_WAVES; ++k) { if (k < w) woff += sm[k]; all += sm[k]; }
     lpre[tid] = woff + incl - tot;
     __syncthreads();
+    return all;
 }
 
 template <bool ATOMIC_RANK>
@@ -310,23 +316,25 @@ __global__ __launch_bounds__(RS_THREADS) void gen_scatter_kernel(ExpandArgs a, c
     const bool staged = (s_end - s_lo) < EXP_RCAP;
     const uint32_t mask = (1u << a.lo_bits) - 1u;
     uint32_t val[RS_ITEMS], rank[RS_ITEMS], dgs[RS_ITEMS];
+    uint32_t vmask = 0;                                  // bit r: item r is a live instance (inside the chunk, tile not completed)
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const int li = w * (GS_WAVE * RS_ITEMS) + r * GS_WAVE + lane;
-        const bool valid = li < cnt;
+        bool valid = li < cnt;
         uint32_t tile = 0, gid = 0;
         if (valid) expand_item(a, own, rec, staged, base, li, s_lo, tile, gid);
+        if (valid && a.done && a.done[tile]) valid = false;
+        if (valid) vmask |= 1u << r;
         dgs[r] = valid ? (tile & mask) : (RS_RADIX - 1);
         val[r] = ((tile >> a.lo_bits) << a.gid_bits) | gid;
         if (ATOMIC_RANK) rank_round_atomic(dgs[r], valid, wcnt[w], rank[r]);
         else rank_round(dgs[r], valid, lane, wcnt[w], rank[r]);
     }
     __syncthreads();                                     // every wave is done reading own[] and rec[]
-    digit_prefixes(wcnt, lpre, sm);
+    const int nlive = (int)digit_prefixes(wcnt, lpre, sm);
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
-        const int li = w * (GS_WAVE * RS_ITEMS) + r * GS_WAVE + lane;
-        if (li < cnt) {
+        if (vmask & (1u << r)) {
             const uint32_t p = lpre[dgs[r]] + wcnt[w][dgs[r]] + rank[r];
             own[p] = val[r];
             sdg[p] = (uint8_t)dgs[r];
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(RS_THREADS) void gen_scatter_kernel(ExpandArgs a, c
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         const int li = r * RS_THREADS + tid;
-        if (li < cnt) {
+        if (li < nlive) {
             const uint32_t dg = sdg[li];
             out[(size_t)gbase[dg] + (uint32_t)(li - (int)lpre[dg])] = own[li];
         }
@@ -344,9 +352,12 @@ __global__ __launch_bounds__(RS_THREADS) void gen_scatter_kernel(ExpandArgs a, c
 }
 
 // ---------------------------------------------------------------- 32-bit radix pass (high tile digit)
+// n_dev != null: the key count is read from the device (a round whose live-instance count is only known there); the
+// launch then covers an upper bound and the surplus workgroups contribute empty histograms / write nothing
 __global__ __launch_bounds__(RS_THREADS) void rs32_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift, uint32_t mask,
-                                                                uint32_t *__restrict__ block_hist, int nblocks) {
+                                                                uint32_t *__restrict__ block_hist, int nblocks, const uint32_t *__restrict__ n_dev) {
     __shared__ uint32_t h[RS_RADIX];
+    if (n_dev) n = (int64_t)*n_dev;
     h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
@@ -362,15 +373,17 @@ __global__ __launch_bounds__(RS_THREADS) void rs32_hist_kernel(const uint32_t *_
 template <bool ATOMIC_RANK>
 __global__ __launch_bounds__(RS_THREADS) void rs32_scatter_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int64_t n,
                                                                    int shift, uint32_t mask, uint32_t out_mask,
-                                                                   const uint32_t *__restrict__ block_hist, int nblocks) {
+                                                                   const uint32_t *__restrict__ block_hist, int nblocks,
+                                                                   const uint32_t *__restrict__ n_dev) {
     __shared__ uint32_t skeys[RS_CHUNK];
+    if (n_dev) n = (int64_t)*n_dev;
     __shared__ uint32_t wcnt[RS_WAVES][RS_RADIX];
     __shared__ uint32_t lpre[RS_RADIX];
     __shared__ uint32_t gbase[RS_RADIX];
     __shared__ uint32_t sm[RS_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
-    const int cnt = (int)min((int64_t)RS_CHUNK, n - base);
+    const int cnt = (int)max((int64_t)0, min((int64_t)RS_CHUNK, n - base));
 #pragma unroll
     for (int k = 0; k < RS_WAVES; ++k) wcnt[k][tid] = 0;
     gbase[tid] = block_hist[(size_t)tid * nblocks + blockIdx.x];
@@ -407,6 +420,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs32_scatter_kernel(const uint32_t
     }
 }
 
+// live instances of a round = sum of the first pass's digit totals (instances of completed tiles were never counted)
+__global__ void sum_digit_totals_kernel(const uint32_t *__restrict__ digit_total, uint32_t *__restrict__ out) {
+    uint32_t v = 0;
+    for (int i = threadIdx.x; i < RS_RADIX; i += 64) v += digit_total[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    if (threadIdx.x == 0) *out = v;
+}
+
 // ---------------------------------------------------------------- driver
 hipError_t gs_bin2_build_lists(const GsBin2Args &b, hipStream_t s) {
     if (b.n_inst <= 0) return hipSuccess;
@@ -414,24 +436,26 @@ hipError_t gs_bin2_build_lists(const GsBin2Args &b, hipStream_t s) {
     hipLaunchKernelGGL(chunk_owner_kernel, dim3((nchunks + 1 + 255) / 256), dim3(256), 0, s, b.offsets, b.n, b.n_inst, b.cs, nchunks);
     ExpandArgs a{};
     a.offsets = b.offsets; a.perm = b.perm; a.rect = b.rect; a.cs = b.cs; a.n_inst = b.n_inst; a.gx = b.gx; a.nchunks = nchunks;
-    a.lo_bits = b.lo_bits; a.gid_bits = b.gid_bits;
+    a.lo_bits = b.lo_bits; a.gid_bits = b.gid_bits; a.done = b.done;
     hipLaunchKernelGGL(gen_hist_kernel, dim3(nchunks), dim3(RS_THREADS), 0, s, a, b.block_hist);
     hipError_t e = gs_launch_radix_scan(b.block_hist, nchunks, b.digit_total, s);
     if (e != hipSuccess) return e;
+    if (b.live_total) hipLaunchKernelGGL(sum_digit_totals_kernel, dim3(1), dim3(64), 0, s, b.digit_total, b.live_total);
     uint32_t *first_out = b.hi_bits > 0 ? b.buf_a : b.ids_out;
     if (b.ballot_ranks) hipLaunchKernelGGL(gen_scatter_kernel<false>, dim3(nchunks), dim3(RS_THREADS), 0, s, a, b.block_hist, first_out);
     else hipLaunchKernelGGL(gen_scatter_kernel<true>, dim3(nchunks), dim3(RS_THREADS), 0, s, a, b.block_hist, first_out);
     if (b.hi_bits > 0) {
         const uint32_t hmask = (1u << b.hi_bits) - 1u, gmask = b.gid_bits >= 32 ? 0xFFFFFFFFu : ((1u << b.gid_bits) - 1u);
-        hipLaunchKernelGGL(rs32_hist_kernel, dim3(nchunks), dim3(RS_THREADS), 0, s, b.buf_a, b.n_inst, b.gid_bits, hmask, b.block_hist, nchunks);
+        hipLaunchKernelGGL(rs32_hist_kernel, dim3(nchunks), dim3(RS_THREADS), 0, s, b.buf_a, b.n_inst, b.gid_bits, hmask, b.block_hist, nchunks,
+                           (const uint32_t *)b.live_total);
         e = gs_launch_radix_scan(b.block_hist, nchunks, b.digit_total, s);
         if (e != hipSuccess) return e;
         if (b.ballot_ranks)
             hipLaunchKernelGGL(rs32_scatter_kernel<false>, dim3(nchunks), dim3(RS_THREADS), 0, s, b.buf_a, b.ids_out, b.n_inst, b.gid_bits, hmask,
-                               gmask, b.block_hist, nchunks);
+                               gmask, b.block_hist, nchunks, (const uint32_t *)b.live_total);
         else
             hipLaunchKernelGGL(rs32_scatter_kernel<true>, dim3(nchunks), dim3(RS_THREADS), 0, s, b.buf_a, b.ids_out, b.n_inst, b.gid_bits, hmask,
-                               gmask, b.block_hist, nchunks);
+                               gmask, b.block_hist, nchunks, (const uint32_t *)b.live_total);
     }
     return hipGetLastError();
 }

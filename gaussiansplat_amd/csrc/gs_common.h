@@ -87,6 +87,11 @@ hipError_t gs_launch_unpack_perm(const uint64_t *pairs, uint32_t *perm, int64_t 
 // into offsets[0..n]; offsets[n] = total instances.
 hipError_t gs_launch_count_scan(const uint16_t *rect, const uint32_t *perm, uint32_t *offsets,
                                 uint32_t *block_sums, int64_t n, hipStream_t s);
+// later rounds of a slab frame: 2-D prefix sums of the live (not completed) tiles, and the count/scan pass that drops the
+// gaussians whose rectangle holds no live tile (rect_out, indexed by gaussian id, receives the rectangles of the round)
+hipError_t gs_launch_live_prefix(const uint8_t *done, int gx, int gy, uint32_t *live2d, uint32_t *rowp_scratch, hipStream_t s);
+hipError_t gs_launch_count_scan_live(const uint16_t *rect, const uint32_t *perm, const uint32_t *live2d, int gx, uint16_t *rect_out,
+                                     uint32_t *offsets, uint32_t *block_sums, int64_t n, hipStream_t s);
 hipError_t gs_launch_emit(const uint16_t *rect, const uint32_t *perm, const uint32_t *offsets,
                           uint64_t *inst, int64_t n, int gx, hipStream_t s);
 hipError_t gs_launch_ranges(const uint64_t *inst, int64_t n_inst, uint32_t *ranges, int64_t n_tiles,
@@ -98,7 +103,10 @@ hipError_t gs_launch_radix_scan(uint32_t *block_hist, int nblocks, uint32_t *dig
 // low-traffic binning (gs_bin2.hip)
 size_t gs_tile_ranges_scratch_ints(int gx, int gy);
 bool gs_tile_ranges_supported(int gx, int gy);          // difference array must fit in LDS
-hipError_t gs_launch_tile_ranges(const uint16_t *rect, int64_t n, int *scratch, int gx, int gy, uint32_t *ranges, hipStream_t s);
+// rect is indexed by gaussian id; perm (may be null = identity) maps the n list positions of the slab to gaussian ids;
+// done (may be null): tiles with done[t] != 0 get an empty range
+hipError_t gs_launch_tile_ranges(const uint16_t *rect, const uint32_t *perm, int64_t n, int *scratch, int gx, int gy, uint32_t *ranges,
+                                 const uint8_t *done, hipStream_t s);
 struct GsBin2Args {
     int64_t n, n_inst;
     int gx;
@@ -110,9 +118,13 @@ struct GsBin2Args {
     uint32_t *buf_a;                  // n_inst words (pass-1 output)
     uint32_t *ids_out;                // n_inst gaussian ids in (tile, list order)
     bool ballot_ranks;                // portable ballot ranking instead of the LDS-atomic rank
+    const uint8_t *done;              // later rounds of a slab frame: tiles completed earlier take no instances (null: none)
+    uint32_t *live_total;             // with `done`: device word receiving the number of instances actually listed; the second
+                                      // pass then reads its key count from it (n_inst is only the upper bound used for grids)
 };
 hipError_t gs_bin2_build_lists(const GsBin2Args &b, hipStream_t s);
 
+#define GS_MAX_ROUNDS 4   // binning rounds (depth slabs) of one frame
 #define GS_G2D_STRIDE 10   // floats (or fixed-point words) per gaussian row of the composite backward's sums
 struct GsCompositeArgs {
     int W, H, gx, gy;
@@ -139,6 +151,14 @@ struct GsCompositeArgs {
     uint32_t *tile_work;       // forward: evaluated entries per tile (the backward's exact work measure); may be null
     unsigned long long *tile_clock; // debug: per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated}
     int grid_waves;            // waves to launch in queue mode
+    // frames binned in depth slabs (several rounds of binning + forward)
+    int nseg;                  // backward: number of list segments per tile (= rounds of the frame, >= 1)
+    const uint32_t *seg_ranges[GS_MAX_ROUNDS];   // backward: per round 2 x tiles [start, end) into seg_ids[round]
+    const uint32_t *seg_ids[GS_MAX_ROUNDS];
+    uint32_t *tile_pos;        // forward: per tile, list position reached by the earlier rounds (read, then += this round's segment); may be null
+    uint8_t *tile_done;        // forward: per tile, 1 = every pixel frozen (written each round; read when `resume`); may be null
+    int resume;                // forward: continue from the pixel state the previous round left in image / trans
+    int final_round;           // forward: last round of the frame: transmittance is written plain (no sign flag)
 };
 // tiles in decreasing order of work[] (a 256-bucket counting sort of work / max; one workgroup)
 hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s);

@@ -188,6 +188,13 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     unsigned long long clk0 = 0;
     if (a.tile_clock) clk0 = __builtin_amdgcn_s_memrealtime();
 
+    // Slab frames (binning in depth slabs): the tile's list arrives in several rounds.  A later round resumes the
+    // pixel state the previous one left in image / trans (a frozen pixel is stored as -T, its sign is the flag), continues
+    // the list position (tile_pos) so that the 64-entry batch boundaries -- where the early-out rule freezes pixels -- stay
+    // those of the whole list, and a tile whose pixels are all frozen is marked done and takes no further instances.
+    if (a.resume && a.tile_done[tile]) return;
+    const uint32_t gp0 = a.tile_pos ? a.tile_pos[tile] : 0u;
+    const size_t plane = (size_t)a.W * a.H;
     float Cr[4], Cg[4], Cb[4], T[4], Tdead[4], fy[4];
     bool dead[4];
     uint32_t walked = 0, evaluated = 0;
@@ -198,14 +205,24 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         const bool in = (px <= a.W && py0 + 4 * p <= a.H);
         T[p] = in ? 1.0f : 0.0f;
         Tdead[p] = 0.0f; dead[p] = !in;
+        if (a.resume && in) {
+            const size_t o = (size_t)(px - 1) + (size_t)a.W * (py0 + 4 * p - 1);
+            Cr[p] = a.image[o]; Cg[p] = a.image[o + plane]; Cb[p] = a.image[o + 2 * plane];
+            const float t = a.trans[o];
+            dead[p] = (__float_as_uint(t) >> 31) != 0u;
+            Tdead[p] = fabsf(t);
+            T[p] = dead[p] ? 0.0f : t;
+        }
     }
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t pos = s0 + lane;
     if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
-    for (uint32_t base = s0; base < s1; base += CB) {
-        const int cnt = (int)min((uint32_t)CB, s1 - base);
-        if (EARLY) {
+    uint32_t gp = gp0;                                                  // list position of `base` in the tile's whole list
+    for (uint32_t base = s0; base < s1;) {
+        const uint32_t phase = gp & (CB - 1);
+        const int cnt = (int)min((uint32_t)CB - phase, s1 - base);      // batches end at multiples of CB of the WHOLE list
+        if (EARLY && phase == 0) {
             bool live = false;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -229,7 +246,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             syhi[slot] = yhi_l;
         }
         __syncthreads();
-        pos = base + CB + lane;
+        base += (uint32_t)cnt; gp += (uint32_t)cnt;
+        pos = base + lane;
         if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
 #pragma unroll 2
         for (int k = 0; k < nk; ++k) {
@@ -252,19 +270,25 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
     }
+    bool anylive = false;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) anylive = anylive || !dead[p];
+    const bool all_dead = __ballot(anylive) == 0ull;                    // complete: no pixel takes anything further
+    const bool plain = a.final_round || all_dead;                       // else frozen pixels are stored as -T for the next round
     if (lane == 0) {
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
-        if (a.tile_work) a.tile_work[tile] = evaluated;
+        if (a.tile_work) a.tile_work[tile] = a.resume ? a.tile_work[tile] + evaluated : evaluated;
+        if (a.tile_done) a.tile_done[tile] = all_dead ? 1 : 0;
+        if (a.tile_pos) a.tile_pos[tile] = gp0 + (s1 - s0);
     }
     if (px <= a.W) {
-        const size_t plane = (size_t)a.W * a.H;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int py = py0 + 4 * p;
             if (py <= a.H) {
                 const size_t o = (size_t)(px - 1) + (size_t)a.W * (py - 1);
                 if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p]; }
-                if (a.trans) a.trans[o] = (EARLY && dead[p]) ? Tdead[p] : T[p];
+                if (a.trans) a.trans[o] = (EARLY && dead[p]) ? (plain ? Tdead[p] : -Tdead[p]) : T[p];
             }
         }
     }
@@ -435,7 +459,6 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
     const float fx = (float)px;
-    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
     const size_t plane = (size_t)a.W * a.H;
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);
     unsigned long long clk0 = 0;
@@ -469,8 +492,6 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t nid = 0;
-    uint32_t pos = s0 + lane;
-    if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
     // pipeline state of the transposed reduction: the sixteen partials read back for the previous entry
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
     uint32_t pend_gid = 0;
@@ -486,16 +507,26 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         if (ocomp_t >= 0) add_to_row<DET>(a, pend_gid, ocomp_t, s);
 #endif
     };
-    for (uint32_t base = s0; base < s1; base += CB) {
-        const int cnt = (int)min((uint32_t)CB, s1 - base);
-        if (EARLY) {
+    // The tile's list is the concatenation of its segments, one per binning round of the frame (one segment unless the
+    // frame was binned in depth slabs); batches end at multiples of CB of the WHOLE list, as in the forward.
+    uint32_t gp = 0;
+    bool stop = false;
+    for (int sg = 0; sg < a.nseg && !stop; ++sg) {
+    const uint32_t *ids = a.seg_ids[sg];
+    const uint32_t s0 = a.seg_ranges[sg][2 * tile], s1 = a.seg_ranges[sg][2 * tile + 1];
+    uint32_t pos = s0 + lane;
+    if (pos < s1) { nid = ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+    for (uint32_t base = s0; base < s1;) {
+        const uint32_t phase = gp & (CB - 1);
+        const int cnt = (int)min((uint32_t)CB - phase, s1 - base);
+        if (EARLY && phase == 0) {
             bool live = false;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 if (!dead[p] && T[p] < a.t_min) { dead[p] = true; T[p] = 0.0f; S[p] = 0.0f; }
                 live = live || !dead[p];
             }
-            if (__ballot(live) == 0ull) break;
+            if (__ballot(live) == 0ull) { stop = true; break; }
         }
         float4 q0, q1, q2;
         bool keep;
@@ -513,8 +544,9 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             sid[slot] = nid;                                             // gaussian id of the staged entry
         }
         __syncthreads();
-        pos = base + CB + lane;
-        if (pos < s1) { nid = a.ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+        base += (uint32_t)cnt; gp += (uint32_t)cnt;
+        pos = base + lane;
+        if (pos < s1) { nid = ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
         if (RED == 2) {
             // software pipeline: arithmetic of entry k | loads of entry k+1 | sums + atomic of entry k-1 (its sixteen
             // partials were read back during the arithmetic) | partials of entry k -> LDS, read back transposed
@@ -584,6 +616,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             }
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
+    }
     }
     if (RED == 2 && pend) finish();
     if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }

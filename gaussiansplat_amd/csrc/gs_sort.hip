@@ -377,6 +377,92 @@ __global__ __launch_bounds__(SC_THREADS) void count_scan_kernel(int64_t n, const
     }
 }
 
+// ---------------------------------------------------------------- later rounds of a slab frame
+// live2d[y * (gx + 1) + x] = number of NOT completed tiles with tx < x and ty < y (0-based): 2-D prefix sums with a zero
+// border, from the per-tile done flags the forward of the previous round wrote.  Two small kernels: one wave per tile row
+// (shuffle scan along x), then one thread per column adding the rows up (independent loads, coalesced across the columns).
+__global__ __launch_bounds__(256) void live_rows_kernel(const uint8_t *__restrict__ done, int gx, int gy, uint32_t *__restrict__ rowp) {
+    const int lane = threadIdx.x & 63, y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= gy) return;
+    const int pitch = gx + 1;
+    uint32_t carry = 0;
+    if (lane == 0) rowp[(y + 1) * pitch] = 0;
+    for (int x0 = 0; x0 < gx; x0 += 64) {
+        const int x = x0 + lane;
+        const uint32_t v = (x < gx && !done[y * gx + x]) ? 1u : 0u;
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (x < gx) rowp[(y + 1) * pitch + x + 1] = carry + incl;
+        carry += __shfl(incl, 63);
+    }
+}
+__global__ __launch_bounds__(256) void live_cols_kernel(const uint32_t *__restrict__ rowp, int gx, int gy, uint32_t *__restrict__ live2d) {
+    const int x = blockIdx.x * 256 + threadIdx.x, pitch = gx + 1;
+    if (x > gx) return;
+    live2d[x] = 0;
+    uint32_t acc = 0;
+#pragma unroll 8
+    for (int y = 1; y <= gy; ++y) { acc += rowp[y * pitch + x]; live2d[y * pitch + x] = acc; }
+}
+hipError_t gs_launch_live_prefix(const uint8_t *done, int gx, int gy, uint32_t *live2d, uint32_t *rowp_scratch, hipStream_t s) {
+    hipLaunchKernelGGL(live_rows_kernel, dim3((gy + 3) / 4), dim3(256), 0, s, done, gx, gy, rowp_scratch);
+    hipLaunchKernelGGL(live_cols_kernel, dim3((gx + 1 + 255) / 256), dim3(256), 0, s, rowp_scratch, gx, gy, live2d);
+    return hipGetLastError();
+}
+
+// count pass of a later round: a gaussian whose tile rectangle holds no live tile drops out of the round (its entry of
+// rect_out becomes the empty rectangle); the others are shrunk to the bounding box of the live tiles inside their
+// rectangle (four binary searches on the 2-D prefix sums), so that the generate passes enumerate as few completed tiles as
+// possible -- the instances of the completed tiles that remain inside the box are dropped there (gs_bin2.hip, ExpandArgs.done).
+__device__ __forceinline__ uint32_t live_count(const uint32_t *__restrict__ L, int pitch, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1) {
+    return L[y1 * pitch + x1] - L[(y0 - 1) * pitch + x1] - L[y1 * pitch + (x0 - 1)] + L[(y0 - 1) * pitch + (x0 - 1)];   // 1-based inclusive
+}
+__global__ __launch_bounds__(SC_THREADS) void count_reduce_live_kernel(const uint16_t *__restrict__ rect, const uint32_t *__restrict__ perm,
+                                                                        int64_t n, const uint32_t *__restrict__ live2d, int gx,
+                                                                        uint16_t *__restrict__ rect_out, uint32_t *__restrict__ block_sums,
+                                                                        uint32_t *__restrict__ counts) {
+    __shared__ uint32_t sm[SC_THREADS / GS_WAVE];
+    const int64_t base = (int64_t)blockIdx.x * SC_CHUNK;
+    const int pitch = gx + 1;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SC_ITEMS; ++i) {
+        const int64_t idx = base + (int64_t)i * SC_THREADS + threadIdx.x;
+        if (idx < n) {
+            const int64_t g = perm ? (int64_t)perm[idx] : idx;
+            uint2 r = reinterpret_cast<const uint2 *>(rect)[g];
+            uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu, y1 = r.y >> 16;
+            uint32_t c = 0;
+            if (x0 != 0u && live_count(live2d, pitch, x0, x1, y0, y1) != 0u) {
+                uint32_t lo = y0, hi = y1;                               // first live row
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (live_count(live2d, pitch, x0, x1, y0, mid)) hi = mid; else lo = mid + 1; }
+                y0 = lo; hi = y1;                                        // last live row
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (live_count(live2d, pitch, x0, x1, mid, y1)) lo = mid; else hi = mid - 1; }
+                y1 = lo;
+                lo = x0; hi = x1;                                        // first / last live column inside those rows
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (live_count(live2d, pitch, x0, mid, y0, y1)) hi = mid; else lo = mid + 1; }
+                x0 = lo; hi = x1;
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (live_count(live2d, pitch, mid, x1, y0, y1)) lo = mid; else hi = mid - 1; }
+                x1 = lo;
+                c = (x1 - x0 + 1u) * (y1 - y0 + 1u);
+                r = make_uint2(x0 | (x1 << 16), y0 | (y1 << 16));
+            } else r = make_uint2(0u, 0u);
+            reinterpret_cast<uint2 *>(rect_out)[g] = r;
+            counts[idx] = c; s += c;
+        }
+    }
+    s = block_reduce_u32(s, sm);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+}
+hipError_t gs_launch_count_scan_live(const uint16_t *rect, const uint32_t *perm, const uint32_t *live2d, int gx, uint16_t *rect_out,
+                                     uint32_t *offsets, uint32_t *block_sums, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipMemsetAsync(offsets, 0, sizeof(uint32_t), s);
+    const int nb = (int)((n + SC_CHUNK - 1) / SC_CHUNK);
+    hipLaunchKernelGGL(count_reduce_live_kernel, dim3(nb), dim3(SC_THREADS), 0, s, rect, perm, n, live2d, gx, rect_out, block_sums, offsets);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, offsets + n);
+    hipLaunchKernelGGL(count_scan_kernel, dim3(nb), dim3(SC_THREADS), 0, s, n, block_sums, offsets);
+    return hipGetLastError();
+}
+
 hipError_t gs_launch_count_scan(const uint16_t *rect, const uint32_t *perm, uint32_t *offsets, uint32_t *block_sums,
                                 int64_t n, hipStream_t s) {
     if (n <= 0) return hipMemsetAsync(offsets, 0, sizeof(uint32_t), s);

@@ -93,7 +93,14 @@ typedef struct {
                                  and 2 balance the SIMDs (work max/mean 1.04 vs 1.17) but scatter the tiles in flight over the
                                  image, and the lost L2 reuse costs far more (forward 0.72 vs 0.37 ms).  Speed only: every mode
                                  gives the same image and (up to atomic order) gradients                                  */
-    int32_t reserved[5];
+    int32_t slab_mode;        /* binning in depth slabs (speed only; image, transmittance and deterministic-mode gradients are
+                                 bit-identical either way): 1 (default) automatic -- when the previous frame walked under 15 % of
+                                 its tile instances before the transmittance early-out stopped every tile, the next frame is
+                                 binned in three rounds over slabs of the depth order and only the tiles still open take the later
+                                 slabs; 0 always one round (the classic full lists).  In a slab frame the per-tile lists are
+                                 spread over the rounds, so GS_ARR_TILE_RANGES / SORTED_IDS / SORTED_KEYS are unavailable (a
+                                 ctx's first frame is always a classic one).                                              */
+    int32_t reserved[4];
 } gs_config;
 
 typedef struct gs_ctx gs_ctx;
@@ -251,6 +258,7 @@ typedef enum {
 
 int64_t gs_num_gaussians(const gs_ctx *ctx);
 int64_t gs_num_instances(const gs_ctx *ctx);      /* I of the last gs_bin */
+int gs_num_rounds(const gs_ctx *ctx);             /* binning rounds of the last gs_bin: 1 = classic full lists, 2..4 = depth slabs */
 
 /* Copy an internal array to a HOST buffer of `bytes` bytes (synchronises). */
 int gs_get_array(gs_ctx *ctx, int which, void *host_dst, int64_t bytes);

@@ -30,7 +30,8 @@ mutable struct GsConfig                      # must mirror gs_config (64 bytes)
     rank_mode::Int32
     alpha_cull::Int32
     schedule::Int32
-    reserved::NTuple{5, Int32}
+    slab_mode::Int32
+    reserved::NTuple{4, Int32}
 end
 
 struct GsGrads                               # gs_grads: device pointers, may be C_NULL
@@ -56,7 +57,7 @@ function check(r::HipRenderer, rc::Cint)
 end
 
 function defaultConfig()
-    cfg = GsConfig(0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, ntuple(_ -> Int32(0), 5))
+    cfg = GsConfig(0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, ntuple(_ -> Int32(0), 4))
     ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
     return cfg
 end
@@ -197,6 +198,7 @@ hip_commDestroy(r::HipRenderer) = check(r, ccall((:gs_comm_destroy, libgs), Cint
 hip_numGaussians(r::HipRenderer) = ccall((:gs_num_gaussians, libgs), Int64, (Ptr{Cvoid},), r.ctx)
 hip_numInstances(r::HipRenderer) = ccall((:gs_num_instances, libgs), Int64, (Ptr{Cvoid},), r.ctx)
 hip_abiVersion() = ccall((:gs_abi_version, libgs), Cint, ())
+hip_numRounds(r::HipRenderer) = ccall((:gs_num_rounds, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 
 # renderer scratch arrays (gs_array ids of include/gsplat.h; e.g. 11 = sortIdxs, 12 = tile ranges, 13 = sorted ids) into a host array
 function hip_getArray!(r::HipRenderer, which::Integer, dst::Array)
