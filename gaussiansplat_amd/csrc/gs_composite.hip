@@ -49,7 +49,7 @@
 #define GS_ABL 0
 #endif
 #ifndef GS_BWD3_MINW
-#define GS_BWD3_MINW 1              // __launch_bounds__ waves/SIMD of backward body 3 (diagnostic builds raise it)
+#define GS_BWD3_MINW 5              // __launch_bounds__ waves/SIMD of backward body 3: 96 VGPRs (unconstrained: 104 -> 4 waves)
 #endif
 #include <cstdlib>
 #define CB 64                       // splats staged per batch
@@ -138,8 +138,13 @@ __device__ __forceinline__ bool rect_can_contribute(float A, float B, float C, f
 }
 
 // keep = false: the whole (tile, splat) entry is a no-op (gs_config.alpha_cull).
+// STRIPS (backward): additionally, bit p of `strips` = the 16 x 4 pixel strip p of the tile (rows 4p .. 4p+3: the pixels the
+// lanes hold in slot p) can reach alpha >= 2^-27 somewhere.  The backward skips the dead strips of an entry with wave-uniform
+// branches: at C3 24 % of the strips of the evaluated entries are dead.  `keep` is the same tile-level test in both kernels, so
+// forward and backward evaluate the same entries.
+template <bool STRIPS>
 __device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2,
-                                              const int tx0, const int ty0, bool &keep) {
+                                              const int tx0, const int ty0, bool &keep, uint32_t &strips) {
     const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
     const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
     const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
@@ -158,7 +163,17 @@ __device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2
         const bool concave = A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f;
         const float rx0 = (float)max(tx0, xmin) - n0.x, rx1 = (float)min(tx0 + GS_TILE - 1, xmax) - n0.x;
         const float ry0 = (float)max(ty0, ymin) - n0.y, ry1 = (float)min(ty0 + GS_TILE - 1, ymax) - n0.y;
-        keep = !empty && rect_can_contribute(A, B, C, 0.5f * B * fast_rcp(A), 0.5f * B * fast_rcp(C), concave, l2s, rx0, rx1, ry0, ry1);
+        const float hBrA = 0.5f * B * fast_rcp(A), hBrC = 0.5f * B * fast_rcp(C);
+        keep = !empty && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, ry0, ry1);
+        strips = 0xFu;
+        if (STRIPS) {
+            strips = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float sy0 = (float)max(ty0 + 4 * p, ymin) - n0.y, sy1 = (float)min(ty0 + 4 * p + 3, ymax) - n0.y;
+                if (keep && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, sy0, sy1)) strips |= 1u << p;
+            }
+        }
     }
     return yhi;
 }
@@ -178,6 +193,8 @@ __device__ __forceinline__ Entry load_entry(const float4 *sp, const float *syhi,
 
 // ---------------------------------------------------------------- forward
 template <bool EARLY, bool CULL>
+// (Skipping the dead 16 x 4 strips of an entry with wave-uniform branches, as the backward does, was measured on the forward
+// too: 0.352 vs 0.357 ms at C3 -- its per-strip work is a 12-instruction dependent chain, the branches cost what they save.)
 __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
@@ -232,14 +249,16 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             if (__ballot(live) == 0ull) break;
         }
         float4 q0, q1, q2;
+        uint32_t strips;
         bool keep;
-        const float yhi_l = stage_record(q0, q1, q2, n0, n1, n2, tx0, ty0, keep);
+        const float yhi_l = stage_record<false>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
         int slot = lane, nk = cnt;
+        if (!CULL) keep = true;
         if (CULL) {                                                     // compact the batch to the entries that can matter
             keep = keep && lane < cnt;
             const uint64_t m = __ballot(keep);
             slot = slot_of(m); nk = __popcll(m);
-        } else keep = true;
+        }
         __syncthreads();                                                // one wave: orders LDS reads/writes only
         if (keep) {
             sp[3 * slot] = q0; sp[3 * slot + 1] = q1; sp[3 * slot + 2] = q2;
@@ -386,10 +405,10 @@ __device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__bui
 // order independent, so the gradients are bitwise reproducible run to run); otherwise float atomics.
 
 // per-pixel arithmetic of one entry: updates T, S; returns the lane's nine partial sums
-// v = {dr, dg, db, S0, Sx, Sy, Sxx, Sxy, Syy}
+// v = {dr, dg, db, S0, Sx, Sy, Sxx, Sxy, Syy}.  live: wave-uniform 4-bit mask of the strips (pixel slots) the entry can touch.
 __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, const float (&fy)[4], const float nbig,
                                                const float (&dCr)[4], const float (&dCg)[4], const float (&dCb)[4],
-                                               float (&T)[4], float (&S)[4], float (&v)[9], bool &any) {
+                                               float (&T)[4], float (&S)[4], float (&v)[9], bool &any, const uint32_t live) {
     const float dX = fx - e.q0.x;
 #if GS_ABL & 16
     const float A0 = fmaf(e.q1.x * dX, dX, e.q0.z);
@@ -398,46 +417,39 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
     const float A0 = fmaf(nbig, fabsf(ex), fmaf(e.q1.x * dX, dX, e.q0.z));
 #endif
     const float B0 = e.q1.y * dX;
-    float al[4], dY[4];
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f, q0s = 0.0f, q1s = 0.0f, q2s = 0.0f, asum = 0.0f;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        dY[p] = fy[p] - e.q0.y;
+        if (!((live >> p) & 1u)) continue;                        // wave-uniform branch: a dead strip costs nothing
+        const float dY = fy[p] - e.q0.y;
 #if GS_ABL & 16
-        const float xp = fmaf(dY[p], fmaf(e.q1.z, dY[p], B0), A0);
+        const float xp = fmaf(dY, fmaf(e.q1.z, dY, B0), A0);
 #else
-        const float ey = dY[p] - __builtin_amdgcn_fmed3f(dY[p], e.q2.w, e.yhi);
-        const float xp = fmaf(nbig, fabsf(ey), fmaf(dY[p], fmaf(e.q1.z, dY[p], B0), A0));
+        const float ey = dY - __builtin_amdgcn_fmed3f(dY, e.q2.w, e.yhi);
+        const float xp = fmaf(nbig, fabsf(ey), fmaf(dY, fmaf(e.q1.z, dY, B0), A0));
 #endif
 #if GS_ABL & 8
-        al[p] = xp * 1.0e-3f;
+        const float al = xp * 1.0e-3f;
 #else
-        al[p] = fast_exp2(xp);
+        const float al = fast_exp2(xp);
 #endif
-    }
-    any = ((al[0] + al[1]) + (al[2] + al[3])) != 0.0f;
-    float ar, ag, ab, q0s, q1s, q2s;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float w = al[p] * T[p];
+        asum += al;
+        const float w = al * T[p];
         const float cdot = fmaf(e.q2.x, dCr[p], fmaf(e.q2.y, dCg[p], e.q2.z * dCb[p]));
         S[p] = fmaf(-cdot, w, S[p]);
 #if GS_ABL & 8
-        const float inv = (1.0f - al[p]) * 0.5f;
+        const float inv = (1.0f - al) * 0.5f;
 #else
-        const float inv = fast_rcp(1.0f - al[p]);
+        const float inv = fast_rcp(1.0f - al);
 #endif
         const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));
-        const float dd = -(al[p] * dalpha);
-        const float ddy = dd * dY[p];
-        if (p == 0) {                                             // plain products: no fma against a zero
-            ar = w * dCr[0]; ag = w * dCg[0]; ab = w * dCb[0];
-            q0s = dd; q1s = ddy; q2s = ddy * dY[0];
-        } else {
-            ar = fmaf(w, dCr[p], ar); ag = fmaf(w, dCg[p], ag); ab = fmaf(w, dCb[p], ab);
-            q0s += dd; q1s += ddy; q2s = fmaf(ddy, dY[p], q2s);
-        }
+        const float dd = -(al * dalpha);
+        const float ddy = dd * dY;
+        ar = fmaf(w, dCr[p], ar); ag = fmaf(w, dCg[p], ag); ab = fmaf(w, dCb[p], ab);
+        q0s += dd; q1s += ddy; q2s = fmaf(ddy, dY, q2s);
         T[p] = T[p] - w;
     }
+    any = asum != 0.0f;
     // raw moments of dd = d L / d(log alpha) about the splat's mean; the factors that are constant per gaussian
     // (1/sig, the conic, 1/2) are applied once per gaussian by the parameter kernels, not once per (tile, splat)
     const float qx = dX * q0s;
@@ -453,8 +465,8 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
 // by construction.
 // RED: 2 transposed LDS reduction, software pipelined (default); 1 reduce-scatter tree on ds_swizzle / ds_bpermute
 template <bool EARLY, bool DET, int RED, bool CULL>
-__device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, uint32_t *sid, float *red,
-                                              const float nbig) {
+__device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, uint32_t *sid, uint32_t *sstrip,
+                                              float *red, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
@@ -529,21 +541,34 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             if (__ballot(live) == 0ull) { stop = true; break; }
         }
         float4 q0, q1, q2;
+        uint32_t strips;
         bool keep;
-        const float yhi_l = stage_record(q0, q1, q2, n0, n1, n2, tx0, ty0, keep);
+        const float yhi_l = stage_record<CULL>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
         int slot = lane, nk = cnt;
+        if (!CULL) keep = true;
+        uint64_t mq[4] = {~0ull, ~0ull, ~0ull, ~0ull};                    // bit k: strip p of the k-th staged entry is live
         if (CULL) {
             keep = keep && lane < cnt;
             const uint64_t m = __ballot(keep);
             slot = slot_of(m); nk = __popcll(m);
-        } else keep = true;
+        }
         __syncthreads();
         if (keep) {
             sp[3 * slot] = q0; sp[3 * slot + 1] = q1; sp[3 * slot + 2] = q2;
             syhi[slot] = yhi_l;
             sid[slot] = nid;                                             // gaussian id of the staged entry
+            if (CULL) sstrip[slot] = strips;
         }
         __syncthreads();
+        if (CULL) {
+            const uint32_t mine = lane < nk ? sstrip[lane] : 0u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) mq[p] = __ballot((mine >> p) & 1u);
+        }
+        auto live_of = [&](int k) -> uint32_t {                          // wave-uniform strip mask of staged entry k
+            return (uint32_t)((mq[0] >> k) & 1ull) | ((uint32_t)((mq[1] >> k) & 1ull) << 1) | ((uint32_t)((mq[2] >> k) & 1ull) << 2)
+                   | ((uint32_t)((mq[3] >> k) & 1ull) << 3);
+        };
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
         if (pos < s1) { nid = ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
@@ -554,7 +579,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             auto step = [&](const Entry &cur, const uint32_t gcur, Entry &nxt, uint32_t &gnxt, const int k) {
                 float v[9];
                 bool any;
-                backward_entry(cur, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any);
+                backward_entry(cur, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
                 const uint32_t gid_k = (uint32_t)__builtin_amdgcn_readfirstlane((int)gcur);
                 __builtin_amdgcn_sched_barrier(0);
                 nxt = load_entry(sp, syhi, k + 1);                       // slot nk <= CB exists (one spare slot), value unused
@@ -587,7 +612,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
 #endif
                 float v[9];
                 bool any = true;
-                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any);
+                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
                 if (!CULL && __ballot(any) == 0ull) continue;
 #if GS_ABL & 1
 #pragma unroll
@@ -608,7 +633,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
                 const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
                 float v[9];
                 bool any;
-                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any);
+                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
                 if (!CULL && __ballot(any) == 0ull) continue;            // nobody in the tile touched it
                 const float d = reduce8_lds(v, lane, xaddr);
                 const float t9 = wave_sum_lds(v[8], xaddr);
@@ -632,11 +657,12 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     __shared__ float4 sp[(CB + 1) * 3];                                  // one spare slot: the pipelined loop loads entry k+1
     __shared__ float syhi[CB + 1];
     __shared__ uint32_t sid[CB + 1];
+    __shared__ uint32_t sstrip[CB];
     __shared__ __attribute__((aligned(16))) float red[RED >= 2 ? RED_FLOATS : 4];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
-        backward_tile<EARLY, DET, RED, CULL>(a, tile, sp, syhi, sid, red, nbig);
+        backward_tile<EARLY, DET, RED, CULL>(a, tile, sp, syhi, sid, sstrip, red, nbig);
         __syncthreads();
     }
 }
@@ -719,8 +745,8 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
-#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 1, true>), grid, block, debug_extra_lds(), s, a); \
-                     else hipLaunchKernelGGL((composite_fwd_kernel<E, 1, false>), grid, block, debug_extra_lds(), s, a); } while (0)
+#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
+                     else hipLaunchKernelGGL((composite_fwd_kernel<E, 5, false>), grid, block, debug_extra_lds(), s, a); } while (0)
     if (early) GS_F(true); else GS_F(false);
 #undef GS_F
     return hipGetLastError();
@@ -765,8 +791,8 @@ int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int 
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     CompositeKernel f = nullptr;
     if (which == 0) {
-        f = early ? (cull ? composite_fwd_kernel<true, 1, true> : composite_fwd_kernel<true, 1, false>)
-                  : (cull ? composite_fwd_kernel<false, 1, true> : composite_fwd_kernel<false, 1, false>);
+        f = early ? (cull ? composite_fwd_kernel<true, 5, true> : composite_fwd_kernel<true, 5, false>)
+                  : (cull ? composite_fwd_kernel<false, 5, true> : composite_fwd_kernel<false, 5, false>);
     } else {
         const int k = (early ? 4 : 0) | (det ? 2 : 0) | (cull ? 1 : 0);
         switch (k) {
