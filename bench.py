@@ -94,6 +94,28 @@ def measured_counters(kernel_stage: str, config: str, t_min: float, avg_ms: floa
     return v.get("hbm_bytes_total"), valu
 
 
+def loop_cost_model(kernel_stage: str, avg_ms: float, evaluated: int):
+    """Compute-side view of a composite kernel: VALU wave-instructions and microbenchmark-priced issue cycles per evaluated
+    (tile, splat) entry from the disassembly of THIS build (tools/loop_cost.py -> profiles/*loop_cost.json, matched by
+    csrc_sha), next to the measured SIMD-time per entry (kernel time x 1024 SIMDs / entries)."""
+    import glob
+    if kernel_stage not in ("composite_fwd", "composite_bwd") or evaluated <= 0 or avg_ms <= 0:
+        return None
+    sha = csrc_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*loop_cost.json")), reverse=True):
+        with open(f) as fh:
+            d = json.load(fh)
+        if d.get("csrc_sha") == sha and kernel_stage in d:
+            k = d[kernel_stage]
+            ns = avg_ms * 1e6 * 1024.0 / evaluated
+            return {"valu_per_entry": k["valu_per_entry_all_strips"], "model_issue_cycles_per_entry": k["model_cycles_per_entry_all_strips"],
+                    "measured_simd_ns_per_entry": ns, "measured_cycles_per_entry_at_2p1GHz": ns * 2.1,
+                    "vgpr": k.get("vgpr"), "source": os.path.relpath(f, ROOT),
+                    "note": "model = per-form issue costs of tools/valu_ubench3.hip summed over the loop body with all four strips live; "
+                            "the backward evaluates ~3 of 4 strips per entry at C3"}
+    return None
+
+
 def launch_command(n: int, argv: list, port: int | None = None) -> list:
     """The child command bench.py starts for --gpus N > 1 from a bare shell (one rank per GPU, rendezvous on 127.0.0.1)."""
     if port is None:
@@ -136,6 +158,8 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--t-min", type=float, default=1e-5, help="transmittance early-out (0 = literal reference)")
     ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--rank-mode", type=int, default=0, help="radix-sort stable ranks: 0 LDS atomic-add-return (probed at gs_create), 1 wave64 ballots")
+    ap.add_argument("--schedule", type=int, default=3, help="gs_config.schedule (3 default; 4 = forward tiles ordered by the previous frame's per-tile work)")
     ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal (t_min=0) measurement")
@@ -190,7 +214,7 @@ def main():
 
     def make(t_min, profile_stages):
         return R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene, device=local, order=args.order, t_min=t_min,
-                             profile_stages=profile_stages, alpha_cull=not args.no_cull)
+                             profile_stages=profile_stages, alpha_cull=not args.no_cull, rank_mode=args.rank_mode, schedule=args.schedule)
 
     from gaussiansplat_amd import distributed as D
     sync_mode = [args.grad_sync]                                                # the exchange `step` uses (N > 1)
@@ -294,7 +318,7 @@ def main():
                                      "never normalises q and |q| scales every footprint by |q|^4; un-normalised q is parity-tested, "
                                      "tests/test_gpu_sizes.py)",
                        "nranks": nranks, "grad_sync": args.grad_sync if world > 1 else None, "backend": args.backend if world > 1 else None,
-                       "rank_mode": int(r.ctx.cfg.rank_mode), "binning_rounds": r.ctx.num_rounds,
+                       "rank_mode": int(r.ctx.cfg.rank_mode), "binning_rounds": r.ctx.num_rounds, "schedule": args.schedule,
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
                        "instances": I, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
                        "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "seed": seed},
@@ -310,6 +334,7 @@ def main():
                                  "fraction is reported as measured"},
         }
         out["roofline"]["traffic"], out["roofline"]["valu"] = measured_counters(dom, args.config, args.t_min, dom_ms)
+        out["roofline"]["loop_cost"] = loop_cost_model(dom, dom_ms, wc["evaluated_bwd"] if dom == "composite_bwd" else wc["evaluated_fwd"])
         if other:
             out["factored_exchange" if other["grad_sync"] == "factored" else "allreduce_exchange"] = other
     if not args.no_literal and args.t_min > 0 and world == 1:      # extra measurements only at N = 1

@@ -105,6 +105,7 @@ struct gs_ctx {
                                              // then 8 u32 per-XCD ticket counters of the forward (byte 32) and 8 of the backward (byte 64)
     DevBuf tile_order_f, tile_order_b, tile_order_p, tile_work, tile_clock;   // longest-first tile orders (+ 9 segment bounds each), per-tile work, debug clocks
     int waves_fwd = 0, waves_bwd = 0;        // resident waves of the persistent composite grids (occupancy x CUs)
+    int64_t tile_work_valid_tiles = 0;       // tile_work holds a forward's per-tile counts for a grid of this many tiles
     int rank_probe = -1;                     // lane-order probe of the LDS atomic rank: -1 not run, 0 passed, 1 failed (ballots forced)
     // ---- binning in depth slabs (gs_config.slab_mode)
     int n_rounds = 1;                        // binning rounds of the current frame
@@ -179,6 +180,21 @@ int composite_sched(gs_ctx *c, GsCompositeArgs &a, int which) {
     const int ntiles = c->gx * c->gy;
     HIPCHK(c, c->tile_work.ensure(sizeof(uint32_t) * (size_t)(ntiles ? ntiles : 1)));
     if (which == 0) a.tile_work = c->tile_work.as<uint32_t>();
+    if (c->cfg.schedule == 3 || c->cfg.schedule == 4) {                      // plain launch; the backward's tiles heaviest first (by the forward's count)
+        if (which == 0 && c->cfg.schedule == 4 && c->tile_work_valid_tiles == ntiles && ntiles > 0) {
+            // opt-in: the forward's tiles by the work the PREVIOUS forward of this ctx measured on the same tile grid (pays when
+            // consecutive frames see similar views; with an unrelated view it degrades to an arbitrary order, which costs nothing)
+            HIPCHK(c, c->tile_order_f.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
+            HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, ntiles, c->tile_order_f.as<uint32_t>(), c->stream));
+            a.tile_order = c->tile_order_f.as<uint32_t>();
+        }
+        if (which == 1 && ntiles > 0) {
+            HIPCHK(c, c->tile_order_b.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
+            HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, ntiles, c->tile_order_b.as<uint32_t>(), c->stream));
+            a.tile_order = c->tile_order_b.as<uint32_t>();
+        }
+        return GS_OK;
+    }
     if (c->cfg.schedule == 1 || ntiles <= 0) return GS_OK;                  // one wave per tile, launch order
     int &waves = which == 0 ? c->waves_fwd : c->waves_bwd;
     if (waves == 0) {
@@ -212,7 +228,7 @@ void gs_default_config(gs_config *cfg) {
     cfg->export_debug = 0;
     cfg->profile_stages = 0;
     cfg->alpha_cull = 1;
-    cfg->schedule = 1;
+    cfg->schedule = 3;
     cfg->slab_mode = 1;
 }
 
@@ -232,7 +248,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (c0.tile_size != GS_TILE) return fail(nullptr, GS_ERR_UNSUPPORTED, "gs_create: only tile_size 16 is supported (reference threads=(16,16))");
     if (c0.order < GS_ORDER_INDEX || c0.order > GS_ORDER_DEPTH_ASC) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad order");
     if (!(c0.t_min >= 0.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: t_min must be >= 0");
-    if (c0.schedule < 0 || c0.schedule > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad schedule");
+    if (c0.schedule < 0 || c0.schedule > 4) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad schedule");
     if (c0.slab_mode < 0 || c0.slab_mode > 1) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad slab_mode");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -548,12 +564,12 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
         HIPCHK(c, c->pairs_b.ensure(sizeof(uint64_t) * n1));
         HIPCHK(c, c->perm.ensure(sizeof(uint32_t) * n1));
         HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n)));
-        HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 256));
-        HIPCHK(c, gs_launch_depth_pairs(c->depth_key.as<uint32_t>(), c->pairs_a.as<uint64_t>(), c->n, c->stream));
+        HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 4 * 256));
         int in_b = 0;
         perm = c->perm.as<uint32_t>();                  // the last pass writes the permutation itself (low word of the pairs)
+        // (depth | id) pairs are formed by the first pass from the 32-bit keys; the last pass writes only the ids
         HIPCHK(c, gs_radix_sort_u64(c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, 32, 64, c->table.as<uint32_t>(),
-                                    c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0, perm));
+                                    c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0, perm, c->depth_key.as<uint32_t>()));
     }
     c->perm_ptr = perm; c->perm_all = perm;
     {
@@ -604,7 +620,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     c->round_ids_off[0] = 0;
     const size_t ni1 = c->n_inst ? (size_t)c->n_inst : 1;
     HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
-    HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 256));
+    HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 4 * 256));
     HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * ni1));
     if (fast) {
         // ---- generate-in-pass binning on 32-bit words (gs_bin2.hip)
@@ -687,6 +703,7 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     if (mem == GS_MEM_HOST && (image || transmittance)) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->did_fwd = true; c->did_bwd = false; c->did_bwd_composite = false;
     c->prev_counters_valid = true; c->prev_n_inst = c->n_inst;
+    c->tile_work_valid_tiles = (int64_t)ntiles;
     return GS_OK;
 }
 
@@ -1094,6 +1111,13 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     HIPCHK(c, c->tile_order_p.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
     HIPCHK(c, gs_launch_tile_order(nullptr, 0, ntiles, c->tile_order_p.as<uint32_t>(), c->tile_order_p.as<uint32_t>() + ntiles, c->stream));
     a.tile_order_plain = c->tile_order_p.as<uint32_t>();
+    {                                                                        // variant tens digit 3: longest-first permutation, plain launch
+        const int fwd_mode = std::getenv("GS_FWD_ORDER_BY_WORK") ? 0 : 1;     // forward: by list length, or (experiment) by the measured work of this frame
+        HIPCHK(c, c->tile_order_f.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
+        HIPCHK(c, gs_launch_tile_lpt_order(which == 0 && fwd_mode ? c->ranges.as<uint32_t>() : c->tile_work.as<uint32_t>(), which == 0 ? fwd_mode : 0, ntiles,
+                                           c->tile_order_f.as<uint32_t>(), c->stream));
+        a.tile_order_band = c->tile_order_f.as<uint32_t>();
+    }
     return GS_OK;
 }
 

@@ -77,7 +77,8 @@ size_t gs_sort_table_entries(int64_t n_max);
 // last pass writes only the low 32 bits of every key (the id of a (key | id) pair) to final_low32, not the 64-bit keys.
 hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
                              uint32_t *block_hist, uint32_t *digit_total, int *result_in_b,
-                             hipStream_t stream, bool ballot_ranks = false, uint32_t *final_low32 = nullptr);
+                             hipStream_t stream, bool ballot_ranks = false, uint32_t *final_low32 = nullptr,
+                             const uint32_t *keys32 = nullptr);
 
 // checks on the current device that one ds_add_rtn_u32 hands same-address lanes their pre-values in ascending lane order
 hipError_t gs_probe_lds_atomic_order(hipStream_t s, int *mismatches);
@@ -148,6 +149,7 @@ struct GsCompositeArgs {
     const uint32_t *queue_seg; // 9 bounds of the per-XCD segments of tile_order
     const uint32_t *tile_order; // segment x: the tiles with tile % 8 == x, heaviest first
     const uint32_t *tile_order_plain; // A/B: the same segments in tile order (no longest-first)
+    const uint32_t *tile_order_band;  // A/B: longest-first permutation for a plain launch (schedule 3), tile % 8 preserved
     uint32_t *tile_work;       // forward: evaluated entries per tile (the backward's exact work measure); may be null
     unsigned long long *tile_clock; // debug: per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated}
     int grid_waves;            // waves to launch in queue mode
@@ -161,6 +163,7 @@ struct GsCompositeArgs {
     int final_round;           // forward: last round of the frame: transmittance is written plain (no sign flag)
 };
 // tiles in decreasing order of work[] (a 256-bucket counting sort of work / max; one workgroup)
+hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s);
 hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s);
 int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body = 0);   // occupancy x CUs (body: A/B variant)
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);

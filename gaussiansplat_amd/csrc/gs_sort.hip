@@ -27,8 +27,12 @@ size_t gs_sort_table_entries(int64_t n_max) {
 }
 
 // ---------------------------------------------------------------- radix pass: histogram
-__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, int64_t n, int shift, uint32_t mask,
-                                                              uint32_t *__restrict__ block_hist, int nblocks) {
+// keys32 != null (first pass of the depth sort): the keys are the 32-bit depth keys themselves; the pair (key << 32 | index)
+// is never stored before the first scatter.  digit_total != null: the 256 digit totals are accumulated here with one atomic
+// per (workgroup, digit) -- for the small tables of the depth sort that saves the separate totals launch.
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ keys32, int64_t n,
+                                                              int shift, uint32_t mask, uint32_t *__restrict__ block_hist, int nblocks,
+                                                              uint32_t *__restrict__ digit_total) {
     __shared__ uint32_t h[RS_RADIX];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -36,10 +40,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__r
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
         const int64_t idx = base + (int64_t)i * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & mask], 1u);
+        if (idx < n) {
+            const uint32_t dg = keys32 ? ((keys32[idx] >> (shift - 32)) & mask) : ((uint32_t)(keys[idx] >> shift) & mask);
+            atomicAdd(&h[dg], 1u);
+        }
     }
     __syncthreads();
-    block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];   // [digit][block]
+    const uint32_t c = h[threadIdx.x];
+    block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = c;   // [digit][block]
+    if (digit_total && c) atomicAdd(&digit_total[threadIdx.x], c);
 }
 
 // ---------------------------------------------------------------- radix pass: scan
@@ -117,7 +126,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
 // placed digit-contiguously in LDS and written out in runs.
 // out32 != null (last pass of a (key | id) pair sort): only the low word -- the id -- is written, as 32 bits.
 template <bool ATOMIC_RANK>
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ in32,
+                                                                 uint64_t *__restrict__ out,
                                                                  int64_t n, int shift, uint32_t mask,
                                                                  const uint32_t *__restrict__ block_hist, int nblocks,
                                                                  uint32_t *__restrict__ out32) {
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     for (int r = 0; r < RS_ITEMS; ++r) {
         const int li = w * (GS_WAVE * RS_ITEMS) + r * GS_WAVE + lane;    // index inside the chunk
         const bool valid = li < cnt;
-        key[r] = valid ? in[base + li] : ~0ull;
+        key[r] = !valid ? ~0ull : in32 ? (((uint64_t)in32[base + li] << 32) | (uint32_t)(base + li)) : in[base + li];
         const uint32_t dg = valid ? ((uint32_t)(key[r] >> shift) & mask) : (RS_RADIX - 1);
         if (ATOMIC_RANK) {                                              // see gs_bin2.hip rank_round_atomic
             rank[r] = 0;
@@ -243,9 +253,12 @@ hipError_t gs_launch_radix_scan(uint32_t *block_hist, int nblocks, uint32_t *dig
     return hipGetLastError();
 }
 
+// keys32 != null: the first pass reads the 32-bit keys and forms (key << 32 | index) on the fly (`a` is then only scratch).
+// Small tables (the depth sort: n / 4096 <= 2048 chunks) fold the digit totals into the histogram kernel (atomics on four
+// zeroed 256-word slices of digit_total, which must then hold 4 x 256 words): 3 launches per pass instead of 4.
 hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
                              uint32_t *block_hist, uint32_t *digit_total, int *result_in_b, hipStream_t stream, bool ballot_ranks,
-                             uint32_t *final_low32) {
+                             uint32_t *final_low32, const uint32_t *keys32) {
     *result_in_b = 0;
     if (n <= 0) return hipSuccess;
     const int nblocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
@@ -254,15 +267,24 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
     const int total = bit_hi - bit_lo;
     const int passes = (total + 7) / 8;
     const int width = (total + passes - 1) / passes;
-    for (int shift = bit_lo; shift < bit_hi; shift += width) {
+    const bool fused_totals = keys32 != nullptr && nblocks <= 2048 && passes <= 4;
+    if (fused_totals) {
+        hipError_t e = hipMemsetAsync(digit_total, 0, sizeof(uint32_t) * 4 * RS_RADIX, stream);
+        if (e != hipSuccess) return e;
+    }
+    int pass = 0;
+    for (int shift = bit_lo; shift < bit_hi; shift += width, ++pass) {
         const int bits = (bit_hi - shift) < width ? (bit_hi - shift) : width;
         const uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, n, shift, mask, block_hist, nblocks);
-        hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
+        const uint32_t *k32 = pass == 0 ? keys32 : nullptr;
+        uint32_t *tot = fused_totals ? digit_total + pass * RS_RADIX : digit_total;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, k32, n, shift, mask, block_hist, nblocks,
+                           fused_totals ? tot : (uint32_t *)nullptr);
+        if (!fused_totals) hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, tot);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, tot);
         uint32_t *o32 = (final_low32 && shift + width >= bit_hi) ? final_low32 : nullptr;      // last pass: ids only
-        if (ballot_ranks) hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks, o32);
-        else hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, dst, n, shift, mask, block_hist, nblocks, o32);
+        if (ballot_ranks) hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32);
+        else hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32);
         uint64_t *t = src; src = dst; dst = t;
         *result_in_b ^= 1;
     }

@@ -105,7 +105,7 @@ def initGrads(splatData: SplatData3D) -> SplatGrads3D:
 class GaussianRenderer3D:               # renderer.jl:205-219
     def __init__(self, splatData: SplatData3D, imgSize, sh_degree: int, device: int = 0, order: int = B.ORDER_DEPTH_DESC,
                  t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False, deterministic: bool = False,
-                 alpha_cull: bool = True):
+                 alpha_cull: bool = True, rank_mode: int = 0, slab_mode: int = 1, schedule: int = 3):
         import torch
         self.splatData = splatData
         self._splatGrads = initGrads(splatData)
@@ -118,7 +118,7 @@ class GaussianRenderer3D:               # renderer.jl:205-219
         self.sh_degree = sh_degree
         self.camera: Camera | None = None
         self.ctx = B.Context(device=device, order=order, t_min=t_min, export_debug=export_debug, profile_stages=profile_stages,
-                             deterministic=deterministic, alpha_cull=alpha_cull)
+                             deterministic=deterministic, alpha_cull=alpha_cull, rank_mode=rank_mode, slab_mode=slab_mode, schedule=schedule)
         # the library enqueues on the caller's CURRENT torch stream (re-read at every API call), like any torch
         # op: no cross-stream fences, so consecutive calls run back to back on the GPU
         self._stream_handle = None

@@ -87,12 +87,15 @@ typedef struct {
                                  (tile, splat) entry whose largest alpha over that tile's pixels is below 2^-27
                                  -- a no-op in the reference's own fp32 arithmetic (T*(1-alpha) == T, colour term
                                  < 7.5e-9*|rgb|).  The lists (gs_bin) are unchanged.  0: evaluate every entry. */
-    int32_t schedule;         /* composite kernels: 1 (default) one wave per tile in launch order -- tiles in flight are spatial
-                                 neighbours, so they share splat payloads in L2; 0 persistent waves pull tiles from per-XCD ticket
-                                 counters, heaviest tile first; 2 the same in arbitrary order.  Measured at C3 (profiles/): modes 0
-                                 and 2 balance the SIMDs (work max/mean 1.04 vs 1.17) but scatter the tiles in flight over the
-                                 image, and the lost L2 reuse costs far more (forward 0.72 vs 0.37 ms).  Speed only: every mode
-                                 gives the same image and (up to atomic order) gradients                                  */
+    int32_t schedule;         /* composite kernels (speed only: every mode gives the same image and, up to atomic order, gradients):
+                                 3 (default) one wave per tile, plain launch; the backward's tiles are permuted heaviest first
+                                   (by the forward's per-tile count of evaluated entries) inside each class tile % 8, i.e. on the
+                                   XCD the launch order would have used -- no tail, same L2 sharing (C3: 0.84 -> 0.74 ms);
+                                 4 as 3, and the forward's tiles by the work the PREVIOUS forward of this ctx measured (opt-in:
+                                   pays when consecutive frames see similar views, C3 same view: forward 0.38 -> 0.33 ms);
+                                 1 one wave per tile in launch order;
+                                 0 persistent waves pull tiles from per-XCD ticket counters, heaviest first; 2 the same in
+                                   arbitrary order (both measured slower: profiles/)                           */
     int32_t slab_mode;        /* binning in depth slabs (speed only; image, transmittance and deterministic-mode gradients are
                                  bit-identical either way): 1 (default) automatic -- when the previous frame walked under 15 % of
                                  its tile instances before the transmittance early-out stopped every tile, the next frame is
