@@ -3,8 +3,10 @@
 
     python3 tools/tile_tail.py [C3] [out.json]
 
-For every scheduling variant (0 = ticket queue, heaviest tile first; 10 = one wave per tile in launch order; 20 = ticket
-queue in tile order) and both kernels it launches once with gs_debug_tile_clock and reports
+For every scheduling variant (tens digit: 1 = one wave per tile in launch order; 3 = plain launch over the longest-first
+permutation that keeps tile % 8 (the default of the backward); 0 = persistent waves on per-XCD ticket queues, heaviest first;
+2 = the same queues in arbitrary order; units digit 1 = the reduce-scatter-tree backward body) and both kernels it launches
+once with gs_debug_tile_clock and reports
   * kernel span (first start .. last end, 100 MHz s_memrealtime ticks -> microseconds),
   * the concurrency profile: time-weighted mean of waves in flight, and the share of the span spent below 50 % / 25 % of
     the peak concurrency (the tail),
@@ -74,7 +76,7 @@ def main():
     ctx.preprocess(); ctx.bin(); ctx.forward_host()
     g = ctx.grads_alloc(); ctx.backward(dC, g); ctx.synchronize()
     res = {"config": cfg, "instances": ctx.num_instances, "work": ctx.work_counters_ex()}
-    variants = {"fwd": [0, 10, 20], "bwd": [0, 10, 20, 2, 12, 1, 11]}
+    variants = {"fwd": [10, 30, 0], "bwd": [10, 30, 0, 20, 11, 31]}
     for which, name in ((0, "fwd"), (1, "bwd")):
         for v in variants[name]:
             a = analyse(ctx.tile_clock(which, v))
