@@ -25,6 +25,7 @@ SOURCES = {
     "gs_preprocess_bwd.hip": [],
     "gs_sort.hip": [],
     "gs_bin2.hip": [],
+    "gs_bin3.hip": [],
     "gs_composite.hip": [],
     "gs_loss.hip": [],
     "gs_api.hip": [],

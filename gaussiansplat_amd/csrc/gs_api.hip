@@ -115,6 +115,11 @@ struct gs_ctx {
     DevBuf ranges_r[GS_MAX_ROUNDS];          // tile ranges of rounds 1.. (round 0 uses `ranges`)
     DevBuf tile_pos, tile_done, live2d, rect_r, offsets_r, live_total;
     uint32_t *perm_all = nullptr;            // the whole depth order (perm_ptr)
+    // ---- two-level binning (gs_bin3.hip): lists per super-tile of 8 x 8 tiles, then per tile
+    bool two_level = false;
+    int sgx = 0, sgy = 0;
+    int64_t coarse_listed = 0;               // coarse instances of the current round
+    DevBuf rect_sorted, l1_table, l1_rows, l1_partials, cids, clr, cranges, segcnt, sdone, bin_totals, tilecnt;
     int tile_bits = 0, gid_bits = 0, lo_bits = 0, hi_bits = 0;
     bool fast_bin = false;
     double walked_ratio = -1.0;              // entries walked / instances of the last completed frame (-1: none yet)
@@ -292,6 +297,7 @@ int gs_destroy(gs_ctx *c) {
                       &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
                       &c->tile_order_f, &c->tile_order_b, &c->tile_order_p, &c->tile_work, &c->tile_clock,
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
+                      &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->bin_totals, &c->tilecnt,
                       &c->ranges_r[0], &c->ranges_r[1], &c->ranges_r[2], &c->ranges_r[3],
                       &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams};
     for (DevBuf *b : bufs) b->release();
@@ -506,8 +512,84 @@ static int plan_rounds(gs_ctx *c) {
     return r;
 }
 
+// Two-level binning of one round (gs_bin3.hip).  two_level_count enqueues the level-1 histogram of the slab's gaussians
+// (after it the round's three totals are on the device: coarse instances listed, fine instances of the slab, of all n);
+// two_level_lists, once the host knows the coarse count, enqueues the super-tile lists and the tile lists.
+static GsBin3L1 two_level_args(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, const uint8_t *sdone) {
+    GsBin3L1 b{};
+    b.rect = c->rect.as<uint16_t>(); b.perm = perm_slab; b.sdone = sdone; b.n = n_all; b.n_slab = nr; b.sgx = c->sgx; b.ns = c->sgx * c->sgy;
+    b.rect_sorted = c->rect_sorted.as<uint32_t>(); b.table = c->l1_table.as<uint32_t>(); b.row_total = c->l1_rows.as<uint32_t>();
+    b.partials = c->l1_partials.as<uint32_t>(); b.totals = c->bin_totals.as<uint32_t>(); b.cranges = c->cranges.as<uint32_t>();
+    b.cids = c->cids.as<uint32_t>(); b.clr = c->clr.as<uint16_t>();
+    b.tilecnt = c->tilecnt.as<uint32_t>(); b.ntiles = c->gx * c->gy;
+    return b;
+}
+static int two_level_count(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, const uint8_t *sdone) {
+    const int ns = c->sgx * c->sgy;
+    HIPCHK(c, c->rect_sorted.ensure(sizeof(uint32_t) * 2 * (size_t)(nr ? nr : 1)));
+    HIPCHK(c, c->l1_table.ensure(sizeof(uint32_t) * gs_bin3_table_words(nr, ns)));
+    HIPCHK(c, c->l1_rows.ensure(sizeof(uint32_t) * (size_t)ns));
+    HIPCHK(c, c->l1_partials.ensure(sizeof(uint32_t) * gs_bin3_partial_words(n_all, ns)));
+    HIPCHK(c, c->bin_totals.ensure(sizeof(uint32_t) * 4));
+    HIPCHK(c, c->cranges.ensure(sizeof(uint32_t) * 2 * (size_t)ns));
+    HIPCHK(c, c->tilecnt.ensure(sizeof(uint32_t) * (size_t)c->gx * c->gy));
+    HIPCHK(c, gs_bin3_l1_count(two_level_args(c, perm_slab, n_all, nr, sdone), c->stream));
+    return GS_OK;
+}
+static int two_level_lists(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, int64_t coarse, uint32_t *ranges, uint32_t *ids_out,
+                           const uint8_t *done, const uint8_t *sdone) {
+    const int ns = c->sgx * c->sgy;
+    c->coarse_listed = coarse;
+    if (coarse <= 0) {                                      // nothing listed: every tile range of the round is empty
+        HIPCHK(c, hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)c->gx * c->gy, c->stream));
+        return GS_OK;
+    }
+    const int64_t max_work = gs_bin3_max_work(coarse, ns);
+    HIPCHK(c, c->cids.ensure(sizeof(uint32_t) * (size_t)coarse));
+    HIPCHK(c, c->clr.ensure(sizeof(uint16_t) * (size_t)coarse));
+    HIPCHK(c, c->segcnt.ensure(sizeof(uint32_t) * 64 * (size_t)max_work));
+    HIPCHK(c, gs_bin3_l1_scatter(two_level_args(c, perm_slab, n_all, nr, sdone), c->stream));
+    GsBin3Args a{};
+    a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>(); a.ranges = ranges; a.tilecnt = c->tilecnt.as<uint32_t>();
+    a.done = done; a.segcnt = c->segcnt.as<uint32_t>(); a.ids_out = ids_out;
+    a.gx = c->gx; a.gy = c->gy; a.sgx = c->sgx; a.ns = ns; a.max_work = (int)max_work;
+    a.wide = (uint64_t)c->n_inst * 4ull >= (1ull << 32);
+    HIPCHK(c, gs_bin3_build_lists(a, c->stream));
+    return GS_OK;
+}
+
+// later round of a slab frame on the two-level path
+static int bin_round_two_level(gs_ctx *c, int r) {
+    const int64_t lo = c->slab_lo[r], nr = c->slab_lo[r + 1] - lo;
+    const int64_t ntiles = (int64_t)c->gx * c->gy;
+    const int ns = c->sgx * c->sgy;
+    const uint32_t *perm = c->perm_all + lo;
+    HIPCHK(c, c->ranges_r[r].ensure(sizeof(uint32_t) * 2 * (size_t)ntiles));
+    HIPCHK(c, c->sdone.ensure((size_t)ns));
+    {
+        StageTimer t(c, GS_STAGE_COUNT_SCAN);
+        HIPCHK(c, gs_launch_super_done(c->tile_done.as<uint8_t>(), c->gx, c->gy, c->sgx, c->sgy, c->sdone.as<uint8_t>(), c->stream));
+        if (int rc = two_level_count(c, perm, nr, nr, c->sdone.as<uint8_t>())) return rc;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->pinned, c->bin_totals.as<uint32_t>(), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev_count));
+    harvest_events(c);
+    const int64_t coarse = (int64_t)c->pinned[0];
+    c->round_gen[r] = (int64_t)c->pinned[1];
+    c->round_ids_off[r] = c->round_ids_off[r - 1] + (size_t)c->round_gen[r - 1];
+    if (c->round_ids_off[r] + (size_t)c->round_gen[r] > (size_t)c->n_inst) return fail(c, GS_ERR_HIP, "gs_forward: slab instance accounting out of range");
+    {
+        StageTimer t(c, GS_STAGE_TILE_SORT);
+        if (int rc = two_level_lists(c, perm, nr, nr, coarse, c->ranges_r[r].as<uint32_t>(), c->ids.as<uint32_t>() + c->round_ids_off[r],
+                                     c->tile_done.as<uint8_t>(), c->sdone.as<uint8_t>())) return rc;
+    }
+    return GS_OK;
+}
+
 // Lists of round r (r >= 1) for the tiles still open; called from gs_forward after the forward of round r - 1.
 static int bin_round(gs_ctx *c, int r) {
+    if (c->two_level) return bin_round_two_level(c, r);
     const int64_t lo = c->slab_lo[r], nr = c->slab_lo[r + 1] - lo;
     const int64_t ntiles = (int64_t)c->gx * c->gy;
     const uint32_t *perm = c->perm_all + lo;
@@ -572,19 +654,19 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
                                     c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0, perm, c->depth_key.as<uint32_t>()));
     }
     c->perm_ptr = perm; c->perm_all = perm;
-    {
-        StageTimer t(c, GS_STAGE_COUNT_SCAN);
-        HIPCHK(c, c->offsets.ensure(sizeof(uint32_t) * (n + 1)));
-        HIPCHK(c, c->block_sums.ensure(sizeof(uint32_t) * (n / 2048 + 2)));
-        HIPCHK(c, gs_launch_count_scan(c->rect.as<uint16_t>(), perm, c->offsets.as<uint32_t>(), c->block_sums.as<uint32_t>(), c->n, c->stream));
-    }
     int tile_bits = 1;
     while ((1LL << tile_bits) < ntiles) ++tile_bits;
     int gid_bits = 1;
     while ((1LL << gid_bits) < c->n) ++gid_bits;
     const int passes = (tile_bits + 7) / 8;
     const int lo_bits = passes <= 1 ? tile_bits : (tile_bits + 1) / 2, hi_bits = tile_bits - lo_bits;
-    const bool fast = c->cfg.bin_path == 0 && passes <= 2 && hi_bits + gid_bits <= 32 && gs_tile_ranges_supported(c->gx, c->gy);
+    int bin_path = c->cfg.bin_path;
+    if (const char *e = std::getenv("GS_BIN_PATH")) bin_path = std::atoi(e);               // experiments
+    const bool fast = bin_path != 1 && passes <= 2 && hi_bits + gid_bits <= 32 && gs_tile_ranges_supported(c->gx, c->gy);
+    // two-level path (gs_bin3.hip): lists per super-tile of 8 x 8 tiles first; its bitmap must fit in LDS
+    const int sb = 1 << gs_bin3_sb_shift();
+    c->sgx = (c->gx + sb - 1) / sb; c->sgy = (c->gy + sb - 1) / sb;
+    c->two_level = fast && bin_path == 0 && gs_bin3_supported(c->sgx * c->sgy);
     c->tile_bits = tile_bits; c->gid_bits = gid_bits; c->lo_bits = lo_bits; c->hi_bits = hi_bits; c->fast_bin = fast;
     HIPCHK(c, c->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)(ntiles ? ntiles : 1)));
     HIPCHK(c, c->counters.ensure(128));
@@ -592,21 +674,35 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     // the share known so far (one frame of lag; only speed depends on it)
     const int R = plan_rounds(c);
     const int64_t n0 = c->slab_lo[1];                                       // list positions of round 0
+    HIPCHK(c, c->block_sums.ensure(sizeof(uint32_t) * 3 * (n / 2048 + 2)));
+    if (c->two_level) {
+        StageTimer t(c, GS_STAGE_COUNT_SCAN);
+        if (int rc = two_level_count(c, perm, c->n, n0, nullptr)) return rc;
+    } else {
+        StageTimer t(c, GS_STAGE_COUNT_SCAN);
+        HIPCHK(c, c->offsets.ensure(sizeof(uint32_t) * (n + 1)));
+        HIPCHK(c, gs_launch_count_scan(c->rect.as<uint16_t>(), perm, c->offsets.as<uint32_t>(), c->block_sums.as<uint32_t>(), c->n, c->stream));
+    }
     // the one host read-back of the frame (the reference reads maxHits back, forward.jl:139): the instance count, the
     // generated positions of round 0 and the previous frame's walked count.  Work that does not need the count (the tile
     // ranges) is enqueued BEFORE the host waits, so the GPU stays busy while the host wakes up and launches the instance passes.
-    HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->pinned + 1, c->offsets.as<uint32_t>() + n0, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->two_level) {
+        HIPCHK(c, hipMemcpyAsync(c->pinned + 4, c->bin_totals.as<uint32_t>(), 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->pinned + 1, c->offsets.as<uint32_t>() + n0, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    }
     if (c->prev_counters_valid) HIPCHK(c, hipMemcpyAsync(c->pinned + 2, c->counters.p, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
-    if (fast) {
+    if (fast && !c->two_level) {
         HIPCHK(c, c->diff.ensure(sizeof(int) * gs_tile_ranges_scratch_ints(c->gx, c->gy)));
         StageTimer t(c, GS_STAGE_RANGES);
         HIPCHK(c, gs_launch_tile_ranges(c->rect.as<uint16_t>(), R > 1 ? perm : nullptr, R > 1 ? n0 : c->n, c->diff.as<int>(), c->gx, c->gy,
                                         c->ranges.as<uint32_t>(), nullptr, c->stream));
     }
     HIPCHK(c, hipEventSynchronize(c->ev_count));
-    harvest_events(c, fast ? GS_STAGE_RANGES : -1);
+    harvest_events(c, fast && !c->two_level ? GS_STAGE_RANGES : -1);
+    if (c->two_level) { c->pinned[0] = c->pinned[6]; c->pinned[1] = c->pinned[5]; }      // totals: [4] coarse, [5] fine of the slab, [6] fine of all
     if (c->pinned[0] == 0xFFFFFFFFu)
         return fail(c, GS_ERR_UNSUPPORTED, "gs_bin: more than 2^32 - 2 tile instances (32-bit list offsets); reduce the scene or the image");
     if (c->prev_counters_valid && c->prev_n_inst > 0) {
@@ -619,9 +715,13 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     c->round_gen[0] = R > 1 ? (int64_t)c->pinned[1] : c->n_inst;
     c->round_ids_off[0] = 0;
     const size_t ni1 = c->n_inst ? (size_t)c->n_inst : 1;
-    HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
+    if (!c->two_level) HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
     HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 4 * 256));
     HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * ni1));
+    if (c->two_level) {
+        StageTimer t(c, GS_STAGE_TILE_SORT);
+        if (int rc = two_level_lists(c, perm, c->n, n0, (int64_t)c->pinned[4], c->ranges.as<uint32_t>(), c->ids.as<uint32_t>(), nullptr, nullptr)) return rc;
+    } else
     if (fast) {
         // ---- generate-in-pass binning on 32-bit words (gs_bin2.hip)
         const size_t nchunks = ((size_t)c->n_inst + 4095) / 4096;

@@ -1,0 +1,563 @@
+// gs_bin3.hip -- two-level tile binning for gfx950 (default path of gs_bin from round 2 on).
+//
+// Same result as the reference's compactIdxs (src/forward.jl:118-161: hitBinning, scan!, compactHits) and as the
+// radix paths of gs_sort.hip / gs_bin2.hip -- per-tile lists in (tile, list order), bit-identical -- but no pass ever
+// sorts the I tile-instances (30 M at 1 M gaussians / 1080p), and nothing depends on the order in which the LDS unit
+// serves the lanes of an atomic:
+//
+//   level 1  the gaussians are listed per SUPER-TILE of 8 x 8 tiles (128 x 128 pixels): 2.2 M coarse instances instead
+//            of 30 M.  A workgroup owns G consecutive list positions (depth order) and builds an LDS bitmap
+//            [super-tile][position] with atomic ORs (order-free).  The row popcounts are the workgroup's histogram
+//            (l1_hist); after an exclusive scan of the table along the workgroups (l1_rowscan) the same bitmap gives
+//            every coarse instance its stable rank -- the popcount of its row below its own bit -- and l1_scatter writes
+//            the gaussian id and the instance's rectangle clipped to the super-tile (12 bits) to their final place.
+//   level 2  a tile's list is the sub-sequence of its super-tile's list whose rectangles cover the tile, in the same
+//            order.  A workgroup takes a segment of L2_SEG entries of one super-tile list; each of its eight waves owns
+//            one tile ROW of the super-tile: it compacts the segment's entries to those touching its row through a
+//            small LDS ring and, per full batch of 64 such entries, one ballot per tile gives the count and every hit
+//            lane's rank; the hit lanes store their gaussian id behind the tile's cursor -- ascending positions, so the
+//            order is the list order by construction (no key, no digit, no rank table).  The cursor of (segment, tile)
+//            starts at the tile's range start + the hits of the earlier segments of the same super-tile, which a count
+//            pass (a 9 x 9 difference array per segment) provides.
+//
+// HBM traffic per instance: the 4-byte id written once (+ 6 B per COARSE instance written and read twice), against
+// 16 B per instance for gs_bin2.hip.  The tile ranges are the exclusive scan of the level-2 hit counts.
+#include "gs_common.h"
+#include <stdlib.h>
+
+#define SB 8                 // super-tile edge in tiles
+#define SB_SHIFT 3
+#define L1_THREADS 256
+#define L2_SEG 2048          // entries of a super-tile list per workgroup
+#define L2_THREADS 256
+
+int gs_bin3_sb_shift() { return SB_SHIFT; }
+int64_t gs_bin3_max_work(int64_t coarse_instances, int ns) { return coarse_instances / L2_SEG + ns; }
+// list positions per level-1 workgroup: the bitmap (ns x G bits), its word prefix (ns x G/32 u16), 2 ns starts and the
+// staging buffer (24 G bytes) share LDS
+static size_t l1_lds_bytes(int ns, int g) { return (size_t)ns * (g / 8 + g / 16 + 8) + 24 * (size_t)g; }
+int gs_bin3_group(int ns) {
+    int g = 1024;
+    while (g > 256 && l1_lds_bytes(ns, g) > 72 * 1024) g >>= 1;
+    return g;
+}
+bool gs_bin3_supported(int ns) { return l1_lds_bytes(ns, 256) <= 140 * 1024 && ns < (1 << 20); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < GS_WAVE; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *sm, int nwaves) {
+#pragma unroll
+    for (int d = GS_WAVE / 2; d > 0; d >>= 1) v += __shfl_down(v, d);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+    for (int i = 0; i < nwaves; ++i) t += sm[i];
+    return t;
+}
+
+// ---------------------------------------------------------------- level 1
+struct L1Args {
+    const uint16_t *rect;        // fine tile rectangles by gaussian id (1-based inclusive, x0 == 0: none)
+    const uint32_t *perm;        // list position -> gaussian id (null: identity)
+    const uint8_t *sdone;        // per super-tile: completed in an earlier round, takes no entries (null: none)
+    int64_t n, n_slab;           // positions summed for the frame's instance count / positions listed by this round
+    int sgx, ns, G, nwg;         // super-tile grid, positions per workgroup, workgroups covering n_slab
+    uint2 *rect_sorted;          // [n_slab] rectangles in list order (written by l1_hist, read by l1_scatter)
+    uint32_t *table;             // [ns][nwg] coarse instances per (super-tile, workgroup) -> exclusive scan along nwg
+    uint32_t *row_total;         // [ns]
+    uint32_t *partials;          // [3][nwg_all]: per workgroup coarse instances, fine instances of the slab, of all positions
+    uint32_t *totals;            // [3] the sums of `partials` (0xFFFFFFFF: does not fit 32 bits)
+    uint32_t *cranges;           // [ns][2]
+    uint32_t *cids;              // coarse lists: gaussian ids in (super-tile, list order)
+    uint16_t *clr;               //               rectangle clipped to the super-tile: lx0 | lx1 << 3 | ly0 << 6 | ly1 << 9
+    int nwg_all;
+    uint32_t *tilecnt;           // [ntiles] zeroed here for the level-2 count pass
+    int ntiles;
+};
+
+// One list position per thread (blockDim = G): sets the position's bits in the LDS bitmap bm[ns][G / 32].
+template <bool FROM_SORTED>
+__device__ __forceinline__ void l1_bitmap(const L1Args &a, uint32_t *bm, int64_t base, uint2 &rr, uint32_t &coarse, uint32_t &fine_slab,
+                                          uint32_t &fine_all) {
+    const int b = threadIdx.x, wpr = a.G >> 5;
+    const int64_t s = base + b;
+    coarse = fine_slab = fine_all = 0;
+    rr = make_uint2(0u, 0u);
+    if (s < a.n) {
+        if (FROM_SORTED) { if (s < a.n_slab) rr = a.rect_sorted[s]; }
+        else rr = reinterpret_cast<const uint2 *>(a.rect)[a.perm ? (int64_t)a.perm[s] : s];
+    }
+    const uint32_t x0 = rr.x & 0xFFFFu, x1 = rr.x >> 16, y0 = rr.y & 0xFFFFu, y1 = rr.y >> 16;
+    if (x0 == 0u) return;
+    const uint32_t area = (x1 - x0 + 1u) * (y1 - y0 + 1u);
+    fine_all = area;
+    if (s >= a.n_slab) return;
+    fine_slab = area;
+    const int cx0 = (int)(x0 - 1u) >> SB_SHIFT, cx1 = (int)(x1 - 1u) >> SB_SHIFT, cy0 = (int)(y0 - 1u) >> SB_SHIFT, cy1 = (int)(y1 - 1u) >> SB_SHIFT;
+    const uint32_t bit = 1u << (b & 31);
+    uint32_t *col = bm + (b >> 5);
+    for (int cy = cy0; cy <= cy1; ++cy)
+        for (int cx = cx0; cx <= cx1; ++cx) {
+            const int S = cy * a.sgx + cx;
+            if (a.sdone && a.sdone[S]) continue;
+            atomicOr(&col[S * wpr], bit);
+            ++coarse;
+        }
+}
+
+// row popcounts of the bitmap with all threads: wpr / 4 lanes share a row (four words each), rows_per_pass rows at a time.
+// pre (may be null): set bits of the row below each word; rowcnt[S] = set bits of the row
+__device__ __forceinline__ void l1_row_counts(const uint32_t *bm, int ns, int wpr, uint16_t *pre, uint32_t *rowcnt) {
+    const int tid = threadIdx.x, lpr = wpr >> 2;            // lanes per row: 8 (G = 1024), 4, 2
+    const int rows_per_pass = blockDim.x / lpr;
+    const int sub = tid % lpr;
+    for (int S0 = 0; S0 < ns; S0 += rows_per_pass) {
+        const int S = S0 + tid / lpr;
+        uint32_t c[4] = {0, 0, 0, 0};
+        if (S < ns) {
+            const uint4 w4 = *reinterpret_cast<const uint4 *>(bm + S * wpr + sub * 4);
+            c[0] = (uint32_t)__popc(w4.x); c[1] = (uint32_t)__popc(w4.y); c[2] = (uint32_t)__popc(w4.z); c[3] = (uint32_t)__popc(w4.w);
+        }
+        const uint32_t tot = c[0] + c[1] + c[2] + c[3];
+        uint32_t incl = tot;
+        for (int d = 1; d < lpr; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (sub >= d) incl += u; }
+        if (S < ns) {
+            uint32_t e = incl - tot;
+            if (pre) {
+                uint16_t *p = pre + S * wpr + sub * 4;
+                p[0] = (uint16_t)e; p[1] = (uint16_t)(e + c[0]); p[2] = (uint16_t)(e + c[0] + c[1]); p[3] = (uint16_t)(e + c[0] + c[1] + c[2]);
+            }
+            if (sub == lpr - 1) rowcnt[S] = incl;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void l1_hist_kernel(L1Args a) {
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t sm[16];
+    uint32_t *bm = lds;
+    uint32_t *rowcnt = lds + a.ns * (a.G >> 5);
+    const int tid = threadIdx.x, wpr = a.G >> 5, nt = blockDim.x;
+    const int64_t base = (int64_t)blockIdx.x * a.G;
+    const bool listed = base < a.n_slab;                    // workgroups beyond the slab only add up the frame's instance count
+    if (listed) {
+        for (int i = tid; i < a.ns * wpr; i += nt) bm[i] = 0;
+        __syncthreads();
+    }
+    uint2 rr;
+    uint32_t coarse, fs, fa;
+    l1_bitmap<false>(a, bm, base, rr, coarse, fs, fa);
+    if (listed) {
+        if (base + tid < a.n_slab) a.rect_sorted[base + tid] = rr;
+        __syncthreads();
+        l1_row_counts(bm, a.ns, wpr, nullptr, rowcnt);
+        __syncthreads();
+        for (int S = tid; S < a.ns; S += nt) a.table[(size_t)S * a.nwg + blockIdx.x] = rowcnt[S];
+    }
+    coarse = block_sum_u32(coarse, sm, nt >> 6);
+    fs = block_sum_u32(fs, sm, nt >> 6);
+    fa = block_sum_u32(fa, sm, nt >> 6);
+    if (tid == 0) { a.partials[blockIdx.x] = coarse; a.partials[a.nwg_all + blockIdx.x] = fs; a.partials[2 * (size_t)a.nwg_all + blockIdx.x] = fa; }
+}
+
+// blocks 0 .. ns-1: exclusive scan of table row S along the workgroups + the row total; blocks ns .. ns+2: the three totals;
+// further blocks: zero the per-tile hit counters of the level-2 count pass
+__global__ __launch_bounds__(256) void l1_rowscan_kernel(L1Args a) {
+    __shared__ uint32_t sm[4];
+    __shared__ unsigned long long wide[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if ((int)blockIdx.x >= a.ns + 3) {
+        const int i = ((int)blockIdx.x - a.ns - 3) * 256 + tid;
+        if (i < a.ntiles) a.tilecnt[i] = 0;
+        return;
+    }
+    if ((int)blockIdx.x >= a.ns) {
+        const int which = (int)blockIdx.x - a.ns;
+        const uint32_t *p = a.partials + (size_t)which * a.nwg_all;
+        unsigned long long t = 0;
+        for (int i = tid; i < a.nwg_all; i += 256) t += p[i];
+#pragma unroll
+        for (int d = GS_WAVE / 2; d > 0; d >>= 1) t += __shfl_down(t, d);
+        if (lane == 0) wide[wv] = t;
+        __syncthreads();
+        if (tid == 0) { const unsigned long long tot = wide[0] + wide[1] + wide[2] + wide[3]; a.totals[which] = tot >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot; }
+        return;
+    }
+    uint32_t *row = a.table + (size_t)blockIdx.x * a.nwg;
+    uint32_t carry = 0;
+    for (int base = 0; base < a.nwg; base += 256) {
+        const int i = base + tid;
+        const uint32_t v = i < a.nwg ? row[i] : 0u;
+        const uint32_t incl = wave_incl_scan_u32(v, lane);
+        __syncthreads();
+        if (lane == 63) sm[wv] = incl;
+        __syncthreads();
+        uint32_t woff = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (k < wv) woff += sm[k]; all += sm[k]; }
+        if (i < a.nwg) row[i] = carry + woff + incl - v;
+        carry += all;
+    }
+    if (tid == 0) a.row_total[blockIdx.x] = carry;
+}
+
+// staging capacity of l1_scatter (coarse instances per workgroup written as runs; the rare surplus is written directly)
+#define L1_CAP(G) (3 * (G))
+__global__ __launch_bounds__(1024) void l1_scatter_kernel(L1Args a) {
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t sm[32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wpr = a.G >> 5, nt = blockDim.x, nw = nt >> 6;
+    const uint32_t cap = (uint32_t)L1_CAP(a.G);
+    uint32_t *bm = lds;                                                 // [ns][wpr]
+    uint32_t *gstart = bm + a.ns * wpr;                                 // [ns] first position of (S, this workgroup) in the coarse lists
+    uint32_t *lstart = gstart + a.ns;                                   // [ns] first staging slot of S
+    uint32_t *st_id = lstart + a.ns;                                    // [cap] staged gaussian ids, grouped by super-tile
+    uint32_t *st_ls = st_id + cap;                                      // [cap] clipped rectangle | S << 12
+    uint16_t *pre = reinterpret_cast<uint16_t *>(st_ls + cap);          // [ns][wpr] set bits of the row below word w
+    const int64_t base = (int64_t)blockIdx.x * a.G;
+    // issued first, used after the bitmap phase: the list-start operands of the first scan pass (all of them when ns <= G)
+    const uint32_t v_first = tid < a.ns ? a.row_total[tid] : 0u;
+    const uint32_t tb_first = tid < a.ns ? a.table[(size_t)tid * a.nwg + blockIdx.x] : 0u;
+    for (int i = tid; i < a.ns * wpr; i += nt) bm[i] = 0;
+    __syncthreads();
+    uint2 rr;
+    uint32_t coarse, fs, fa;
+    l1_bitmap<true>(a, bm, base, rr, coarse, fs, fa);
+    const int64_t s = base + tid;
+    const uint32_t gid = (rr.x & 0xFFFFu) && s < a.n_slab ? (a.perm ? a.perm[s] : (uint32_t)s) : 0u;
+    __syncthreads();
+    l1_row_counts(bm, a.ns, wpr, pre, lstart);
+    __syncthreads();
+    // two exclusive scans over the super-tiles: the list starts (row totals; every workgroup redoes it: ns words) and the
+    // staging starts (this workgroup's row counts)
+    uint32_t carry = 0, lcarry = 0;
+    for (int b0 = 0; b0 < a.ns; b0 += nt) {
+        const int S = b0 + tid;
+        const uint32_t lc = S < a.ns ? lstart[S] : 0u;
+        uint32_t v = v_first, tb = tb_first;
+        if (b0 > 0) { v = S < a.ns ? a.row_total[S] : 0u; tb = S < a.ns ? a.table[(size_t)S * a.nwg + blockIdx.x] : 0u; }
+        const uint32_t incl = wave_incl_scan_u32(v, lane), lincl = wave_incl_scan_u32(lc, lane);
+        __syncthreads();
+        if (lane == 63) { sm[wv] = incl; sm[16 + wv] = lincl; }
+        __syncthreads();
+        uint32_t woff = 0, all = 0, lwoff = 0, lall = 0;
+        for (int k = 0; k < nw; ++k) {
+            if (k < wv) { woff += sm[k]; lwoff += sm[16 + k]; }
+            all += sm[k]; lall += sm[16 + k];
+        }
+        if (S < a.ns) {
+            const uint32_t st = carry + woff + incl - v;
+            gstart[S] = st + tb;
+            lstart[S] = lcarry + lwoff + lincl - lc;
+            if (blockIdx.x == 0) { a.cranges[2 * S] = st; a.cranges[2 * S + 1] = st + v; }
+        }
+        carry += all; lcarry += lall;
+    }
+    __syncthreads();
+    const uint32_t x0 = rr.x & 0xFFFFu;
+    if (x0 != 0u && s < a.n_slab) {
+        const int fx0 = (int)x0 - 1, fx1 = (int)(rr.x >> 16) - 1, fy0 = (int)(rr.y & 0xFFFFu) - 1, fy1 = (int)(rr.y >> 16) - 1;
+        const int cx0 = fx0 >> SB_SHIFT, cx1 = fx1 >> SB_SHIFT, cy0 = fy0 >> SB_SHIFT, cy1 = fy1 >> SB_SHIFT;
+        const uint32_t below = (1u << (tid & 31)) - 1u;
+        const int w = tid >> 5;
+        for (int cy = cy0; cy <= cy1; ++cy) {
+            const int oy = cy << SB_SHIFT;
+            const uint32_t lry = (uint32_t)(((max(fy0, oy) - oy) << 6) | ((min(fy1, oy + SB - 1) - oy) << 9));
+            for (int cx = cx0; cx <= cx1; ++cx) {
+                const int S = cy * a.sgx + cx;
+                if (a.sdone && a.sdone[S]) continue;
+                const uint32_t rank = pre[S * wpr + w] + (uint32_t)__popc(bm[S * wpr + w] & below);
+                const int ox = cx << SB_SHIFT;
+                const uint32_t lr = lry | (uint32_t)((max(fx0, ox) - ox) | ((min(fx1, ox + SB - 1) - ox) << 3));
+                const uint32_t lp = lstart[S] + rank;
+                if (lp < cap) { st_id[lp] = gid; st_ls[lp] = lr | ((uint32_t)S << 12); }
+                else { const uint32_t pos = gstart[S] + rank; a.cids[pos] = gid; a.clr[pos] = (uint16_t)lr; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t staged = min(lcarry, cap);
+    for (uint32_t j = tid; j < staged; j += nt) {                       // runs: consecutive slots of a super-tile are consecutive list positions
+        const uint32_t ls = st_ls[j], S = ls >> 12;
+        const uint32_t pos = gstart[S] + (j - lstart[S]);
+        a.cids[pos] = st_id[j];
+        a.clr[pos] = (uint16_t)(ls & 0xFFFu);
+    }
+}
+
+// ---------------------------------------------------------------- level 2
+// Work item blockIdx.x -> (super-tile S, entries [e0, e1) of its list, w0 = first work item of S).  Every workgroup
+// rebuilds the prefix of the per-super-tile segment counts from the coarse ranges (ns <= a few thousand words from L2).
+template <int NT>
+__device__ bool find_work(const GsBin3Args &a, uint32_t *sh, int &S, uint32_t &e0, uint32_t &e1, uint32_t &w0) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t w = blockIdx.x;
+    if (tid == 0) { sh[8] = 0xFFFFFFFFu; sh[9] = 0; }
+    uint32_t carry = 0;
+    for (int base = 0; base < a.ns; base += NT) {
+        const int s = base + tid;
+        uint32_t nseg = 0, c0 = 0, c1 = 0;
+        if (s < a.ns) { const uint2 cr = reinterpret_cast<const uint2 *>(a.cranges)[s]; c0 = cr.x; c1 = cr.y; nseg = (c1 - c0 + (L2_SEG - 1)) / L2_SEG; }
+        const uint32_t incl = wave_incl_scan_u32(nseg, lane);
+        __syncthreads();                                   // sh[0..7] free again (and the initial sh[8] visible)
+        if (lane == 63) sh[wv] = incl;
+        __syncthreads();
+        uint32_t woff = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < NT / GS_WAVE; ++k) { if (k < wv) woff += sh[k]; all += sh[k]; }
+        const uint32_t excl = carry + woff + incl - nseg;
+        if (nseg && excl <= w && w < excl + nseg) { sh[8] = (uint32_t)s; sh[9] = excl; sh[10] = c0; sh[11] = c1; }
+        carry += all;
+        if (carry > w) break;                              // uniform: carry is the same in every thread
+    }
+    __syncthreads();
+    if (sh[8] == 0xFFFFFFFFu) return false;
+    S = (int)sh[8]; w0 = sh[9];
+    const uint32_t c0 = sh[10], c1 = sh[11];
+    e0 = c0 + (w - w0) * L2_SEG;
+    e1 = min(c1, e0 + L2_SEG);
+    return true;
+}
+
+// Hits per (segment, local tile): every entry adds the four corners of its clipped rectangle to a 9 x 9 difference array;
+// 16 private copies (lane & 15) keep the lanes of one LDS atomic instruction off each other's cells (rectangles that
+// cover the whole super-tile all hit the same four corners).
+#define CNT_COPIES 16
+#define CNT_CELLS ((SB + 1) * (SB + 1))
+__global__ __launch_bounds__(L2_THREADS) void l2_count_kernel(GsBin3Args a) {
+    __shared__ int diff[CNT_COPIES * CNT_CELLS];
+    __shared__ uint32_t sh[12];
+    int S; uint32_t e0, e1, w0;
+    if (!find_work<L2_THREADS>(a, sh, S, e0, e1, w0)) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < CNT_COPIES * CNT_CELLS; i += L2_THREADS) diff[i] = 0;
+    __syncthreads();
+    int *my = diff + (tid & (CNT_COPIES - 1)) * CNT_CELLS;
+    for (uint32_t e = e0 + tid; e < e1; e += L2_THREADS) {
+        const uint32_t lr = a.clr[e];
+        const int lx0 = lr & 7, lx1 = (lr >> 3) & 7, ly0 = (lr >> 6) & 7, ly1 = (lr >> 9) & 7;
+        atomicAdd(&my[ly0 * (SB + 1) + lx0], 1);
+        atomicAdd(&my[ly0 * (SB + 1) + lx1 + 1], -1);
+        atomicAdd(&my[(ly1 + 1) * (SB + 1) + lx0], -1);
+        atomicAdd(&my[(ly1 + 1) * (SB + 1) + lx1 + 1], 1);
+    }
+    __syncthreads();
+    if (tid < CNT_CELLS) {
+        int s = 0;
+#pragma unroll
+        for (int c = 0; c < CNT_COPIES; ++c) s += diff[c * CNT_CELLS + tid];
+        diff[tid] = s;                                     // copy 0 now holds the sum (each cell is read and written by its own thread)
+    }
+    __syncthreads();
+    if (tid < SB * SB) {
+        const int ty = tid >> SB_SHIFT, tx = tid & (SB - 1);
+        int s = 0;
+        for (int y = 0; y <= ty; ++y)
+            for (int x = 0; x <= tx; ++x) s += diff[y * (SB + 1) + x];
+        a.segcnt[(size_t)blockIdx.x * (SB * SB) + tid] = (uint32_t)s;
+        const int gtx = (S % a.sgx) * SB + tx, gty = (S / a.sgx) * SB + ty;
+        if (s && gtx < a.gx && gty < a.gy) atomicAdd(&a.tilecnt[gty * a.gx + gtx], (uint32_t)s);   // the tile's list length (integer adds commute)
+    }
+}
+
+// tile ranges = exclusive scan of the tile counts in tile order (one workgroup); completed tiles get an empty range
+__global__ __launch_bounds__(1024) void l2_ranges_kernel(const uint32_t *__restrict__ tilecnt, int ntiles, const uint8_t *__restrict__ done,
+                                                          uint32_t *__restrict__ ranges) {
+    __shared__ uint32_t sm[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < ntiles; b0 += 1024 * 4) {
+        uint32_t v[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = b0 + tid * 4 + k;
+            v[k] = t < ntiles && !(done && done[t]) ? tilecnt[t] : 0u;
+            tot += v[k];
+        }
+        const uint32_t incl = wave_incl_scan_u32(tot, lane);
+        __syncthreads();
+        if (lane == 63) sm[wv] = incl;
+        __syncthreads();
+        uint32_t woff = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { if (k < wv) woff += sm[k]; all += sm[k]; }
+        uint32_t off = carry + woff + incl - tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = b0 + tid * 4 + k;
+            if (t < ntiles) { ranges[2 * t] = off; ranges[2 * t + 1] = off + v[k]; }
+            off += v[k];
+        }
+        carry += all;
+    }
+}
+
+// One wave per tile ROW of the super-tile (8 waves, 8 tiles each).  A wave first compacts the segment's entries to those
+// that touch its row (about half at C3) through a small LDS ring, and runs the per-tile ballots only on full batches of
+// 64 compacted entries: 64 x entries tests become ~ 8 x entries (row filter) + 8 x 0.47 x entries x 8 (tile tests).
+#define L2W_THREADS 512
+#define RING 128
+// cur[k]: byte offset of tile k's cursor from `out` (WIDE: entry index, for lists beyond 4 GB)
+template <bool WIDE>
+__device__ __forceinline__ void emit_batch(uint32_t id, uint32_t m8, uint32_t (&cur)[SB], uint32_t *__restrict__ out) {
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        const bool hit = (m8 & (1u << k)) != 0u;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (WIDE) { if (hit) out[(size_t)cur[k] + rank] = id; cur[k] += (uint32_t)__popcll(bal); }
+        else {
+            if (hit) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(out) + (cur[k] + (rank << 2))) = id;
+            cur[k] += (uint32_t)__popcll(bal) << 2;
+        }
+    }
+}
+template <bool WIDE>
+__global__ __launch_bounds__(L2W_THREADS) void l2_write_kernel(GsBin3Args a) {
+    __shared__ uint32_t sid[L2_SEG];
+    __shared__ uint8_t scol[L2_SEG];                        // column bits of the entry inside the super-tile
+    __shared__ uint8_t srow[L2_SEG];                        // row bits
+    __shared__ uint32_t ring_id[L2W_THREADS / GS_WAVE][RING], ring_m[L2W_THREADS / GS_WAVE][RING];
+    __shared__ uint32_t sh[12];
+    __shared__ uint32_t sdead[2];
+    int S; uint32_t e0, e1, w0;
+    if (!find_work<L2W_THREADS>(a, sh, S, e0, e1, w0)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ox = (S % a.sgx) * SB, oy = (S / a.sgx) * SB;
+    const int cnt = (int)(e1 - e0);
+    constexpr int ITEMS = L2_SEG / L2W_THREADS;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int i = tid + k * L2W_THREADS;
+        if (i < cnt) {
+            const uint32_t lr = a.clr[e0 + i];
+            const int lx0 = lr & 7, lx1 = (lr >> 3) & 7, ly0 = (lr >> 6) & 7, ly1 = (lr >> 9) & 7;
+            sid[i] = a.cids[e0 + i];
+            scol[i] = (uint8_t)((2u << lx1) - (1u << lx0));
+            srow[i] = (uint8_t)((2u << ly1) - (1u << ly0));
+        }
+    }
+    // cursors of the wave's eight tiles (row wv of the super-tile): range start + the hits of the earlier segments
+    uint32_t base = 0;
+    if (lane < SB) {
+        const int t = SB * wv + lane;
+        const int tx = ox + lane, ty = oy + wv;
+        if (tx < a.gx && ty < a.gy) {
+            base = a.ranges[2 * (ty * a.gx + tx)];
+#pragma unroll 8
+            for (uint32_t w = w0; w < blockIdx.x; ++w) base += a.segcnt[(size_t)w * (SB * SB) + t];
+        }
+    }
+    if (wv == 0) {                                         // tiles outside the grid or completed in an earlier round take nothing
+        const int tx = ox + (lane & (SB - 1)), ty = oy + (lane >> SB_SHIFT);
+        const bool dead = tx >= a.gx || ty >= a.gy || (a.done && a.done[ty * a.gx + tx]);
+        const unsigned long long b = __ballot(dead);
+        if (lane == 0) { sdead[0] = (uint32_t)b; sdead[1] = (uint32_t)(b >> 32); }
+    }
+    uint32_t cur[SB];
+#pragma unroll
+    for (int k = 0; k < SB; ++k) cur[k] = __builtin_amdgcn_readlane(WIDE ? base : base << 2, k);
+    __syncthreads();
+    const uint32_t live8 = ~((wv < 4 ? sdead[0] : sdead[1]) >> ((wv & 3) * SB)) & 0xFFu;     // live tiles of this wave's row
+    uint32_t *__restrict__ out = a.ids_out;
+    uint32_t *rid = ring_id[wv], *rm = ring_m[wv];
+    uint32_t fill = 0;
+    if (live8)
+    for (int b = 0; b < cnt; b += GS_WAVE) {
+        const int i = b + lane;
+        uint32_t m8 = 0, id = 0;
+        if (i < cnt && ((srow[i] >> wv) & 1u)) { m8 = scol[i] & live8; id = sid[i]; }
+        const bool touch = m8 != 0u;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(touch);
+        if (bal == 0ull) continue;
+        const uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (touch) { rid[pos] = id; rm[pos] = m8; }
+        fill += (uint32_t)__popcll(bal);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (fill >= GS_WAVE) {                              // uniform
+            const uint32_t bid = rid[lane], bm = rm[lane];
+            const uint32_t tid2 = rid[GS_WAVE + lane], tm2 = rm[GS_WAVE + lane];
+            emit_batch<WIDE>(bid, bm, cur, out);
+            fill -= GS_WAVE;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if ((uint32_t)lane < fill) { rid[lane] = tid2; rm[lane] = tm2; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    if (fill) {
+        uint32_t bid = 0, bm = 0;
+        if ((uint32_t)lane < fill) { bid = rid[lane]; bm = rm[lane]; }
+        emit_batch<WIDE>(bid, bm, cur, out);
+    }
+}
+
+// sdone[S] = 1 when every tile of super-tile S that lies inside the grid completed in an earlier round
+__global__ __launch_bounds__(L2_THREADS) void super_done_kernel(const uint8_t *__restrict__ done, int gx, int gy, int sgx, int ns, uint8_t *__restrict__ sdone) {
+    const int lane = threadIdx.x & 63, S = blockIdx.x * (L2_THREADS / GS_WAVE) + (threadIdx.x >> 6);
+    if (S >= ns) return;
+    const int tx = (S % sgx) * SB + (lane & (SB - 1)), ty = (S / sgx) * SB + (lane >> SB_SHIFT);
+    const bool dead = tx >= gx || ty >= gy || done[ty * gx + tx];
+    const unsigned long long b = __ballot(dead);
+    if (lane == 0) sdone[S] = b == ~0ull ? 1 : 0;
+}
+hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, uint8_t *sdone, hipStream_t s) {
+    const int ns = sgx * sgy, per = L2_THREADS / GS_WAVE;
+    hipLaunchKernelGGL(super_done_kernel, dim3((ns + per - 1) / per), dim3(L2_THREADS), 0, s, done, gx, gy, sgx, ns, sdone);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- drivers
+static L1Args l1_args(const GsBin3L1 &b) {
+    L1Args a{};
+    a.rect = b.rect; a.perm = b.perm; a.sdone = b.sdone; a.n = b.n; a.n_slab = b.n_slab; a.sgx = b.sgx; a.ns = b.ns;
+    a.G = gs_bin3_group(b.ns);
+    a.nwg = (int)((b.n_slab + a.G - 1) / a.G); a.nwg_all = (int)((b.n + a.G - 1) / a.G);
+    a.rect_sorted = reinterpret_cast<uint2 *>(b.rect_sorted); a.table = b.table; a.row_total = b.row_total;
+    a.partials = b.partials; a.totals = b.totals; a.cranges = b.cranges; a.cids = b.cids; a.clr = b.clr;
+    a.tilecnt = b.tilecnt; a.ntiles = b.ntiles;
+    return a;
+}
+size_t gs_bin3_table_words(int64_t n_slab, int ns) { const int G = gs_bin3_group(ns); return (size_t)ns * (size_t)((n_slab + G - 1) / G + 1); }
+size_t gs_bin3_partial_words(int64_t n, int ns) { const int G = gs_bin3_group(ns); return 3 * (size_t)((n + G - 1) / G + 1); }
+
+// histogram + scan: after this the three totals (coarse instances of the slab, fine instances of the slab, of all n) are on the device
+hipError_t gs_bin3_l1_count(const GsBin3L1 &b, hipStream_t s) {
+    const L1Args a = l1_args(b);
+    if (a.nwg_all <= 0) return hipMemsetAsync(b.totals, 0, 3 * sizeof(uint32_t), s);
+    const size_t lds = sizeof(uint32_t) * ((size_t)a.ns * (a.G >> 5) + a.ns);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(l1_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(l1_hist_kernel, dim3(a.nwg_all), dim3(a.G), lds, s, a);
+    hipLaunchKernelGGL(l1_rowscan_kernel, dim3(a.ns + 3 + (a.ntiles + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+// coarse lists (cids, clr, cranges); gs_bin3_l1_count of the same arguments first
+hipError_t gs_bin3_l1_scatter(const GsBin3L1 &b, hipStream_t s) {
+    const L1Args a = l1_args(b);
+    if (a.nwg <= 0) return hipMemsetAsync(b.cranges, 0, 2 * sizeof(uint32_t) * (size_t)b.ns, s);
+    const size_t lds = sizeof(uint32_t) * ((size_t)a.ns * (a.G >> 5) + 2 * (size_t)a.ns + 2 * (size_t)L1_CAP(a.G)) + sizeof(uint16_t) * (size_t)a.ns * (a.G >> 5);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(l1_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(l1_scatter_kernel, dim3(a.nwg), dim3(a.G), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s) {
+    if (a.max_work <= 0) return hipSuccess;
+    hipLaunchKernelGGL(l2_count_kernel, dim3(a.max_work), dim3(L2_THREADS), 0, s, a);
+    hipLaunchKernelGGL(l2_ranges_kernel, dim3(1), dim3(1024), 0, s, a.tilecnt, a.gx * a.gy, a.done, a.ranges);
+    if (a.wide) hipLaunchKernelGGL(l2_write_kernel<true>, dim3(a.max_work), dim3(L2W_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(l2_write_kernel<false>, dim3(a.max_work), dim3(L2W_THREADS), 0, s, a);
+    return hipGetLastError();
+}

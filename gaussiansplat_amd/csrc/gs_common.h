@@ -42,7 +42,6 @@ struct GsPreprocessArgs {
     uint16_t *rect;       // 4 x n : x0 x1 y0 y1 (1-based inclusive, x0 == 0 -> no tile)
     GsDebugArrays dbg;
 };
-
 // launchers (each enqueues on `stream`, returns hipGetLastError())
 hipError_t gs_launch_preprocess(const GsPreprocessArgs &a, const GsCamera &cam, hipStream_t stream);
 
@@ -124,6 +123,48 @@ struct GsBin2Args {
                                       // pass then reads its key count from it (n_inst is only the upper bound used for grids)
 };
 hipError_t gs_bin2_build_lists(const GsBin2Args &b, hipStream_t s);
+
+// two-level binning (gs_bin3.hip): lists per super-tile of 8 x 8 tiles (level 1), then the tile lists as filtered copies of
+// the super-tile lists (level 2)
+struct GsBin3L1 {
+    const uint16_t *rect;      // fine tile rectangles by gaussian id
+    const uint32_t *perm;      // list position -> gaussian id of the round's slab (null: identity)
+    const uint8_t *sdone;      // per super-tile: completed in an earlier round (null: none)
+    int64_t n, n_slab;         // positions whose instances are summed (totals[2]) / positions listed by this round
+    int sgx, ns;
+    uint32_t *rect_sorted;     // 2 x n_slab words: rectangles in list order
+    uint32_t *table;           // gs_bin3_table_words(n_slab, ns)
+    uint32_t *row_total;       // ns
+    uint32_t *partials;        // gs_bin3_partial_words(n, ns)
+    uint32_t *totals;          // 3: coarse instances listed, fine instances of the slab (upper bound of what the round lists), of all n
+    uint32_t *cranges;         // 2 x ns
+    uint32_t *cids;            // totals[0] gaussian ids in (super-tile, list order)
+    uint16_t *clr;             // totals[0] rectangles clipped to the super-tile
+    uint32_t *tilecnt;         // ntiles words: zeroed by gs_bin3_l1_count, accumulated and scanned by gs_bin3_build_lists
+    int ntiles;
+};
+struct GsBin3Args {
+    const uint32_t *cranges;   // 2 x ns: [start, end) of every super-tile's list inside cids
+    const uint32_t *cids;      // gaussian ids in (super-tile, list order)
+    const uint16_t *clr;       // the entries' rectangles clipped to their super-tile (lx0 | lx1 << 3 | ly0 << 6 | ly1 << 9)
+    uint32_t *ranges;          // 2 x tiles: the tile ranges of this round (written here: exclusive scan of the tile counts)
+    uint32_t *tilecnt;         // tiles: hits per tile, zero on entry
+    const uint8_t *done;       // per tile: completed in an earlier round, takes no entries (null: none)
+    uint32_t *segcnt;          // [max_work][64] hits per (segment, local tile)
+    uint32_t *ids_out;         // gaussian ids in (tile, list order)
+    int gx, gy, sgx, ns;
+    int max_work;              // upper bound of the number of (super-tile, segment) work items
+    int wide;                  // the lists reach beyond 4 GB from ids_out: 64-bit store addresses
+};
+int gs_bin3_sb_shift();
+bool gs_bin3_supported(int ns);
+int64_t gs_bin3_max_work(int64_t coarse_instances, int ns);
+size_t gs_bin3_table_words(int64_t n_slab, int ns);
+size_t gs_bin3_partial_words(int64_t n, int ns);
+hipError_t gs_bin3_l1_count(const GsBin3L1 &b, hipStream_t s);
+hipError_t gs_bin3_l1_scatter(const GsBin3L1 &b, hipStream_t s);
+hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s);
+hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, uint8_t *sdone, hipStream_t s);
 
 #define GS_MAX_ROUNDS 4   // binning rounds (depth slabs) of one frame
 #define GS_G2D_STRIDE 10   // floats (or fixed-point words) per gaussian row of the composite backward's sums
