@@ -186,6 +186,7 @@ int composite_sched(gs_ctx *c, GsCompositeArgs &a, int which) {
     HIPCHK(c, c->tile_work.ensure(sizeof(uint32_t) * (size_t)(ntiles ? ntiles : 1)));
     if (which == 0) a.tile_work = c->tile_work.as<uint32_t>();
     if (c->cfg.schedule == 3 || c->cfg.schedule == 4) {                      // plain launch; the backward's tiles heaviest first (by the forward's count)
+        if (ntiles > 35000) return GS_OK;                                    // beyond the order kernel's LDS (8K-class images): launch order
         if (which == 0 && c->cfg.schedule == 4 && c->tile_work_valid_tiles == ntiles && ntiles > 0) {
             // opt-in: the forward's tiles by the work the PREVIOUS forward of this ctx measured on the same tile grid (pays when
             // consecutive frames see similar views; with an unrelated view it degrades to an arbitrary order, which costs nothing)

@@ -718,19 +718,34 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 // work / max in 256 steps; tiles inside a bucket keep no particular order.  work = src[t], or the list length (ranges_mode).
 __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles,
                                                                uint32_t *__restrict__ order) {
+    extern __shared__ uint32_t wk[];                                     // the tiles' work, read from memory once
     __shared__ uint32_t hist[2048];                                      // [residue][bucket], bucket 0 = heaviest
     __shared__ uint32_t wmax;
     const int tid = threadIdx.x;
     hist[tid] = 0; hist[tid + 1024] = 0;
     if (tid == 0) wmax = 1;
     __syncthreads();
-    auto work = [&](int t) -> uint32_t { return ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t]; };
     uint32_t m = 0;
-    for (int t = tid; t < ntiles; t += 1024) m = max(m, work(t));
-    atomicMax(&wmax, m);
+    for (int t0 = 0; t0 < ntiles; t0 += 8 * 1024) {                     // eight independent loads in flight per thread
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * 1024 + tid;
+            v[k] = 0;
+            if (t < ntiles) v[k] = ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * 1024 + tid;
+            if (t < ntiles) { wk[t] = v[k]; m = max(m, v[k]); }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if ((tid & 63) == 0) atomicMax(&wmax, m);
     __syncthreads();
     const float scale = 255.0f / (float)wmax;
-    auto bucket = [&](int t) -> int { return (t & 7) * 256 + 255 - (int)((float)work(t) * scale); };
+    auto bucket = [&](int t) -> int { return (t & 7) * 256 + 255 - (int)((float)wk[t] * scale); };
     for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[bucket(t)], 1u);
     __syncthreads();
     if (tid < 512) {                                                     // eight independent exclusive scans of 256 counters: one wave each
@@ -750,7 +765,13 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
 }
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), 0, s, work_or_ranges, ranges_mode, ntiles, order);
+    const size_t lds = sizeof(uint32_t) * (size_t)ntiles;
+    if (lds > 140 * 1024) return hipErrorInvalidValue;                   // 35 840 tiles: beyond 8K images
+    if (lds > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_lpt_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, order);
     return hipGetLastError();
 }
 

@@ -30,25 +30,28 @@ size_t gs_sort_table_entries(int64_t n_max) {
 // keys32 != null (first pass of the depth sort): the keys are the 32-bit depth keys themselves; the pair (key << 32 | index)
 // is never stored before the first scatter.  digit_total != null: the 256 digit totals are accumulated here with one atomic
 // per (workgroup, digit) -- for the small tables of the depth sort that saves the separate totals launch.
-__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ keys32, int64_t n,
-                                                              int shift, uint32_t mask, uint32_t *__restrict__ block_hist, int nblocks,
-                                                              uint32_t *__restrict__ digit_total) {
+template <int NT>
+__global__ __launch_bounds__(NT) void rs_hist_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ keys32, int64_t n,
+                                                      int shift, uint32_t mask, uint32_t *__restrict__ block_hist, int nblocks,
+                                                      uint32_t *__restrict__ digit_total) {
     __shared__ uint32_t h[RS_RADIX];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < RS_RADIX) h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; ++i) {
-        const int64_t idx = base + (int64_t)i * RS_THREADS + threadIdx.x;
+    for (int i = 0; i < RS_CHUNK / NT; ++i) {
+        const int64_t idx = base + (int64_t)i * NT + threadIdx.x;
         if (idx < n) {
             const uint32_t dg = keys32 ? ((keys32[idx] >> (shift - 32)) & mask) : ((uint32_t)(keys[idx] >> shift) & mask);
             atomicAdd(&h[dg], 1u);
         }
     }
     __syncthreads();
-    const uint32_t c = h[threadIdx.x];
-    block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = c;   // [digit][block]
-    if (digit_total && c) atomicAdd(&digit_total[threadIdx.x], c);
+    if (threadIdx.x < RS_RADIX) {
+        const uint32_t c = h[threadIdx.x];
+        block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = c;   // [digit][block]
+        if (digit_total && c) atomicAdd(&digit_total[threadIdx.x], c);
+    }
 }
 
 // ---------------------------------------------------------------- radix pass: scan
@@ -86,8 +89,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_totals_kernel(const uint3
     if (threadIdx.x == 0) digit_total[blockIdx.x] = s;
 }
 
+// row_total_out != null ("relative" mode of the small sorts): digit_total is not read, the row is scanned from zero and its
+// total is stored; the scatter kernel adds the totals of the smaller digits itself (no totals pass, no atomics)
 __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restrict__ block_hist, int nblocks,
-                                                              const uint32_t *__restrict__ digit_total) {
+                                                              const uint32_t *__restrict__ digit_total, uint32_t *__restrict__ row_total_out) {
     // one workgroup per digit row.  The row is walked in tiles of 256 x 8 consecutive counters: thread t owns the
     // eight counters [8t, 8t+8) of the tile, so the wave's loads and stores are contiguous 2 KiB runs (the earlier
     // thread-owns-a-slice layout read with a stride of nblocks/256 and ran at 0.7 TB/s on 124 K-block tables)
@@ -95,9 +100,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
     __shared__ uint32_t sm[RS_WAVES];
     __shared__ uint32_t carry_s;
     const int d = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t below = (threadIdx.x < d) ? digit_total[threadIdx.x] : 0u;
-    below = block_reduce_u32(below, sm);
-    __syncthreads();
+    uint32_t below = 0;
+    if (!row_total_out) {
+        below = (threadIdx.x < d) ? digit_total[threadIdx.x] : 0u;
+        below = block_reduce_u32(below, sm);
+        __syncthreads();
+    }
     uint32_t *row = block_hist + (size_t)d * nblocks;
     uint32_t carry = below;
     for (int base = 0; base < nblocks; base += TILE) {
@@ -117,6 +125,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
         __syncthreads();
         carry = carry_s;
     }
+    if (row_total_out && threadIdx.x == 0) row_total_out[d] = carry;
 }
 
 // ---------------------------------------------------------------- radix pass: stable scatter
@@ -125,34 +134,52 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
 // the set of lanes holding the same digit) and a per-wave running LDS counter; keys are then
 // placed digit-contiguously in LDS and written out in runs.
 // out32 != null (last pass of a (key | id) pair sort): only the low word -- the id -- is written, as 32 bits.
-template <bool ATOMIC_RANK>
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ in32,
-                                                                 uint64_t *__restrict__ out,
-                                                                 int64_t n, int shift, uint32_t mask,
-                                                                 const uint32_t *__restrict__ block_hist, int nblocks,
-                                                                 uint32_t *__restrict__ out32) {
+// NT threads per 4096-key chunk: 256 (sixteen rounds per wave) for the big instance sorts, 1024 (four rounds, sixteen waves)
+// for the depth sort, whose 244 workgroups at 1 M gaussians would otherwise leave one wave per SIMD to hide every latency.
+template <int NT, bool ATOMIC_RANK>
+__global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ in32,
+                                                         uint64_t *__restrict__ out,
+                                                         int64_t n, int shift, uint32_t mask,
+                                                         const uint32_t *__restrict__ block_hist, int nblocks,
+                                                         uint32_t *__restrict__ out32, const uint32_t *__restrict__ row_total) {
+    constexpr int NW = NT / GS_WAVE, ITEMS = RS_CHUNK / NT;
     __shared__ uint64_t skeys[RS_CHUNK];                 // 32 KiB
-    __shared__ uint32_t wcnt[RS_WAVES][RS_RADIX];        // running count per (wave, digit)
+    __shared__ uint32_t wcnt[NW][RS_RADIX];              // running count per (wave, digit)
     __shared__ uint32_t lpre[RS_RADIX];                  // exclusive prefix over digits in this chunk
     __shared__ uint32_t gbase[RS_RADIX];
-    __shared__ uint32_t sm[RS_WAVES];
+    __shared__ uint32_t sm[RS_RADIX / GS_WAVE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
     const int64_t remain = n - base;
     const int cnt = remain < RS_CHUNK ? (int)remain : RS_CHUNK;
-#pragma unroll
-    for (int k = 0; k < RS_WAVES; ++k) wcnt[k][tid] = 0;
-    gbase[tid] = block_hist[(size_t)tid * nblocks + blockIdx.x];
+    for (int i = tid; i < NW * RS_RADIX; i += NT) (&wcnt[0][0])[i] = 0;
+    {   // table entry (+ in relative mode the totals of the smaller digits: exclusive scan of the 256 row totals)
+        uint32_t g = 0, t = 0;
+        if (tid < RS_RADIX) { g = block_hist[(size_t)tid * nblocks + blockIdx.x]; if (row_total) t = row_total[tid]; }
+        if (row_total) {
+            const uint32_t incl = wave_incl_scan(t, lane);
+            if (tid < RS_RADIX && lane == 63) sm[w] = incl;
+            __syncthreads();
+            if (tid < RS_RADIX) { for (int k = 0; k < w; ++k) g += sm[k]; g += incl - t; }
+            __syncthreads();
+        }
+        if (tid < RS_RADIX) gbase[tid] = g;
+    }
     __syncthreads();
 
-    uint64_t key[RS_ITEMS];
-    uint32_t rank[RS_ITEMS];
+    uint64_t key[ITEMS];
+    uint32_t rank[ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        const int li = w * (GS_WAVE * RS_ITEMS) + r * GS_WAVE + lane;    // index inside the chunk
+    for (int r = 0; r < ITEMS; ++r) {
+        const int li = w * (GS_WAVE * ITEMS) + r * GS_WAVE + lane;      // index inside the chunk
         const bool valid = li < cnt;
         key[r] = !valid ? ~0ull : in32 ? (((uint64_t)in32[base + li] << 32) | (uint32_t)(base + li)) : in[base + li];
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int li = w * (GS_WAVE * ITEMS) + r * GS_WAVE + lane;
+        const bool valid = li < cnt;
         const uint32_t dg = valid ? ((uint32_t)(key[r] >> shift) & mask) : (RS_RADIX - 1);
         if (ATOMIC_RANK) {                                              // see gs_bin2.hip rank_round_atomic
             rank[r] = 0;
@@ -174,20 +201,22 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     __syncthreads();
     // thread `tid` == digit: per-wave exclusive offsets and the chunk's digit prefix
     uint32_t tot = 0;
+    if (tid < RS_RADIX) {
 #pragma unroll
-    for (int k = 0; k < RS_WAVES; ++k) { const uint32_t c = wcnt[k][tid]; wcnt[k][tid] = tot; tot += c; }
-    {
-        const uint32_t incl = wave_incl_scan(tot, lane);
-        if (lane == 63) sm[w] = incl;
-        __syncthreads();
+        for (int k = 0; k < NW; ++k) { const uint32_t c = wcnt[k][tid]; wcnt[k][tid] = tot; tot += c; }
+    }
+    const uint32_t incl = wave_incl_scan(tot, lane);
+    if (tid < RS_RADIX && lane == 63) sm[w] = incl;
+    __syncthreads();
+    if (tid < RS_RADIX) {
         uint32_t woff = 0;
         for (int k = 0; k < w; ++k) woff += sm[k];
         lpre[tid] = woff + incl - tot;
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        const int li = w * (GS_WAVE * RS_ITEMS) + r * GS_WAVE + lane;
+    for (int r = 0; r < ITEMS; ++r) {
+        const int li = w * (GS_WAVE * ITEMS) + r * GS_WAVE + lane;
         if (li < cnt) {
             const uint32_t dg = (uint32_t)(key[r] >> shift) & mask;
             skeys[lpre[dg] + wcnt[w][dg] + rank[r]] = key[r];
@@ -195,8 +224,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        const int li = r * RS_THREADS + tid;
+    for (int r = 0; r < ITEMS; ++r) {
+        const int li = r * NT + tid;
         if (li < cnt) {
             const uint64_t k = skeys[li];
             const uint32_t dg = (uint32_t)(k >> shift) & mask;
@@ -249,13 +278,12 @@ hipError_t gs_probe_lds_atomic_order(hipStream_t s, int *mismatches) {
 
 hipError_t gs_launch_radix_scan(uint32_t *block_hist, int nblocks, uint32_t *digit_total, hipStream_t stream) {
     hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total, (uint32_t *)nullptr);
     return hipGetLastError();
 }
 
 // keys32 != null: the first pass reads the 32-bit keys and forms (key << 32 | index) on the fly (`a` is then only scratch).
-// Small tables (the depth sort: n / 4096 <= 2048 chunks) fold the digit totals into the histogram kernel (atomics on four
-// zeroed 256-word slices of digit_total, which must then hold 4 x 256 words): 3 launches per pass instead of 4.
+// digit_total must hold 4 x 256 words.
 hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, int bit_hi,
                              uint32_t *block_hist, uint32_t *digit_total, int *result_in_b, hipStream_t stream, bool ballot_ranks,
                              uint32_t *final_low32, const uint32_t *keys32) {
@@ -267,24 +295,29 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
     const int total = bit_hi - bit_lo;
     const int passes = (total + 7) / 8;
     const int width = (total + passes - 1) / passes;
-    const bool fused_totals = keys32 != nullptr && nblocks <= 2048 && passes <= 4;
-    if (fused_totals) {
-        hipError_t e = hipMemsetAsync(digit_total, 0, sizeof(uint32_t) * 4 * RS_RADIX, stream);
-        if (e != hipSuccess) return e;
-    }
+    // small sorts (the depth sort: at most 2048 chunks) run 1024 threads per chunk -- same chunks and table, four times the
+    // waves in flight -- and need no totals pass: the scan stores each digit row's total (digit_total + 256 pass) and the
+    // scatter adds up the totals of the smaller digits itself.  3 launches per pass, no atomics.
+    const bool small = nblocks <= 2048 && passes <= 4;
     int pass = 0;
     for (int shift = bit_lo; shift < bit_hi; shift += width, ++pass) {
         const int bits = (bit_hi - shift) < width ? (bit_hi - shift) : width;
         const uint32_t mask = (1u << bits) - 1u;
         const uint32_t *k32 = pass == 0 ? keys32 : nullptr;
-        uint32_t *tot = fused_totals ? digit_total + pass * RS_RADIX : digit_total;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, k32, n, shift, mask, block_hist, nblocks,
-                           fused_totals ? tot : (uint32_t *)nullptr);
-        if (!fused_totals) hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, tot);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, tot);
         uint32_t *o32 = (final_low32 && shift + width >= bit_hi) ? final_low32 : nullptr;      // last pass: ids only
-        if (ballot_ranks) hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32);
-        else hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32);
+        if (small) {
+            uint32_t *tot = digit_total + pass * RS_RADIX;
+            hipLaunchKernelGGL(rs_hist_kernel<1024>, dim3(nblocks), dim3(1024), 0, stream, src, k32, n, shift, mask, block_hist, nblocks, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, (const uint32_t *)nullptr, tot);
+            if (ballot_ranks) hipLaunchKernelGGL((rs_scatter_kernel<1024, false>), dim3(nblocks), dim3(1024), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32, tot);
+            else hipLaunchKernelGGL((rs_scatter_kernel<1024, true>), dim3(nblocks), dim3(1024), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32, tot);
+        } else {
+            hipLaunchKernelGGL(rs_hist_kernel<RS_THREADS>, dim3(nblocks), dim3(RS_THREADS), 0, stream, src, k32, n, shift, mask, block_hist, nblocks, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total);
+            hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, digit_total, (uint32_t *)nullptr);
+            if (ballot_ranks) hipLaunchKernelGGL((rs_scatter_kernel<RS_THREADS, false>), dim3(nblocks), dim3(RS_THREADS), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32, (const uint32_t *)nullptr);
+            else hipLaunchKernelGGL((rs_scatter_kernel<RS_THREADS, true>), dim3(nblocks), dim3(RS_THREADS), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32, (const uint32_t *)nullptr);
+        }
         uint64_t *t = src; src = dst; dst = t;
         *result_in_b ^= 1;
     }
