@@ -193,7 +193,9 @@ __device__ __forceinline__ Entry load_entry(const float4 *sp, const float *syhi,
 }
 
 // ---------------------------------------------------------------- forward
-template <bool EARLY, bool CULL>
+template <bool EARLY, bool CULL, bool LEAN>
+// LEAN (A/B variant 2 of the forward): no register prefetch of the next batch and no 2-entry interleave, to fit 64 VGPRs =
+// eight waves per SIMD, i.e. every tile of a 1080p frame resident at once.
 // (Skipping the dead 16 x 4 strips of an entry with wave-uniform branches, as the backward does, was measured on the forward
 // too: 0.352 vs 0.357 ms at C3 -- its per-strip work is a 12-instruction dependent chain, the branches cost what they save.)
 __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, const float nbig) {
@@ -235,7 +237,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t pos = s0 + lane;
-    if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+    if (!LEAN && pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
     uint32_t gp = gp0;                                                  // list position of `base` in the tile's whole list
     for (uint32_t base = s0; base < s1;) {
         const uint32_t phase = gp & (CB - 1);
@@ -252,6 +254,11 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         float4 q0, q1, q2;
         uint32_t strips;
         bool keep;
+        if (LEAN) {
+            n0 = n1 = n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            pos = base + lane;
+            if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+        }
         const float yhi_l = stage_record<false>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
         int slot = lane, nk = cnt;
         if (!CULL) keep = true;
@@ -268,8 +275,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         __syncthreads();
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
-        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
-#pragma unroll 2
+        if (!LEAN && pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+#pragma clang loop unroll_count(LEAN ? 1 : 2)
         for (int k = 0; k < nk; ++k) {
             const Entry e = load_entry(sp, syhi, k);
             const float dX = fx - e.q0.x;
@@ -319,14 +326,14 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     }
 }
 
-template <bool EARLY, int MINW, bool CULL>
+template <bool EARLY, int MINW, bool CULL, bool LEAN = false>
 __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
-        forward_tile<EARLY, CULL>(a, tile, sp, syhi, nbig);
+        forward_tile<EARLY, CULL, LEAN>(a, tile, sp, syhi, nbig);
         __syncthreads();                                                // the next tile restages sp[]
     }
 }
@@ -813,7 +820,8 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
-#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
+#define GS_F(E) do { if (a.variant % 10 == 2 && a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 8, true, true>), grid, block, debug_extra_lds(), s, a); \
+                     else if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
                      else hipLaunchKernelGGL((composite_fwd_kernel<E, 5, false>), grid, block, debug_extra_lds(), s, a); } while (0)
     if (early) GS_F(true); else GS_F(false);
 #undef GS_F

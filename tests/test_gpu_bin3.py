@@ -1,0 +1,98 @@
+"""Two-level tile binning (gaussiansplat_amd/csrc/gs_bin3.hip, the default path of gs_bin) against the oracle's lists
+(oracle gso_bin = the reference's hitBinning / scan! / compactHits result, src/forward.jl:118-161, src/compact.jl:3-21)
+on the cases its structure makes special:
+
+  * footprints that cover many super-tiles (8 x 8 tiles) -- the level-1 staging buffer overflows and the surplus takes the
+    direct-write path; super-tile lists far longer than one level-2 segment;
+  * grids whose last super-tile row / column is ragged (gx, gy not multiples of 8) and grids smaller than one super-tile;
+  * fewer list positions than one level-1 workgroup, a single gaussian, gaussians without any tile;
+  * a 4K-class grid (510 super-tiles: 512 positions per level-1 workgroup instead of 1024).
+Lists are compared bit for bit, for the depth and the index order, and with the generate-in-pass radix path (bin_path 2).
+"""
+import numpy as np
+import pytest
+
+from common import hip_context, scene_and_cameras
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_lists(O, B, sc, cam, T, P, ocam, W, H, deg, order, bin_path=0):
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0, bin_path=bin_path)
+    ctx.preprocess(); ctx.bin()
+    ranges, ids, okeys = O.bin_lists(pre["bbs"], pre["tps"], order, 16, gx, gy)
+    assert ctx.num_instances == len(ids)
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ranges)
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ids)
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), okeys)
+    n_inst = ctx.num_instances
+    ctx.close()
+    return n_inst
+
+
+@pytest.mark.parametrize("order", [1, 0])
+@pytest.mark.parametrize("n,W,H,grow", [
+    (3000, 640, 400, 3.2),       # footprints of hundreds of pixels: most gaussians span many super-tiles (staging overflow, long lists)
+    (1500, 1000, 600, 4.0),      # 63 x 38 tiles: ragged last super-tile row and column
+    (700, 100, 90, 2.0),         # 7 x 6 tiles: the whole grid is inside one super-tile
+    (1, 333, 222, 3.0),          # one gaussian
+    (65, 2040, 72, 2.5),         # 128 x 5 tiles: one row of super-tiles
+])
+def test_big_footprints_and_ragged_grids(oracle, n, W, H, grow, order):
+    from gaussiansplat_amd import backend as B
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, 1, 4000 + n)
+    sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(grow)).astype(np.float32)        # log-scales: exp(grow) times larger
+    ni = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 1, order)
+    if n >= 1500:
+        assert ni > 20 * n                                                                     # the footprints really are large
+
+
+def test_gaussians_without_tiles_and_duplicates(oracle):
+    """Half of the gaussians behind the camera / off screen (empty rectangles), the rest exact duplicates (equal depth keys:
+    ties must stay in gaussian-index order through both levels)."""
+    from gaussiansplat_amd import backend as B
+    n, W, H = 4099, 512, 384
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, 0, 99)
+    sc = dict(sc)
+    m = sc["means"].copy()
+    m[::2] += np.float32(1e6)                                      # far off screen
+    m[1::2] = m[1]                                                 # all the others: the same gaussian
+    sc["means"] = m
+    for k in ("scales", "quats", "opacities"):
+        a = sc[k].copy(); a[1::2] = a[1]; sc[k] = a
+    sc["scales"] = (sc["scales"] + np.float32(2.0)).astype(np.float32)
+    _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
+
+
+def test_4k_grid_small_scene(oracle):
+    """3840 x 2160: 240 x 135 tiles = 30 x 17 super-tiles (510): the level-1 workgroups take 512 positions."""
+    from gaussiansplat_amd import backend as B
+    n, W, H = 20_000, 3840, 2160
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, 0, 77)
+    sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(1.0)).astype(np.float32)
+    a = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
+    b = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, bin_path=2)
+    assert a == b
+
+
+def test_render_through_two_level_lists_matches_radix_lists(oracle):
+    """forward + backward on the two-level lists == on the radix lists (same lists => bit-identical image and T)."""
+    import torch
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg = 30_000, 800, 608, 1
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 5)
+    sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(1.5)).astype(np.float32)
+    dC = synthetic.make_dC(W, H, 3)
+    out = []
+    for bp in (0, 2):
+        ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, bin_path=bp, deterministic=True)
+        ctx.preprocess(); ctx.bin()
+        img, tr = ctx.forward_host()
+        g = ctx.grads_alloc(); ctx.backward(dC, g); ctx.synchronize()
+        out.append((img.copy(), tr.copy(), {k: v.copy() for k, v in ctx.grads_read(g, deg).items()}))
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    for k in out[0][2]:
+        assert np.array_equal(out[0][2][k], out[1][2][k]), k        # deterministic mode: bitwise
