@@ -482,9 +482,16 @@ int gs_preprocess(gs_ctx *c) {
 // boundaries as the single list, so image, transmittance and (deterministic mode) gradients are bit-identical to the
 // classic path.  The slab bounds come from the share of the instances the previous frame walked; a first frame, a sparse
 // scene (share >= GS_SLAB_MAX_RATIO) or t_min = 0 take the classic single round.
-// Measured on MI355X: at C3 (share 0.28) two rounds cost more than they save (two forward launches with their tails, the second
-// count pass; 2.16 vs 1.97 ms), at C5 (share 0.06) three rounds cut the frame from 10.4 to 7.7 ms: slabs below a share of 0.15.
-#define GS_SLAB_MAX_RATIO 0.15
+// Measured on MI355X.  With the radix binning of round 1 (16 B of traffic per instance): at C3 (share 0.28) two rounds cost
+// more than they save, at C5 (share 0.06) three rounds cut the frame from 10.4 to 6.8 ms.  With the two-level binning
+// (gs_bin3.hip: 4 B written per instance, no pass over the instances) the single round wins at C5 as well (5.54 vs 5.67 ms:
+// three forward launches with their tails and three level-1 passes cost more than the 0.4 ms of list writes they save), so
+// the automatic mode now engages only below a share of 0.03 (GS_SLAB_MAX_RATIO overrides; the tests use 0.15).
+#define GS_SLAB_MAX_RATIO 0.03
+static double slab_max_ratio() {
+    if (const char *e = std::getenv("GS_SLAB_MAX_RATIO")) { const double v = std::atof(e); if (v > 0.0 && v <= 1.0) return v; }
+    return GS_SLAB_MAX_RATIO;
+}
 static int plan_rounds(gs_ctx *c) {
     c->n_rounds = 1;
     c->slab_lo[0] = 0; c->slab_lo[1] = c->n;
@@ -494,7 +501,7 @@ static int plan_rounds(gs_ctx *c) {
     if (const char *e = std::getenv("GS_SLABS")) {                          // experiments: explicit fractions "f1[,f2[,f3]]", "" = classic
         const char *p = e;
         while (*p && R < GS_MAX_ROUNDS) { char *q = nullptr; const double v = std::strtod(p, &q); if (q == p) break; f[R - 1] = v; ++R; p = *q == ',' ? q + 1 : q; }
-    } else if (c->cfg.slab_mode == 1 && c->walked_ratio >= 0.0 && c->walked_ratio < GS_SLAB_MAX_RATIO) {
+    } else if (c->cfg.slab_mode == 1 && c->walked_ratio >= 0.0 && c->walked_ratio < slab_max_ratio()) {
         const double rho = c->walked_ratio;
         f[0] = std::min(0.9, std::max(0.02, 2.0 * rho + 0.02));
         f[1] = std::min(0.95, std::max(f[0] + 0.05, 6.0 * rho + 0.05));
