@@ -24,7 +24,7 @@ STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges
 
 # every symbol include/gsplat.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
-           "gs_synchronize", "gs_set_model", "gs_set_model_2d", "gs_set_image_size", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_forward",
+           "gs_synchronize", "gs_set_model", "gs_set_model_2d", "gs_set_image_size", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_bind_outputs", "gs_forward",
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
@@ -80,6 +80,7 @@ def load():
     L.gs_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, fp, fp, C.c_int32, C.c_int32]
     L.gs_preprocess.argtypes = [vp]
     L.gs_bin.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gs_bind_outputs.argtypes = [vp, vp, vp]
     L.gs_forward.argtypes = [vp, vp, vp, C.c_int]
     L.gs_backward.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads)]
     L.gs_backward_ex.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads), C.c_int]
@@ -201,6 +202,11 @@ class Context:
         tr = np.empty((self.H, self.W), np.float32)
         self._chk(self.L.gs_forward(self.h, C.c_void_p(img.ctypes.data), C.c_void_p(tr.ctypes.data), GS_MEM_HOST))
         return img, tr
+
+    def bind_outputs(self, image_ptr: int = 0, trans_ptr: int = 0):
+        """gs_bind_outputs: the forward writes straight into these device buffers (0, 0 unbinds); they must stay valid and
+        unmodified until the frame's last backward."""
+        self._chk(self.L.gs_bind_outputs(self.h, C.c_void_p(image_ptr), C.c_void_p(trans_ptr)))
 
     def forward_device(self, image_ptr: int = 0, trans_ptr: int = 0):
         self._chk(self.L.gs_forward(self.h, C.c_void_p(image_ptr), C.c_void_p(trans_ptr), GS_MEM_DEVICE))

@@ -67,6 +67,7 @@ struct RcclApi {
 
 }  // namespace
 
+#define GS_COUNTER_BYTES 192      // 128 B of work / ticket counters + the binning totals at byte 128 (one read-back for both)
 struct gs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -119,7 +120,12 @@ struct gs_ctx {
     bool two_level = false;
     int sgx = 0, sgy = 0;
     int64_t coarse_listed = 0;               // coarse instances of the current round
-    DevBuf rect_sorted, l1_table, l1_rows, l1_partials, cids, clr, cranges, segcnt, sdone, bin_totals, tilecnt;
+    DevBuf rect_sorted, l1_table, l1_rows, l1_partials, cids, clr, cranges, segcnt, sdone, tilecnt;
+    uint32_t *bin_totals() { return counters.as<uint32_t>() + 32; }
+    float *bound_image = nullptr, *bound_trans = nullptr;   // gs_bind_outputs: caller-owned device buffers the forward writes directly
+    float *img() { return bound_image ? bound_image : image.as<float>(); }
+    float *tr() { return bound_trans ? bound_trans : trans.as<float>(); }
+    bool counters_zeroed = false;            // the forward's counters were zeroed by a binning kernel of this frame
     int tile_bits = 0, gid_bits = 0, lo_bits = 0, hi_bits = 0;
     bool fast_bin = false;
     double walked_ratio = -1.0;              // entries walked / instances of the last completed frame (-1: none yet)
@@ -181,7 +187,7 @@ int bind_device(gs_ctx *c) {
 // Scheduling of a composite launch (gs_config.schedule): the ticket counter inside c->counters (zeroed by the caller's
 // memset of that buffer), the resident-wave grid and, for schedule 0, the longest-first tile order -- for the forward by
 // list length, for the backward by the forward's per-tile count of evaluated entries (its exact work).
-int composite_sched(gs_ctx *c, GsCompositeArgs &a, int which) {
+int composite_sched(gs_ctx *c, GsCompositeArgs &a, int which, bool *zeroed_bwd_counters = nullptr) {
     const int ntiles = c->gx * c->gy;
     HIPCHK(c, c->tile_work.ensure(sizeof(uint32_t) * (size_t)(ntiles ? ntiles : 1)));
     if (which == 0) a.tile_work = c->tile_work.as<uint32_t>();
@@ -196,7 +202,9 @@ int composite_sched(gs_ctx *c, GsCompositeArgs &a, int which) {
         }
         if (which == 1 && ntiles > 0) {
             HIPCHK(c, c->tile_order_b.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
-            HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, ntiles, c->tile_order_b.as<uint32_t>(), c->stream));
+            HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, ntiles, c->tile_order_b.as<uint32_t>(), c->stream,
+                                               zeroed_bwd_counters ? a.walked : nullptr));
+            if (zeroed_bwd_counters) *zeroed_bwd_counters = true;
             a.tile_order = c->tile_order_b.as<uint32_t>();
         }
         return GS_OK;
@@ -271,7 +279,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipSetDevice"); }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipStreamCreate"); }
     c->own_stream = true;
-    if ((e = hipHostMalloc((void **)&c->pinned, 64, hipHostMallocDefault)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return hipfail(nullptr, e, "hipHostMalloc"); }
+    if ((e = hipHostMalloc((void **)&c->pinned, 512, hipHostMallocDefault)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return hipfail(nullptr, e, "hipHostMalloc"); }
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
         for (int k = 0; k < 2; ++k)
             if ((e = hipEventCreate(&c->ev[s][k])) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
@@ -298,7 +306,7 @@ int gs_destroy(gs_ctx *c) {
                       &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
                       &c->tile_order_f, &c->tile_order_b, &c->tile_order_p, &c->tile_work, &c->tile_clock,
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
-                      &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->bin_totals, &c->tilecnt,
+                      &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->tilecnt,
                       &c->ranges_r[0], &c->ranges_r[1], &c->ranges_r[2], &c->ranges_r[3],
                       &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams};
     for (DevBuf *b : bufs) b->release();
@@ -527,9 +535,10 @@ static GsBin3L1 two_level_args(gs_ctx *c, const uint32_t *perm_slab, int64_t n_a
     GsBin3L1 b{};
     b.rect = c->rect.as<uint16_t>(); b.perm = perm_slab; b.sdone = sdone; b.n = n_all; b.n_slab = nr; b.sgx = c->sgx; b.ns = c->sgx * c->sgy;
     b.rect_sorted = c->rect_sorted.as<uint32_t>(); b.table = c->l1_table.as<uint32_t>(); b.row_total = c->l1_rows.as<uint32_t>();
-    b.partials = c->l1_partials.as<uint32_t>(); b.totals = c->bin_totals.as<uint32_t>(); b.cranges = c->cranges.as<uint32_t>();
+    b.partials = c->l1_partials.as<uint32_t>(); b.totals = c->bin_totals(); b.cranges = c->cranges.as<uint32_t>();
     b.cids = c->cids.as<uint32_t>(); b.clr = c->clr.as<uint16_t>();
     b.tilecnt = c->tilecnt.as<uint32_t>(); b.ntiles = c->gx * c->gy;
+    b.zero_words = sdone ? nullptr : c->counters.as<uint32_t>();           // round 0 (no completed tiles yet): the forward's counters
     return b;
 }
 static int two_level_count(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, const uint8_t *sdone) {
@@ -538,7 +547,7 @@ static int two_level_count(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, 
     HIPCHK(c, c->l1_table.ensure(sizeof(uint32_t) * gs_bin3_table_words(nr, ns)));
     HIPCHK(c, c->l1_rows.ensure(sizeof(uint32_t) * (size_t)ns));
     HIPCHK(c, c->l1_partials.ensure(sizeof(uint32_t) * gs_bin3_partial_words(n_all, ns)));
-    HIPCHK(c, c->bin_totals.ensure(sizeof(uint32_t) * 4));
+    HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
     HIPCHK(c, c->cranges.ensure(sizeof(uint32_t) * 2 * (size_t)ns));
     HIPCHK(c, c->tilecnt.ensure(sizeof(uint32_t) * (size_t)c->gx * c->gy));
     HIPCHK(c, gs_bin3_l1_count(two_level_args(c, perm_slab, n_all, nr, sdone), c->stream));
@@ -557,6 +566,7 @@ static int two_level_lists(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, 
     HIPCHK(c, c->clr.ensure(sizeof(uint16_t) * (size_t)coarse));
     HIPCHK(c, c->segcnt.ensure(sizeof(uint32_t) * 64 * (size_t)max_work));
     HIPCHK(c, gs_bin3_l1_scatter(two_level_args(c, perm_slab, n_all, nr, sdone), c->stream));
+    if (!sdone) c->counters_zeroed = true;
     GsBin3Args a{};
     a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>(); a.ranges = ranges; a.tilecnt = c->tilecnt.as<uint32_t>();
     a.done = done; a.segcnt = c->segcnt.as<uint32_t>(); a.ids_out = ids_out;
@@ -579,7 +589,7 @@ static int bin_round_two_level(gs_ctx *c, int r) {
         HIPCHK(c, gs_launch_super_done(c->tile_done.as<uint8_t>(), c->gx, c->gy, c->sgx, c->sgy, c->sdone.as<uint8_t>(), c->stream));
         if (int rc = two_level_count(c, perm, nr, nr, c->sdone.as<uint8_t>())) return rc;
     }
-    HIPCHK(c, hipMemcpyAsync(c->pinned, c->bin_totals.as<uint32_t>(), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pinned, c->bin_totals(), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev_count));
     harvest_events(c);
@@ -677,7 +687,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     c->two_level = fast && bin_path == 0 && gs_bin3_supported(c->sgx * c->sgy);
     c->tile_bits = tile_bits; c->gid_bits = gid_bits; c->lo_bits = lo_bits; c->hi_bits = hi_bits; c->fast_bin = fast;
     HIPCHK(c, c->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)(ntiles ? ntiles : 1)));
-    HIPCHK(c, c->counters.ensure(128));
+    HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
     // the slab plan needs the previous frame's walked share, which the read-back below delivers: the plan of THIS frame uses
     // the share known so far (one frame of lag; only speed depends on it)
     const int R = plan_rounds(c);
@@ -694,13 +704,13 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     // the one host read-back of the frame (the reference reads maxHits back, forward.jl:139): the instance count, the
     // generated positions of round 0 and the previous frame's walked count.  Work that does not need the count (the tile
     // ranges) is enqueued BEFORE the host waits, so the GPU stays busy while the host wakes up and launches the instance passes.
-    if (c->two_level) {
-        HIPCHK(c, hipMemcpyAsync(c->pinned + 4, c->bin_totals.as<uint32_t>(), 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->two_level) {       // one copy: the previous frame's walked count (bytes 0..7) and the totals (bytes 128..139)
+        HIPCHK(c, hipMemcpyAsync(c->pinned + 8, c->counters.p, GS_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
     } else {
         HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->pinned + 1, c->offsets.as<uint32_t>() + n0, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     }
-    if (c->prev_counters_valid) HIPCHK(c, hipMemcpyAsync(c->pinned + 2, c->counters.p, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->prev_counters_valid && !c->two_level) HIPCHK(c, hipMemcpyAsync(c->pinned + 2, c->counters.p, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
     if (fast && !c->two_level) {
         HIPCHK(c, c->diff.ensure(sizeof(int) * gs_tile_ranges_scratch_ints(c->gx, c->gy)));
@@ -710,7 +720,10 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     }
     HIPCHK(c, hipEventSynchronize(c->ev_count));
     harvest_events(c, fast && !c->two_level ? GS_STAGE_RANGES : -1);
-    if (c->two_level) { c->pinned[0] = c->pinned[6]; c->pinned[1] = c->pinned[5]; }      // totals: [4] coarse, [5] fine of the slab, [6] fine of all
+    if (c->two_level) {                                      // totals: coarse listed, fine of the slab, fine of all
+        c->pinned[2] = c->pinned[8]; c->pinned[3] = c->pinned[9];
+        c->pinned[4] = c->pinned[8 + 32]; c->pinned[1] = c->pinned[8 + 33]; c->pinned[0] = c->pinned[8 + 34];
+    }
     if (c->pinned[0] == 0xFFFFFFFFu)
         return fail(c, GS_ERR_UNSUPPORTED, "gs_bin: more than 2^32 - 2 tile instances (32-bit list offsets); reduce the scene or the image");
     if (c->prev_counters_valid && c->prev_n_inst > 0) {
@@ -770,6 +783,14 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     return GS_OK;
 }
 
+int gs_bind_outputs(gs_ctx *c, float *image, float *transmittance) {
+    if (!c) return GS_ERR_INVALID;
+    if ((image == nullptr) != (transmittance == nullptr)) return fail(c, GS_ERR_INVALID, "gs_bind_outputs: bind both buffers or neither");
+    c->bound_image = image; c->bound_trans = transmittance;
+    c->did_fwd = c->did_bwd = false;                                      // the forward's result lives in the buffers bound at its time
+    return GS_OK;
+}
+
 int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_bin) return fail(c, GS_ERR_INVALID, "gs_forward: gs_bin first");
@@ -777,10 +798,13 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t px = (size_t)c->cam.W * c->cam.H;
     const size_t ntiles = (size_t)c->gx * c->gy;
-    HIPCHK(c, c->image.ensure(sizeof(float) * 3 * px));
-    HIPCHK(c, c->trans.ensure(sizeof(float) * px));
-    HIPCHK(c, c->counters.ensure(128));
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 128, c->stream));         // work counters + both sets of ticket counters
+    if (!c->bound_image) {
+        HIPCHK(c, c->image.ensure(sizeof(float) * 3 * px));
+        HIPCHK(c, c->trans.ensure(sizeof(float) * px));
+    }
+    HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
+    if (!c->counters_zeroed) HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 128, c->stream));   // work counters + both sets of ticket counters
+    c->counters_zeroed = false;
     const int R = c->n_rounds;
     if (R > 1) {
         HIPCHK(c, c->tile_pos.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
@@ -793,7 +817,7 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
         a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
         a.ranges = r == 0 ? c->ranges.as<uint32_t>() : c->ranges_r[r].as<uint32_t>();
         a.ids = c->ids.as<uint32_t>() + c->round_ids_off[r]; a.payload = c->payload.as<GsPayload>();
-        a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
+        a.image = c->img(); a.trans = c->tr();
         a.walked = c->counters.as<unsigned long long>();
         a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
         a.resume = r > 0; a.final_round = r == R - 1;
@@ -806,8 +830,8 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
         }
     }
     const hipMemcpyKind kind = mem == GS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    if (image) HIPCHK(c, hipMemcpyAsync(image, c->image.p, sizeof(float) * 3 * px, kind, c->stream));
-    if (transmittance) HIPCHK(c, hipMemcpyAsync(transmittance, c->trans.p, sizeof(float) * px, kind, c->stream));
+    if (image && image != c->img()) HIPCHK(c, hipMemcpyAsync(image, c->img(), sizeof(float) * 3 * px, kind, c->stream));
+    if (transmittance && transmittance != c->tr()) HIPCHK(c, hipMemcpyAsync(transmittance, c->tr(), sizeof(float) * px, kind, c->stream));
     if (mem == GS_MEM_HOST && (image || transmittance)) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->did_fwd = true; c->did_bwd = false; c->did_bwd_composite = false;
     c->prev_counters_valid = true; c->prev_n_inst = c->n_inst;
@@ -838,7 +862,7 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     GsCompositeArgs a{};
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
-    a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
+    a.image = c->img(); a.trans = c->tr();
     a.nseg = 0;
     for (int r = 0; r < c->n_rounds; ++r) {
         if (r > 0 && c->round_gen[r] == 0) continue;                       // a round that listed nothing
@@ -852,8 +876,9 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     if (!params_only) {
         c->last_dC = dC_dev;
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
-        HIPCHK(c, hipMemsetAsync(a.walked, 0, 112, c->stream));             // the backward's work counters + the ticket counters
-        if (int rc = composite_sched(c, a, 1)) return rc;
+        bool zeroed = false;                                           // the order kernel of schedule 3 / 4 zeroes the counters on its way
+        if (int rc = composite_sched(c, a, 1, &zeroed)) return rc;
+        if (!zeroed) HIPCHK(c, hipMemsetAsync(a.walked, 0, 112, c->stream));    // the backward's work counters + the ticket counters
         {
             StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                   // the kernel alone (what rocprof reports for it)
             HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
@@ -1195,7 +1220,7 @@ int gs_get_stage_stats(gs_ctx *c, double sum_ms[GS_STAGE_COUNT], int64_t count[G
 static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeArgs &a) {
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
-    a.image = c->image.as<float>(); a.trans = c->trans.as<float>();
+    a.image = c->img(); a.trans = c->tr();
     a.dC = c->last_dC; a.walked = nullptr;
     a.final_round = 1;
     a.nseg = 0;

@@ -80,6 +80,7 @@ struct L1Args {
     int nwg_all;
     uint32_t *tilecnt;           // [ntiles] zeroed here for the level-2 count pass
     int ntiles;
+    uint32_t *zero_words;        // 32 words zeroed by l1_scatter (the forward's work counters: saves a memset command); may be null
 };
 
 // One list position per thread (blockDim = G): sets the position's bits in the LDS bitmap bm[ns][G / 32].
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(1024) void l1_scatter_kernel(L1Args a) {
     uint32_t *st_ls = st_id + cap;                                      // [cap] clipped rectangle | S << 12
     uint16_t *pre = reinterpret_cast<uint16_t *>(st_ls + cap);          // [ns][wpr] set bits of the row below word w
     const int64_t base = (int64_t)blockIdx.x * a.G;
+    if (a.zero_words && blockIdx.x == 0 && tid < 32) a.zero_words[tid] = 0;
     // issued first, used after the bitmap phase: the list-start operands of the first scan pass (all of them when ns <= G)
     const uint32_t v_first = tid < a.ns ? a.row_total[tid] : 0u;
     const uint32_t tb_first = tid < a.ns ? a.table[(size_t)tid * a.nwg + blockIdx.x] : 0u;
@@ -521,7 +523,7 @@ static L1Args l1_args(const GsBin3L1 &b) {
     a.nwg = (int)((b.n_slab + a.G - 1) / a.G); a.nwg_all = (int)((b.n + a.G - 1) / a.G);
     a.rect_sorted = reinterpret_cast<uint2 *>(b.rect_sorted); a.table = b.table; a.row_total = b.row_total;
     a.partials = b.partials; a.totals = b.totals; a.cranges = b.cranges; a.cids = b.cids; a.clr = b.clr;
-    a.tilecnt = b.tilecnt; a.ntiles = b.ntiles;
+    a.tilecnt = b.tilecnt; a.ntiles = b.ntiles; a.zero_words = b.zero_words;
     return a;
 }
 size_t gs_bin3_table_words(int64_t n_slab, int ns) { const int G = gs_bin3_group(ns); return (size_t)ns * (size_t)((n_slab + G - 1) / G + 1); }

@@ -142,6 +142,7 @@ struct GsBin3L1 {
     uint16_t *clr;             // totals[0] rectangles clipped to the super-tile
     uint32_t *tilecnt;         // ntiles words: zeroed by gs_bin3_l1_count, accumulated and scanned by gs_bin3_build_lists
     int ntiles;
+    uint32_t *zero_words;      // gs_bin3_l1_scatter zeroes these 32 words (may be null)
 };
 struct GsBin3Args {
     const uint32_t *cranges;   // 2 x ns: [start, end) of every super-tile's list inside cids
@@ -204,7 +205,9 @@ struct GsCompositeArgs {
     int final_round;           // forward: last round of the frame: transmittance is written plain (no sign flag)
 };
 // tiles in decreasing order of work[] (a 256-bucket counting sort of work / max; one workgroup)
-hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s);
+// zero14 (may be null): fourteen 64-bit words zeroed on the way (the backward's work and ticket counters: saves a memset command)
+hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s,
+                                    unsigned long long *zero14 = nullptr);
 hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s);
 int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body = 0);   // occupancy x CUs (body: A/B variant)
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);

@@ -724,13 +724,14 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 // as well but lost more to their per-tile overhead and placement).  One workgroup: a counting sort per residue class on
 // work / max in 256 steps; tiles inside a bucket keep no particular order.  work = src[t], or the list length (ranges_mode).
 __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles,
-                                                               uint32_t *__restrict__ order) {
+                                                               uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14) {
     extern __shared__ uint32_t wk[];                                     // the tiles' work, read from memory once
     __shared__ uint32_t hist[2048];                                      // [residue][bucket], bucket 0 = heaviest
     __shared__ uint32_t wmax;
     const int tid = threadIdx.x;
     hist[tid] = 0; hist[tid + 1024] = 0;
     if (tid == 0) wmax = 1;
+    if (zero14 && tid < 14) zero14[tid] = 0ull;
     __syncthreads();
     uint32_t m = 0;
     for (int t0 = 0; t0 < ntiles; t0 += 8 * 1024) {                     // eight independent loads in flight per thread
@@ -770,7 +771,8 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
     __syncthreads();
     for (int t = tid; t < ntiles; t += 1024) order[8u * atomicAdd(&hist[bucket(t)], 1u) + (uint32_t)(t & 7)] = (uint32_t)t;
 }
-hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s) {
+hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s,
+                                    unsigned long long *zero14) {
     if (ntiles <= 0) return hipSuccess;
     const size_t lds = sizeof(uint32_t) * (size_t)ntiles;
     if (lds > 140 * 1024) return hipErrorInvalidValue;                   // 35 840 tiles: beyond 8K images
@@ -778,7 +780,7 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_lpt_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, order);
+    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, order, zero14);
     return hipGetLastError();
 }
 

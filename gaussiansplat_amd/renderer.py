@@ -318,7 +318,11 @@ def compactIdxs(renderer, threads=(16, 16), blocks=None):
 def forward(renderer, tps=None, threads=(16, 16), blocks=None):
     """forward.jl:163-198: writes renderer.imageData and renderer.transmittance in place."""
     renderer._begin()
-    renderer.ctx.forward_device(renderer.imageData.data_ptr(), renderer.transmittance.data_ptr())
+    ip, tp = renderer.imageData.data_ptr(), renderer.transmittance.data_ptr()
+    if getattr(renderer, "_bound_out", None) != (ip, tp):       # imageData / transmittance ARE the library's output buffers: no copy
+        renderer.ctx.bind_outputs(ip, tp)
+        renderer._bound_out = (ip, tp)
+    renderer.ctx.forward_device(ip, tp)
 
 
 def backward(renderer, ΔC, skip_shs: bool = False, phase: str = "all"):

@@ -160,6 +160,14 @@ int gs_preprocess(gs_ctx *ctx);
  * ceil(H/16). */
 int gs_bin(gs_ctx *ctx, int32_t gx, int32_t gy);
 
+/* Optional: the forward writes image [3,H,W] and transmittance [H,W] DIRECTLY into these caller-owned DEVICE buffers instead of
+ * the ctx's own (and gs_backward reads them back from there), which saves the two device-to-device copies of
+ * gs_forward(..., GS_MEM_DEVICE).  Contract: the buffers stay valid and unmodified from gs_forward until the last
+ * gs_backward of the frame; size them for the image set with gs_set_camera.  Passing the bound pointers to gs_forward is
+ * allowed (no copy).  NULL, NULL unbinds.  (The reference keeps imageData / transmittance in the renderer, renderer.jl:89-117;
+ * this is the same ownership with the host's allocator.) */
+int gs_bind_outputs(gs_ctx *ctx, float *image_dev, float *transmittance_dev);
+
 /* forward(renderer, tps, threads, blocks): per-tile alpha composite.  image: W*H*3 floats
  * (planar), transmittance: W*H floats.  Either may be NULL. */
 int gs_forward(gs_ctx *ctx, float *image, float *transmittance, int mem);

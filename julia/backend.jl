@@ -114,6 +114,11 @@ end
 hip_compactIdxs(r::HipRenderer, threads, blocks) =
     check(r, ccall((:gs_bin, libgs), Cint, (Ptr{Cvoid}, Int32, Int32), r.ctx, blocks[1], blocks[2]))
 
+# optional: the forward writes directly into caller-owned DEVICE buffers (e.g. a ROCArray's pointer); C_NULL, C_NULL unbinds
+function hip_bind_outputs(r::HipRenderer, image_dev::Ptr{Float32}, transmittance_dev::Ptr{Float32})
+    check(r, ccall((:gs_bind_outputs, libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}), r.ctx, image_dev, transmittance_dev))
+end
+
 # forward(renderer, tps, threads, blocks)  (src/forward.jl:163-198): fills imageData (W x H x 3), transmittance (W x H)
 function hip_forward!(r::HipRenderer, imageData::Array{Float32, 3}, transmittance::Array{Float32, 2})
     check(r, ccall((:gs_forward, libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Cint),
