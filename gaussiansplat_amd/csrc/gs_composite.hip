@@ -530,6 +530,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     // The tile's list is the concatenation of its segments, one per binning round of the frame (one segment unless the
     // frame was binned in depth slabs); batches end at multiples of CB of the WHOLE list, as in the forward.
     uint32_t gp = 0;
+    uint32_t alive = 0xFu;                                                // strips with a live pixel (refreshed at every batch boundary)
     bool stop = false;
     for (int sg = 0; sg < a.nseg && !stop; ++sg) {
     const uint32_t *ids = a.seg_ids[sg];
@@ -541,17 +542,20 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         const int cnt = (int)min((uint32_t)CB - phase, s1 - base);
         if (EARLY && phase == 0) {
             bool live = false;
+            alive = 0;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 if (!dead[p] && T[p] < a.t_min) { dead[p] = true; T[p] = 0.0f; S[p] = 0.0f; }
                 live = live || !dead[p];
+                if (__ballot(!dead[p]) != 0ull) alive |= 1u << p;           // strip p still has a pixel that takes entries
             }
-            if (__ballot(live) == 0ull) { stop = true; break; }
+            if (alive == 0u) { stop = true; break; }
         }
         float4 q0, q1, q2;
         uint32_t strips;
         bool keep;
         const float yhi_l = stage_record<CULL>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
+        if (CULL && EARLY) strips &= alive;                                 // a strip of frozen pixels (T = S = 0) adds exact zeros
         int slot = lane, nk = cnt;
         if (!CULL) keep = true;
         uint64_t mq[4] = {~0ull, ~0ull, ~0ull, ~0ull};                    // bit k: strip p of the k-th staged entry is live
