@@ -78,8 +78,9 @@ typedef struct {
                                  gs_get_array; costs 124 extra bytes/gaussian of HBM writes   */
     int32_t profile_stages;   /* 1: record hipEvents around every stage (gs_get_stage_times; costs ~3 % of a C3 frame);
                                  2 + s: around stage s (gs_stage) only; 0: none */
-    int32_t bin_path;         /* 0: generate-in-pass binning on 32-bit words (default); 1: explicit
-                                 64-bit tile|id instances + two radix passes (fallback, same result) */
+    int32_t bin_path;         /* tile lists (same lists on every path, bit for bit): 0 (default) two-level binning -- lists per
+                                 super-tile of 8 x 8 tiles from an LDS bitmap, tile lists as filtered copies; 2: radix sort of
+                                 instances generated in-pass (32-bit words); 1: explicit 64-bit tile|id instances + two radix passes */
     int32_t rank_mode;        /* radix-sort stable ranks: 0 = one LDS atomic-add-return per key -- its pre-values come back in
                                  ascending lane order on gfx950, which gs_create CHECKS on the device with a probe kernel and
                                  falls back to 1 if the check fails; 1 = wave64 ballots (portable); same lists either way   */
