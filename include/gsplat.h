@@ -98,8 +98,9 @@ typedef struct {
                                  0 persistent waves pull tiles from per-XCD ticket counters, heaviest first; 2 the same in
                                    arbitrary order (both measured slower: profiles/)                           */
     int32_t slab_mode;        /* binning in depth slabs (speed only; image, transmittance and deterministic-mode gradients are
-                                 bit-identical either way): 1 (default) automatic -- when the previous frame walked under 15 % of
-                                 its tile instances before the transmittance early-out stopped every tile, the next frame is
+                                 bit-identical either way): 1 (default) automatic -- when the previous frame walked under 3 % of
+                                 its tile instances before the transmittance early-out stopped every tile (with the two-level
+                                 binning a single round is faster above that share), the next frame is
                                  binned in three rounds over slabs of the depth order and only the tiles still open take the later
                                  slabs; 0 always one round (the classic full lists).  In a slab frame the per-tile lists are
                                  spread over the rounds, so GS_ARR_TILE_RANGES / SORTED_IDS / SORTED_KEYS are unavailable (a
