@@ -571,7 +571,7 @@ static int two_level_lists(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, 
     a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>(); a.ranges = ranges; a.tilecnt = c->tilecnt.as<uint32_t>();
     a.done = done; a.segcnt = c->segcnt.as<uint32_t>(); a.ids_out = ids_out;
     a.gx = c->gx; a.gy = c->gy; a.sgx = c->sgx; a.ns = ns; a.max_work = (int)max_work;
-    a.wide = (uint64_t)c->n_inst * 4ull >= (1ull << 32);
+    a.wide = (uint64_t)c->n_inst * 4ull >= (1ull << 32) || std::getenv("GS_BIN3_WIDE") != nullptr;   // env: tests force the 64-bit cursors
     HIPCHK(c, gs_bin3_build_lists(a, c->stream));
     return GS_OK;
 }

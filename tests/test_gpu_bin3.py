@@ -77,6 +77,36 @@ def test_4k_grid_small_scene(oracle):
     assert a == b
 
 
+def test_8k_grid_and_wide_cursors(oracle):
+    """7680 x 4320: 480 x 270 tiles = 60 x 34 super-tiles (2040: 256 positions per level-1 workgroup, > 64 KB of LDS; the
+    backward's tile order kernel is beyond its LDS and the launch order is used).  GS_BIN3_WIDE forces the 64-bit cursors
+    that lists beyond 4 GB take."""
+    import os
+    from gaussiansplat_amd import backend as B, synthetic
+    n, W, H = 3_000, 7680, 4320
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, 0, 78)
+    sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(2.0)).astype(np.float32)
+    a = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
+    os.environ["GS_BIN3_WIDE"] = "1"
+    try:
+        b = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
+        n2, W2, H2 = 5_000, 640, 480
+        sc2, cam2, T2, P2, ocam2 = scene_and_cameras(n2, W2, H2, 0, 79)
+        sc2 = dict(sc2); sc2["scales"] = (sc2["scales"] + np.float32(1.5)).astype(np.float32)
+        _check_lists(oracle, B, sc2, cam2, T2, P2, ocam2, W2, H2, 0, 1)
+    finally:
+        os.environ.pop("GS_BIN3_WIDE", None)
+    assert a == b
+    # forward + backward run at this size (plain tile order in the backward)
+    ctx = hip_context(sc, cam, T, P, W, H, 0, t_min=1e-5)
+    ctx.preprocess(); ctx.bin()
+    img, tr = ctx.forward_host()
+    g = ctx.grads_alloc(); ctx.backward(synthetic.make_dC(W, H, 2), g); ctx.synchronize()
+    gr = ctx.grads_read(g, 0)
+    assert np.isfinite(img).all() and all(np.isfinite(v).all() for v in gr.values()) and float(tr.min()) < 1.0
+    ctx.close()
+
+
 def test_render_through_two_level_lists_matches_radix_lists(oracle):
     """forward + backward on the two-level lists == on the radix lists (same lists => bit-identical image and T)."""
     import torch
