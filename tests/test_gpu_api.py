@@ -264,3 +264,51 @@ def test_split_backward_and_overlapped_factored_step_equal_plain_backward(oracle
     assert np.array_equal(out["plain"], out["split"])
     assert np.array_equal(out["plain"][:11 * n], out["factored"][:11 * n])
     assert np.linalg.norm(out["plain"][11 * n:] - out["factored"][11 * n:]) <= 2e-6 * np.linalg.norm(out["plain"][11 * n:])
+
+
+def test_bound_output_buffers(oracle):
+    """gs_bind_outputs: the forward writes image / transmittance straight into caller-owned device buffers and the backward
+    reads them back from there -- same bits as the ctx-owned buffers + copy, for the forward and (deterministic mode) the
+    gradients; other destinations still get a copy; unbinding restores the ctx's own buffers."""
+    import torch
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg = 5000, 208, 144, 2
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 11)
+    dC = torch.as_tensor(synthetic.make_dC(W, H, 4)).cuda()
+
+    def run(ctx, img, tr, bind):
+        if bind:
+            ctx.bind_outputs(img.data_ptr(), tr.data_ptr())
+        ctx.preprocess(); ctx.bin()
+        ctx.forward_device(img.data_ptr(), tr.data_ptr())
+        g = ctx.grads_alloc()
+        ctx.backward(dC.data_ptr(), g, overwrite=True)
+        ctx.synchronize()
+        return img.cpu().numpy().copy(), tr.cpu().numpy().copy(), {k: v.copy() for k, v in ctx.grads_read(g, deg).items()}
+
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, deterministic=True)
+    i0, t0 = torch.zeros((3, H, W), device="cuda"), torch.zeros((H, W), device="cuda")
+    ref = run(ctx, i0, t0, bind=False)
+    i1, t1 = torch.full((3, H, W), 7.0, device="cuda"), torch.full((H, W), 7.0, device="cuda")
+    got = run(ctx, i1, t1, bind=True)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    for k in ref[2]:
+        assert np.array_equal(got[2][k], ref[2][k]), k
+    # another destination while bound: it receives a copy, the bound buffers hold the result as well
+    i2, t2 = torch.zeros((3, H, W), device="cuda"), torch.zeros((H, W), device="cuda")
+    ctx.preprocess(); ctx.bin(); ctx.forward_device(i2.data_ptr(), t2.data_ptr()); ctx.synchronize()
+    assert np.array_equal(i2.cpu().numpy(), ref[0]) and np.array_equal(i1.cpu().numpy(), ref[0])
+    # a frame whose backward must read the BOUND transmittance: scribble over the ctx-independent copy first
+    i2.zero_(); t2.zero_()
+    g = ctx.grads_alloc(); ctx.backward(dC.data_ptr(), g, overwrite=True); ctx.synchronize()
+    again = ctx.grads_read(g, deg)
+    for k in ref[2]:
+        assert np.array_equal(again[k], ref[2][k]), k
+    # unbind: back to the ctx-owned buffers
+    ctx.bind_outputs(0, 0)
+    i3, t3 = torch.zeros((3, H, W), device="cuda"), torch.zeros((H, W), device="cuda")
+    back = run(ctx, i3, t3, bind=False)
+    assert np.array_equal(back[0], ref[0]) and np.array_equal(back[1], ref[1])
+    with pytest.raises(Exception):
+        ctx.bind_outputs(i3.data_ptr(), 0)                          # both or neither
+    ctx.close()
