@@ -7,15 +7,19 @@
 // The reference relies on an AD package that is not in its Manifest; here the gradient is written
 // out: with mu = k*x, s_xx = k*x^2, s_xy = k*xy and S = A1 A2 / (B1 B2),
 //     dS_q/dx_p = k(q-p) [ dS/dmu_x + 2 x_p dS/ds_xx + y_p dS/ds_xy ]_q
-// so dC = w1 sign(x-y) + w2 (k*G_mu + 2x k*G_xx + y k*G_xy): two LDS-tiled 11x11 stencil passes.
-// HBM-bound byte work (no MFMA): pass 1 reads 8 B and writes 12 B per pixel-channel, pass 2 reads
-// 20 B and writes 4 B.
+// so dC = w1 sign(x-y) + w2 (k*G_mu + 2x k*G_xx + y k*G_xy): two LDS-tiled 11x11 stencil passes
+// (pass 1 reads 8 B and writes 12 B per pixel-channel, pass 2 reads 20 B and writes 4 B; no MFMA: the window is a
+// 121-tap non-separable stencil on fp32 data whose symmetric taps are folded first).
 #include "gs_common.h"
 
 #define LW 11
 #define LP 5
-#define LT 16
-#define LH (LT + 2 * LP)          // 26
+#define LTX 64                    // tile: 64 x 16 outputs of one channel per workgroup, 4 consecutive pixels per thread
+#define LTY 16
+#define LHX (LTX + 2 * LP)        // 74 halo columns
+#define LHY (LTY + 2 * LP)        // 26 halo rows
+#define LPITCH 76                 // floats per LDS row (16-byte aligned rows for ds_read_b128)
+#define LNF 6                     // folded window rows / columns: w[j][i] = w[10-j][i] = w[j][10-i]
 
 struct GsLossArgs {
     int W, H, C;
@@ -27,6 +31,11 @@ struct GsLossArgs {
     float win[LW * LW];
 };
 
+// The window exp(-|d|) of loss.jl:4-11 is not separable, but it is symmetric under both reflections, so the 121 taps fold
+// onto 6 x 6 weights: rows j and 10-j are added sample by sample first (shared by a thread's four outputs), then columns i
+// and 10-i per output.  That is 1/3 of the multiply-adds of the plain stencil, all of them on VGPR operands (an SGPR
+// weight operand halves the fma rate on gfx950), and the samples come in as 16-byte LDS reads shared by four outputs.
+// Measured at 1920x1080x3: 0.85 ms for the two plain 121-tap kernels of round 1, see DESIGN.md for this version.
 __device__ __forceinline__ float block_sum_256(float v, float *sm) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
@@ -36,87 +45,159 @@ __device__ __forceinline__ float block_sum_256(float v, float *sm) {
     return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-__global__ __launch_bounds__(256) void ssim_stats_kernel(GsLossArgs a) {
-    __shared__ float sx[LH][LH + 1], sy[LH][LH + 1];
+// halo tile of one plane: rows y0-5 .. y0+20, columns x0-5 .. x0+68, zero outside the image (loss.jl:29 pads with zeros)
+__device__ __forceinline__ void load_halo(float (*dst)[LPITCH], const float *__restrict__ plane, int W, int H, int x0, int y0) {
+    for (int i = threadIdx.x; i < LHY * LPITCH; i += 256) {
+        const int hy = i / LPITCH, hx = i - hy * LPITCH, gx = x0 + hx - LP, gy = y0 + hy - LP;
+        const bool in = hx < LHX && gx >= 0 && gx < W && gy >= 0 && gy < H;
+        dst[hy][hx] = in ? plane[(size_t)gy * W + gx] : 0.0f;
+    }
+}
+// sixteen consecutive samples of a halo row starting at column 4 tx (the thread's outputs need columns 0 .. 13 of them)
+__device__ __forceinline__ void load_row16(float (&v)[16], const float (*src)[LPITCH], int row, int tx) {
+    const float4 *p = reinterpret_cast<const float4 *>(&src[row][4 * tx]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float4 t = p[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+}
+// acc[o] += sum_i w[i] F[o + i] over the 11 window columns of output o, with the columns folded: 5 adds + 6 fma per output
+__device__ __forceinline__ void fold_cols(float (&acc)[4], const float (&F)[16], const float (&w)[LNF]) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float a = acc[o];
+#pragma unroll
+        for (int c = 0; c < LP; ++c) a = fmaf(w[c], F[o + c] + F[o + 2 * LP - c], a);
+        acc[o] = fmaf(w[LP], F[o + LP], a);
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void ssim_stats_kernel(GsLossArgs a) {
+    __shared__ __attribute__((aligned(16))) float sx[LHY][LPITCH], sy[LHY][LPITCH];
     __shared__ float sm[4], sm2[4];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, c = blockIdx.z;
+    const int x0 = blockIdx.x * LTX, y0 = blockIdx.y * LTY, c = blockIdx.z;
     const size_t plane = (size_t)a.W * a.H;
-    const float *ix = a.img + c * plane, *iy = a.gt + c * plane;
-    for (int i = threadIdx.x; i < LH * LH; i += 256) {
-        const int hy = i / LH, hx = i % LH, gx = x0 + hx - LP, gy = y0 + hy - LP;
-        const bool in = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;           // zero padding (loss.jl:29)
-        sx[hy][hx] = in ? ix[(size_t)gy * a.W + gx] : 0.0f;
-        sy[hy][hx] = in ? iy[(size_t)gy * a.W + gx] : 0.0f;
-    }
+    load_halo(sx, a.img + c * plane, a.W, a.H, x0, y0);
+    load_halo(sy, a.gt + c * plane, a.W, a.H, x0, y0);
     __syncthreads();
-    float mux = 0, muy = 0, sxx = 0, syy = 0, sxy = 0;
+    float mux[4] = {0, 0, 0, 0}, muy[4] = {0, 0, 0, 0}, sxx[4] = {0, 0, 0, 0}, syy[4] = {0, 0, 0, 0}, sxy[4] = {0, 0, 0, 0};
+    float xc[4], yc[4];                                                       // the outputs' own samples (L1 term)
+#pragma unroll 1
+    for (int j = 0; j < LNF; ++j) {
+        float w[LNF];
 #pragma unroll
-    for (int j = 0; j < LW; ++j)
+        for (int i = 0; i < LNF; ++i) w[i] = a.win[j * LW + i];
+        float x1[16], y1[16], F[16];
+        load_row16(x1, sx, ty + j, tx); load_row16(y1, sy, ty + j, tx);
+        if (j < LP) {
+            float x2[16], y2[16];
+            load_row16(x2, sx, ty + 2 * LP - j, tx); load_row16(y2, sy, ty + 2 * LP - j, tx);
 #pragma unroll
-        for (int i = 0; i < LW; ++i) {
-            const float k = a.win[j * LW + i], x = sx[ty + j][tx + i], y = sy[ty + j][tx + i];
-            mux = fmaf(k, x, mux); muy = fmaf(k, y, muy);
-            sxx = fmaf(k * x, x, sxx); syy = fmaf(k * y, y, syy); sxy = fmaf(k * x, y, sxy);
+            for (int i = 0; i < 14; ++i) F[i] = x1[i] + x2[i];
+            fold_cols(mux, F, w);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) F[i] = y1[i] + y2[i];
+            fold_cols(muy, F, w);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) F[i] = fmaf(x1[i], x1[i], x2[i] * x2[i]);
+            fold_cols(sxx, F, w);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) F[i] = fmaf(y1[i], y1[i], y2[i] * y2[i]);
+            fold_cols(syy, F, w);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) F[i] = fmaf(x1[i], y1[i], x2[i] * y2[i]);
+            fold_cols(sxy, F, w);
+        } else {                                                              // the window's centre row
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { xc[o] = x1[o + LP]; yc[o] = y1[o + LP]; }
+            fold_cols(mux, x1, w);
+            fold_cols(muy, y1, w);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) F[i] = x1[i] * x1[i];
+            fold_cols(sxx, F, w);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) F[i] = y1[i] * y1[i];
+            fold_cols(syy, F, w);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) F[i] = x1[i] * y1[i];
+            fold_cols(sxy, F, w);
         }
-    const int px = x0 + tx, py = y0 + ty;
-    const bool in = px < a.W && py < a.H;
-    float l1 = 0.0f, S = 0.0f;
-    if (in) {
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;                  // loss.jl:37-38
-        const float s2x = sxx - mux * mux, s2y = syy - muy * muy, cxy = sxy - mux * muy;
-        const float A1 = 2.0f * mux * muy + C1, A2 = 2.0f * cxy + C2;
-        const float B1 = mux * mux + muy * muy + C1, B2 = s2x + s2y + C2;
-        const float iB = 1.0f / (B1 * B2);
-        S = A1 * A2 * iB;                                                    // loss.jl:53-56
-        // partials at fixed (s_xx, s_xy): A1_mu = 2 mu_y, A2_mu = -2 mu_y, B1_mu = 2 mu_x, B2_mu = -2 mu_x
-        const float dmu = (2.0f * muy * A2 - 2.0f * muy * A1) * iB - S * (2.0f * mux / B1 - 2.0f * mux / B2);
-        const size_t o = c * plane + (size_t)py * a.W + px;
-        a.g_mu[o] = dmu;
-        a.g_xx[o] = -S / B2;
-        a.g_xy[o] = 2.0f * A1 * iB;
-        l1 = fabsf(sx[ty + LP][tx + LP] - sy[ty + LP][tx + LP]);
+    }
+    const int py = y0 + ty;
+    float l1 = 0.0f, St = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int px = x0 + 4 * tx + o;
+        if (px < a.W && py < a.H) {
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;              // loss.jl:37-38
+            const float s2x = sxx[o] - mux[o] * mux[o], s2y = syy[o] - muy[o] * muy[o], cxy = sxy[o] - mux[o] * muy[o];
+            const float A1 = 2.0f * mux[o] * muy[o] + C1, A2 = 2.0f * cxy + C2;
+            const float B1 = mux[o] * mux[o] + muy[o] * muy[o] + C1, B2 = s2x + s2y + C2;
+            const float iB = 1.0f / (B1 * B2);
+            const float S = A1 * A2 * iB;                                    // loss.jl:53-56
+            // partials at fixed (s_xx, s_xy): A1_mu = 2 mu_y, A2_mu = -2 mu_y, B1_mu = 2 mu_x, B2_mu = -2 mu_x
+            const float dmu = (2.0f * muy[o] * A2 - 2.0f * muy[o] * A1) * iB - S * (2.0f * mux[o] / B1 - 2.0f * mux[o] / B2);
+            const size_t q = c * plane + (size_t)py * a.W + px;
+            a.g_mu[q] = dmu;
+            a.g_xx[q] = -S / B2;
+            a.g_xy[q] = 2.0f * A1 * iB;
+            l1 += fabsf(xc[o] - yc[o]);
+            St += S;
+        }
     }
     const float t1 = block_sum_256(l1, sm);
-    const float t2 = block_sum_256(S, sm2);
+    const float t2 = block_sum_256(St, sm2);
     if (threadIdx.x == 0) { atomicAdd(&a.acc[0], (double)t1); atomicAdd(&a.acc[1], (double)t2); }
 }
 
-__global__ __launch_bounds__(256) void ssim_grad_kernel(GsLossArgs a) {
-    __shared__ float s0[LH][LH + 1], s1[LH][LH + 1], s2[LH][LH + 1];
+__global__ __launch_bounds__(256, 4) void ssim_grad_kernel(GsLossArgs a) {
+    __shared__ __attribute__((aligned(16))) float s0[LHY][LPITCH], s1[LHY][LPITCH], s2[LHY][LPITCH];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, c = blockIdx.z;
+    const int x0 = blockIdx.x * LTX, y0 = blockIdx.y * LTY, c = blockIdx.z;
     const size_t plane = (size_t)a.W * a.H, cb = c * plane;
-    for (int i = threadIdx.x; i < LH * LH; i += 256) {
-        const int hy = i / LH, hx = i % LH, gx = x0 + hx - LP, gy = y0 + hy - LP;
-        const bool in = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;           // no ssim term outside the image
-        const size_t o = cb + (size_t)gy * a.W + gx;
-        s0[hy][hx] = in ? a.g_mu[o] : 0.0f;
-        s1[hy][hx] = in ? a.g_xx[o] : 0.0f;
-        s2[hy][hx] = in ? a.g_xy[o] : 0.0f;
-    }
+    load_halo(s0, a.g_mu + cb, a.W, a.H, x0, y0);                             // no ssim term outside the image
+    load_halo(s1, a.g_xx + cb, a.W, a.H, x0, y0);
+    load_halo(s2, a.g_xy + cb, a.W, a.H, x0, y0);
     __syncthreads();
-    float c0 = 0, c1 = 0, c2 = 0;
+    float c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int j = 0; j < LNF; ++j) {                                           // symmetric window: k(q-p) = k(p-q)
+        float w[LNF];
 #pragma unroll
-    for (int j = 0; j < LW; ++j)
+        for (int i = 0; i < LNF; ++i) w[i] = a.win[j * LW + i];
+        float u[16], v[16];
+        load_row16(u, s0, ty + j, tx);
+        if (j < LP) { load_row16(v, s0, ty + 2 * LP - j, tx);
 #pragma unroll
-        for (int i = 0; i < LW; ++i) {
-            const float k = a.win[j * LW + i];                               // symmetric window: k(q-p) = k(p-q)
-            c0 = fmaf(k, s0[ty + j][tx + i], c0); c1 = fmaf(k, s1[ty + j][tx + i], c1); c2 = fmaf(k, s2[ty + j][tx + i], c2);
+            for (int i = 0; i < 14; ++i) u[i] += v[i]; }
+        fold_cols(c0, u, w);
+        load_row16(u, s1, ty + j, tx);
+        if (j < LP) { load_row16(v, s1, ty + 2 * LP - j, tx);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) u[i] += v[i]; }
+        fold_cols(c1, u, w);
+        load_row16(u, s2, ty + j, tx);
+        if (j < LP) { load_row16(v, s2, ty + 2 * LP - j, tx);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) u[i] += v[i]; }
+        fold_cols(c2, u, w);
+    }
+    const int py = y0 + ty;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int px = x0 + 4 * tx + o;
+        if (px < a.W && py < a.H) {
+            const size_t q = cb + (size_t)py * a.W + px;
+            const float x = a.img[q], y = a.gt[q], d = x - y;
+            const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+            a.dC[q] = a.w_l1 * sgn + a.w_ssim * (c0[o] + 2.0f * x * c1[o] + y * c2[o]);
         }
-    const int px = x0 + tx, py = y0 + ty;
-    if (px < a.W && py < a.H) {
-        const size_t o = cb + (size_t)py * a.W + px;
-        const float x = a.img[o], y = a.gt[o], d = x - y;
-        const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-        a.dC[o] = a.w_l1 * sgn + a.w_ssim * (c0 + 2.0f * x * c1 + y * c2);
     }
 }
 
 hipError_t gs_launch_loss(const GsLossArgs &a, hipStream_t s) {
     hipError_t e = hipMemsetAsync(a.acc, 0, 2 * sizeof(double), s);
     if (e != hipSuccess) return e;
-    const dim3 grid((a.W + LT - 1) / LT, (a.H + LT - 1) / LT, a.C), block(256);
+    const dim3 grid((a.W + LTX - 1) / LTX, (a.H + LTY - 1) / LTY, a.C), block(256);
     hipLaunchKernelGGL(ssim_stats_kernel, grid, block, 0, s, a);
     hipLaunchKernelGGL(ssim_grad_kernel, grid, block, 0, s, a);
     return hipGetLastError();
