@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--t-min", type=float, default=1e-5, help="transmittance early-out (0 = literal reference)")
     ap.add_argument("--order", type=int, default=1)
-    ap.add_argument("--rank-mode", type=int, default=0, help="radix-sort stable ranks: 0 LDS atomic-add-return (probed at gs_create), 1 wave64 ballots")
+    ap.add_argument("--rank-mode", type=int, default=1, help="radix-sort stable ranks (depth sort): 1 wave64 ballots (default), 0 LDS atomic-add-return (probed at gs_create; -4 us per C3 frame)")
     ap.add_argument("--schedule", type=int, default=3, help="gs_config.schedule (3 default; 4 = forward tiles ordered by the previous frame's per-tile work)")
     ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")

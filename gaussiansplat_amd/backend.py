@@ -122,7 +122,7 @@ class Context:
     """Owns one gs_ctx (one GPU, one stream)."""
 
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
-                 profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 0,
+                 profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 1,
                  alpha_cull: bool = True, schedule: int = 3, slab_mode: int = 1):
         self.L = load()
         cfg = default_config()

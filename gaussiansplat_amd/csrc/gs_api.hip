@@ -241,6 +241,7 @@ void gs_default_config(gs_config *cfg) {
     cfg->deterministic = 0;
     cfg->export_debug = 0;
     cfg->profile_stages = 0;
+    cfg->rank_mode = 1;                  // ballots: with the two-level binning the LDS-atomic rank only serves the depth sort (0.3 % of a C3 frame)
     cfg->alpha_cull = 1;
     cfg->schedule = 3;
     cfg->slab_mode = 1;

@@ -105,7 +105,7 @@ def initGrads(splatData: SplatData3D) -> SplatGrads3D:
 class GaussianRenderer3D:               # renderer.jl:205-219
     def __init__(self, splatData: SplatData3D, imgSize, sh_degree: int, device: int = 0, order: int = B.ORDER_DEPTH_DESC,
                  t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False, deterministic: bool = False,
-                 alpha_cull: bool = True, rank_mode: int = 0, slab_mode: int = 1, schedule: int = 3):
+                 alpha_cull: bool = True, rank_mode: int = 1, slab_mode: int = 1, schedule: int = 3):
         import torch
         self.splatData = splatData
         self._splatGrads = initGrads(splatData)

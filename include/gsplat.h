@@ -81,9 +81,11 @@ typedef struct {
     int32_t bin_path;         /* tile lists (same lists on every path, bit for bit): 0 (default) two-level binning -- lists per
                                  super-tile of 8 x 8 tiles from an LDS bitmap, tile lists as filtered copies; 2: radix sort of
                                  instances generated in-pass (32-bit words); 1: explicit 64-bit tile|id instances + two radix passes */
-    int32_t rank_mode;        /* radix-sort stable ranks: 0 = one LDS atomic-add-return per key -- its pre-values come back in
-                                 ascending lane order on gfx950, which gs_create CHECKS on the device with a probe kernel and
-                                 falls back to 1 if the check fails; 1 = wave64 ballots (portable); same lists either way   */
+    int32_t rank_mode;        /* radix-sort stable ranks: 1 (default) = wave64 ballots (portable); 0 = one LDS atomic-add-return per
+                                 key -- its pre-values come back in ascending lane order on gfx950, which is an observed, not a
+                                 documented property: gs_create CHECKS it on the device with a probe kernel and falls back to 1 if
+                                 the check fails.  Same lists either way.  Since the two-level binning only the depth sort ranks
+                                 keys at all; there the atomic form saves 4 us of a 1.44 ms C3 frame, so ballots are the default */
     int32_t alpha_cull;       /* 1 (default): while staging a tile's list the composite kernels drop every
                                  (tile, splat) entry whose largest alpha over that tile's pixels is below 2^-27
                                  -- a no-op in the reference's own fp32 arithmetic (T*(1-alpha) == T, colour term
