@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal (t_min=0) measurement")
+    ap.add_argument("--no-train-iteration", action="store_true", help="skip the extra training-iteration measurement (loss + SGD, N = 1)")
     ap.add_argument("--grad-sync", default="allreduce", choices=["factored", "allreduce"],
                     help="N > 1, the exchange of the headline number: 'allreduce' (default, the north_star collective) = ONE all-reduce "
                          "of the flat 59N-float gradient buffer; 'factored' = the same gradients from an all-reduce of the 11N geometry "
@@ -348,6 +349,25 @@ def main():
             out["literal_t_min_0"] = {"value": world * n * k0 / dt0 / 1e6, "unit": "Msplats/s", "ms_per_step": dt0 / k0 * 1e3, "steps": k0,
                                       "stage_ms": {k: round(s / c if c else 0.0, 4) for k, (s, c) in st0.items()}}
         del r0
+    if not args.no_train_iteration and world == 1 and args.config in ("C1", "C2", "C3"):
+        # SURVEY 8(f).2 beside the headline: one iteration of src/train.jl as intended = the fwd+bwd step + the L1/DSSIM loss
+        # with its image gradient (gs_loss.hip) + the SGD update; reported, never `value`
+        from gaussiansplat_amd import train as TR
+        torch.cuda.empty_cache()
+        rt = make(args.t_min, 0)
+        gt = torch.rand((3, H, W), device="cuda")
+        lf = TR.getLossFunction((W, H, 3), 11, 3, renderer=rt)
+        for _ in range(3):
+            TR.trainStep(rt, gt, 1e-4, lf, cam, want_loss=False)
+        torch.cuda.synchronize()
+        kt = max(2, min(args.steps, 20))
+        t0 = time.perf_counter()
+        for _ in range(kt):
+            TR.trainStep(rt, gt, 1e-4, lf, cam, want_loss=False)
+        torch.cuda.synchronize()
+        out["train_iteration"] = {"ms": (time.perf_counter() - t0) / kt * 1e3, "iterations": kt,
+                                  "what": "preprocess, lists, forward, L1+DSSIM loss and image gradient, backward, SGD step (train.jl:33-56)"}
+        del rt
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:                # rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.t_min, args.order)
