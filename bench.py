@@ -367,6 +367,14 @@ def main():
         torch.cuda.synchronize()
         out["train_iteration"] = {"ms": (time.perf_counter() - t0) / kt * 1e3, "iterations": kt,
                                   "what": "preprocess, lists, forward, L1+DSSIM loss and image gradient, backward, SGD step (train.jl:33-56)"}
+        for _ in range(2):
+            TR.trainStep(rt, gt, 1e-4, lf, cam, want_loss=False, fused_sgd=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(kt):
+            TR.trainStep(rt, gt, 1e-4, lf, cam, want_loss=False, fused_sgd=True)
+        torch.cuda.synchronize()
+        out["train_iteration"]["ms_with_fused_backward_sgd"] = (time.perf_counter() - t0) / kt * 1e3
         del rt
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:                # rank 0, N = 1 only

@@ -24,7 +24,7 @@ STAGES = ("preprocess", "depth_sort", "count_scan", "emit", "tile_sort", "ranges
 
 # every symbol include/gsplat.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs_last_error", "gs_set_stream",
-           "gs_synchronize", "gs_set_model", "gs_set_model_2d", "gs_set_image_size", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_bind_outputs", "gs_forward",
+           "gs_synchronize", "gs_set_model", "gs_set_model_2d", "gs_set_image_size", "gs_set_camera", "gs_preprocess", "gs_bin", "gs_bind_outputs", "gs_forward", "gs_backward_sgd",
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
@@ -81,6 +81,7 @@ def load():
     L.gs_preprocess.argtypes = [vp]
     L.gs_bin.argtypes = [vp, C.c_int32, C.c_int32]
     L.gs_bind_outputs.argtypes = [vp, vp, vp]
+    L.gs_backward_sgd.argtypes = [vp, vp, C.c_int, C.c_float]
     L.gs_forward.argtypes = [vp, vp, vp, C.c_int]
     L.gs_backward.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads)]
     L.gs_backward_ex.argtypes = [vp, vp, C.c_int, C.POINTER(GsGrads), C.c_int]
@@ -230,6 +231,10 @@ class Context:
         assert cr.ndim == 2 and cr.shape[1] == 38
         self._chk(self.L.gs_sh_grads_from_views(self.h, cr.shape[0], C.c_void_p(cr.ctypes.data), C.c_void_p(int(drgb_ptr)),
                                                 C.c_void_p(int(d_shs_ptr)), 1 if overwrite else 0))
+
+    def backward_sgd(self, dC_ptr: int, lr: float):
+        """gs_backward_sgd: backward and `param .-= lr * grad` (train.jl:42-46) in one pass on the resident model; dC on the device."""
+        self._chk(self.L.gs_backward_sgd(self.h, C.c_void_p(dC_ptr), GS_MEM_DEVICE, C.c_float(lr)))
 
     def grads_alloc(self) -> GsGrads:
         """Library-owned flat gradient buffer (for hosts without a device allocator, e.g. plain Julia)."""

@@ -842,7 +842,24 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
 
 int gs_backward(gs_ctx *c, const float *dC, int mem, const gs_grads *grads) { return gs_backward_ex(c, dC, mem, grads, 0); }
 
-int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, int flags) {
+static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, int flags, float sgd_scale);
+int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, int flags) { return backward_impl(c, dC, mem, grads, flags, 0.0f); }
+
+// backward + SGD in one pass: the per-gaussian kernels apply param = fma(-lr, gradient, param) to the resident model instead
+// of storing the gradient (the same fma gs_sgd_step applies to the stored float): one read-modify-write of the parameters
+// instead of gradient write + gradient read + parameter read-modify-write.  Single-view steps only (nothing is accumulated).
+int gs_backward_sgd(gs_ctx *c, const float *dC, int mem, float lr) {
+    if (!c) return GS_ERR_INVALID;
+    if (c->kind != 0) return fail(c, GS_ERR_UNSUPPORTED, "gs_backward_sgd: 3-D renderer only");
+    if (!(lr != 0.0f)) return fail(c, GS_ERR_INVALID, "gs_backward_sgd: lr must be non-zero");
+    gs_grads g{const_cast<float *>(c->means), const_cast<float *>(c->scales), const_cast<float *>(c->quats),
+               const_cast<float *>(c->opac), const_cast<float *>(c->shs)};
+    const int rc = backward_impl(c, dC, mem, &g, 0, -lr);
+    if (rc == GS_OK) c->did_pre = c->did_bin = c->did_fwd = c->did_bwd = false;       // the model changed
+    return rc;
+}
+
+static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, int flags, float sgd_scale) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_backward: gs_forward first");
     const bool params_only = (flags & GS_BWD_PARAMS_ONLY) != 0, composite_only = (flags & GS_BWD_COMPOSITE_ONLY) != 0;
@@ -914,6 +931,7 @@ int gs_backward_ex(gs_ctx *c, const float *dC, int mem, const gs_grads *grads, i
     HIPCHK(c, c->dpc.ensure(sizeof(float) * 4 * n1));
     b.dpc = c->dpc.as<float>();
     b.overwrite = (flags & GS_BWD_OVERWRITE) ? 1 : 0;
+    b.sgd_scale = sgd_scale;
     b.d_means = grads->d_means; b.d_scales = grads->d_scales; b.d_quats = grads->d_quats;
     b.d_opac = grads->d_opacities; b.d_shs = grads->d_shs;
     {

@@ -222,6 +222,8 @@ struct GsPreprocessBwdArgs {
     float *d_means, *d_scales, *d_quats, *d_opac, *d_shs;   // accumulate (+=) or overwrite; may be null
     float *dpc;           // scratch 4 x n: d L / d tps[1:3] through the colour
     int overwrite;        // 1: store instead of accumulate
+    float sgd_scale;      // != 0 (accumulate mode only): target = fma(sgd_scale, gradient, target) -- with the parameter arrays as
+                          // targets and sgd_scale = -lr this IS the SGD step, fused (gs_backward_sgd)
 };
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s);
 

@@ -134,13 +134,19 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
             for (int i4 = threadIdx.x; i4 < nb * (3 * K / 4); i4 += blockDim.x) {
                 const float *t = tile + ((i4 * 4) / (3 * K)) * ROW + (i4 * 4) % (3 * K);
                 float4 v = make_float4(t[0], t[1], t[2], t[3]);
-                if (!OVERWRITE) { const float4 o = dst[i4]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                if (!OVERWRITE) {
+                    const float4 o = dst[i4];
+                    if (a.sgd_scale != 0.0f) { v.x = fmaf(a.sgd_scale, v.x, o.x); v.y = fmaf(a.sgd_scale, v.y, o.y); v.z = fmaf(a.sgd_scale, v.z, o.z); v.w = fmaf(a.sgd_scale, v.w, o.w); }
+                    else { v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                }
                 dst[i4] = v;
             }
         } else {
             for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x) {
                 const float v = tile[(idx / (3 * K)) * ROW + idx % (3 * K)];
-                if (OVERWRITE) a.d_shs[gb * 3 * K + idx] = v; else a.d_shs[gb * 3 * K + idx] += v;
+                if (OVERWRITE) a.d_shs[gb * 3 * K + idx] = v;
+                else if (a.sgd_scale != 0.0f) a.d_shs[gb * 3 * K + idx] = fmaf(a.sgd_scale, v, a.d_shs[gb * 3 * K + idx]);
+                else a.d_shs[gb * 3 * K + idx] += v;
             }
         }
     }
@@ -151,6 +157,10 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
 __device__ __forceinline__ float add_exact(float old, float v) {
 #pragma clang fp contract(off)
     return old + v;
+}
+// accumulate, or (sgd_scale != 0) apply the step: the same fma gs_sgd_step would do on the stored float gradient
+__device__ __forceinline__ float acc_or_step(float old, float v, float sgd_scale) {
+    return sgd_scale != 0.0f ? fmaf(sgd_scale, v, old) : add_exact(old, v);
 }
 
 template <bool OVERWRITE>
@@ -292,25 +302,25 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float v = live ? (float)(T[4 * j] * dt[0] + T[1 + 4 * j] * dt[1] + T[2 + 4 * j] * dt[2] + T[3 + 4 * j] * dt[3]) : 0.0f;
-            if (OVERWRITE) a.d_means[3 * g + j] = v; else a.d_means[3 * g + j] = add_exact(a.d_means[3 * g + j], v);
+            if (OVERWRITE) a.d_means[3 * g + j] = v; else a.d_means[3 * g + j] = acc_or_step(a.d_means[3 * g + j], v, a.sgd_scale);
         }
     }
     if (a.d_scales) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float v = live ? (float)(de[j] * e[j]) : 0.0f;
-            if (OVERWRITE) a.d_scales[3 * g + j] = v; else a.d_scales[3 * g + j] = add_exact(a.d_scales[3 * g + j], v);
+            if (OVERWRITE) a.d_scales[3 * g + j] = v; else a.d_scales[3 * g + j] = acc_or_step(a.d_scales[3 * g + j], v, a.sgd_scale);
         }
     }
     if (a.d_quats) {
         float4 *q = reinterpret_cast<float4 *>(a.d_quats) + g;
         float4 o = OVERWRITE ? make_float4(0.f, 0.f, 0.f, 0.f) : *q;
-        if (live) { o.x = add_exact(o.x, (float)dw); o.y = add_exact(o.y, (float)dx); o.z = add_exact(o.z, (float)dy); o.w = add_exact(o.w, (float)dz); }
+        if (live) { o.x = acc_or_step(o.x, (float)dw, a.sgd_scale); o.y = acc_or_step(o.y, (float)dx, a.sgd_scale); o.z = acc_or_step(o.z, (float)dy, a.sgd_scale); o.w = acc_or_step(o.w, (float)dz, a.sgd_scale); }
         *q = o;
     }
     if (a.d_opac) {
         const float v = live ? (float)(gsig * sg * (1.0 - sg)) : 0.0f;
-        if (OVERWRITE) a.d_opac[g] = v; else a.d_opac[g] = add_exact(a.d_opac[g], v);
+        if (OVERWRITE) a.d_opac[g] = v; else a.d_opac[g] = acc_or_step(a.d_opac[g], v, a.sgd_scale);
     }
 }
 

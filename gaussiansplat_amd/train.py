@@ -66,12 +66,20 @@ def getLossFunction(imSize, windowSize: int, nChannels: int, renderer=None, λ: 
     return LossFunction(renderer, imSize, windowSize, nChannels, λ)
 
 
-def trainStep(renderer, gtimg, lr: float, lossFunc: LossFunction, camera=None, want_loss: bool = True):
-    """One iteration of train.jl:33-56 as intended (see module docstring)."""
+def trainStep(renderer, gtimg, lr: float, lossFunc: LossFunction, camera=None, want_loss: bool = True, fused_sgd: bool = False):
+    """One iteration of train.jl:33-56 as intended (see module docstring).
+    fused_sgd (3-D renderer): backward and the parameter update in one pass (gs_backward_sgd) -- the same parameters bit for
+    bit (deterministic mode), but renderer.splatGrads is not filled."""
     tps = R.preprocess(renderer, camera)
     R.compactIdxs(renderer)
     R.forward(renderer, tps)
     loss, ΔC = lossFunc.value_and_grad(renderer.imageData, gtimg, want_loss)
+    if fused_sgd:
+        renderer._dC_keepalive = ΔC
+        renderer._begin()
+        renderer.ctx.backward_sgd(ΔC.data_ptr(), float(lr))
+        renderer._end()
+        return loss
     R.backward(renderer, ΔC)
     renderer._begin()
     renderer.ctx.sgd_step(float(lr), renderer._grads)        # param .-= lr * Δparam (train.jl:42-46)

@@ -199,6 +199,10 @@ int gs_backward(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads);
 #define GS_BWD_COMPOSITE_ONLY 2
 #define GS_BWD_PARAMS_ONLY 4
 int gs_backward_ex(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads, int flags);
+/* Backward AND the optimiser step of train.jl:39-46 in one pass (3-D renderer, single-view steps): the per-gaussian kernels apply
+ * param = fma(-lr, gradient, param) to the resident model instead of storing gradients -- bit-identical to gs_backward
+ * (GS_BWD_OVERWRITE) followed by gs_sgd_step, at one read-modify-write of the 59 N parameter floats instead of three passes. */
+int gs_backward_sgd(gs_ctx *ctx, const float *dC, int mem, float lr);
 
 /* resetGrads: zero the arrays of `grads` (DEVICE pointers) on the ctx stream. */
 int gs_reset_grads(gs_ctx *ctx, const gs_grads *grads);

@@ -125,6 +125,11 @@ function hip_forward!(r::HipRenderer, imageData::Array{Float32, 3}, transmittanc
                    r.ctx, imageData, transmittance, GS_MEM_HOST))
 end
 
+# backward + `param .-= lr * grad` (src/train.jl:42-46) fused: the resident model is updated in place, no gradient arrays
+function hip_backward_sgd!(r::HipRenderer, ΔC::Array{Float32, 3}, lr::Float32)
+    check(r, ccall((:gs_backward_sgd, libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}, Cint, Cfloat), r.ctx, ΔC, GS_MEM_HOST, lr))
+end
+
 # initGrads (src/splat.jl:137-156): one flat zeroed device buffer owned by the library
 function hip_initGrads(r::HipRenderer)
     g = Ref(GsGrads(C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))

@@ -55,3 +55,27 @@ def test_sgd_step_and_training_reduces_loss():
     losses = TR.train(r, gt, 2.0, lf, iterations=25, camera=cam)
     assert losses[-1] < 0.95 * l0 and losses[-1] < losses[0], (l0, losses[0], losses[-1])   # plain SGD: slow but downhill
     assert all(np.isfinite(losses))
+
+
+def test_fused_backward_sgd_equals_backward_then_sgd():
+    """gs_backward_sgd updates the resident model exactly like gs_backward (overwrite) followed by gs_sgd_step: the same fma on
+    the same float gradient, so the parameters agree bit for bit in deterministic mode."""
+    import torch
+    from gaussiansplat_amd import renderer as R, synthetic, train as TR
+    n, W, H, deg = 4000, 160, 112, 3
+    gx, gy = W // 16, H // 16
+    scene = synthetic.make_scene(n, W, H, deg, seed=21)
+    cam = synthetic.scene_camera(W)
+    gt = torch.rand((3, H, W), device="cuda")
+    out = []
+    for fused in (False, True):
+        r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene, deterministic=True)
+        lf = TR.getLossFunction((W, H, 3), 11, 3, renderer=r)
+        for _ in range(3):
+            TR.trainStep(r, gt, 0.05, lf, cam, want_loss=False, fused_sgd=fused)
+        torch.cuda.synchronize()
+        sd = r.splatData
+        out.append([x.clone() for x in (sd.means, sd.scales, sd.quaternions, sd.opacities, sd.shs)])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert not torch.equal(out[0][4], torch.as_tensor(scene["shs"]).reshape(out[0][4].shape).cuda())    # the model moved

@@ -16,16 +16,17 @@ r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene, device=0,
 cam = synthetic.scene_camera(W, view=0)
 gt = torch.rand((3, H, W), device="cuda")
 lossFunc = TR.getLossFunction((W, H, 3), 11, 3, renderer=r)
-for want in (False, True):
+for want, fused in ((False, False), (True, False), (False, True)):
     for _ in range(5):
-        TR.trainStep(r, gt, 1e-4, lossFunc, cam, want_loss=want)
+        TR.trainStep(r, gt, 1e-4, lossFunc, cam, want_loss=want, fused_sgd=fused)
     torch.cuda.synchronize()
     K = 50
     t0 = time.perf_counter()
     for _ in range(K):
-        TR.trainStep(r, gt, 1e-4, lossFunc, cam, want_loss=want)
+        TR.trainStep(r, gt, 1e-4, lossFunc, cam, want_loss=want, fused_sgd=fused)
     torch.cuda.synchronize()
-    print({"config": cfg, "want_loss_value_on_host": want, "ms_per_iteration": round((time.perf_counter() - t0) / K * 1e3, 3)})
+    print({"config": cfg, "want_loss_value_on_host": want, "fused_backward_sgd": fused,
+           "ms_per_iteration": round((time.perf_counter() - t0) / K * 1e3, 3)})
 # the pieces
 def timeit(f, k=50):
     for _ in range(3): f()
