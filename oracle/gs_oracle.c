@@ -444,16 +444,37 @@ int gso_tile_rect(const float bb[4], int tile, int gx, int gy, int32_t rect[4]) 
     return 1;
 }
 
+/* hitBinning + scan! + compactHits as sparse lists (binning.jl:3-35, forward.jl:137-141, compact.jl:3-21).
+ * Threads own bands of tile ROWS: every thread walks the gaussians in list order and only touches the tiles
+ * of its rows, so every tile's list is written by one thread in list order -- the result does not depend on the
+ * thread count (the single-threaded build runs the same code with one band). */
 int64_t gso_bin(int64_t n, const float *bbs, const float *tps, const uint32_t *perm,
                 int order, int tile, int gx, int gy,
                 uint32_t *ranges, uint32_t *ids, uint64_t *keys, int64_t cap) {
     const int64_t nt = (int64_t)gx * gy;
     int64_t *cnt = (int64_t *)calloc((size_t)nt + 1, sizeof(int64_t));
+    int32_t *rcs = (int32_t *)malloc(sizeof(int32_t) * 4 * (size_t)(n > 0 ? n : 1));   /* tile rect per gaussian, rcs[4g] = 0: none */
+#pragma omp parallel for schedule(static)
     for (int64_t g = 0; g < n; ++g) {
         int32_t rc[4];
-        if (!gso_tile_rect(bbs + 4 * g, tile, gx, gy, rc)) continue;
-        for (int ty = rc[2]; ty <= rc[3]; ++ty)
-            for (int tx = rc[0]; tx <= rc[1]; ++tx) cnt[(int64_t)(ty - 1) * gx + (tx - 1)]++;
+        if (!gso_tile_rect(bbs + 4 * g, tile, gx, gy, rc)) rc[0] = rc[1] = rc[2] = rc[3] = 0;
+        memcpy(rcs + 4 * g, rc, sizeof(rc));
+    }
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+        const int nth = omp_get_num_threads(), tid = omp_get_thread_num();
+#else
+        const int nth = 1, tid = 0;
+#endif
+        const int y0 = (int)((int64_t)gy * tid / nth) + 1, y1 = (int)((int64_t)gy * (tid + 1) / nth);   /* rows y0..y1, 1-based */
+        for (int64_t g = 0; g < n && y0 <= y1; ++g) {
+            const int32_t *rc = rcs + 4 * g;
+            if (rc[0] == 0) continue;
+            const int a = rc[2] > y0 ? rc[2] : y0, b = rc[3] < y1 ? rc[3] : y1;
+            for (int ty = a; ty <= b; ++ty)
+                for (int tx = rc[0]; tx <= rc[1]; ++tx) cnt[(int64_t)(ty - 1) * gx + (tx - 1)]++;
+        }
     }
     int64_t total = 0;
     for (int64_t t = 0; t < nt; ++t) { int64_t c = cnt[t]; cnt[t] = total; total += c; }
@@ -462,23 +483,35 @@ int64_t gso_bin(int64_t n, const float *bbs, const float *tps, const uint32_t *p
     if (ids || keys) {
         int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nt > 0 ? nt : 1));
         memcpy(cur, cnt, sizeof(int64_t) * (size_t)nt);
-        for (int64_t s = 0; s < n; ++s) {
-            int64_t g = perm ? (int64_t)perm[s] : s;        /* list order: index or depth rank */
-            int32_t rc[4];
-            if (!gso_tile_rect(bbs + 4 * g, tile, gx, gy, rc)) continue;
-            uint32_t lo = (order == GSO_ORDER_INDEX) ? (uint32_t)g : gso_depth_key(tps[4 * g + 2], order);
-            for (int ty = rc[2]; ty <= rc[3]; ++ty)
-                for (int tx = rc[0]; tx <= rc[1]; ++tx) {
-                    int64_t t = (int64_t)(ty - 1) * gx + (tx - 1);
-                    int64_t p = cur[t]++;
-                    if (p < cap) {
-                        if (ids) ids[p] = (uint32_t)g;
-                        if (keys) keys[p] = ((uint64_t)t << 32) | lo;
+#pragma omp parallel
+        {
+#ifdef _OPENMP
+            const int nth = omp_get_num_threads(), tid = omp_get_thread_num();
+#else
+            const int nth = 1, tid = 0;
+#endif
+            const int y0 = (int)((int64_t)gy * tid / nth) + 1, y1 = (int)((int64_t)gy * (tid + 1) / nth);
+            for (int64_t s = 0; s < n && y0 <= y1; ++s) {
+                const int64_t g = perm ? (int64_t)perm[s] : s;      /* list order: index or depth rank */
+                const int32_t *rc = rcs + 4 * g;
+                if (rc[0] == 0) continue;
+                const int a = rc[2] > y0 ? rc[2] : y0, b = rc[3] < y1 ? rc[3] : y1;
+                if (a > b) continue;
+                const uint32_t lo = (order == GSO_ORDER_INDEX) ? (uint32_t)g : gso_depth_key(tps[4 * g + 2], order);
+                for (int ty = a; ty <= b; ++ty)
+                    for (int tx = rc[0]; tx <= rc[1]; ++tx) {
+                        const int64_t t = (int64_t)(ty - 1) * gx + (tx - 1);
+                        const int64_t p = cur[t]++;
+                        if (p < cap) {
+                            if (ids) ids[p] = (uint32_t)g;
+                            if (keys) keys[p] = ((uint64_t)t << 32) | lo;
+                        }
                     }
-                }
+            }
         }
         free(cur);
     }
+    free(rcs);
     free(cnt);
     return total;
 }

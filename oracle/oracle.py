@@ -39,6 +39,7 @@ def lib(omp: bool = False):
     if key not in _libs:
         build()
         path = os.path.join(_HERE, "_build", "libgs_oracle_omp.so" if omp else "libgs_oracle.so")
+        path = os.environ.get("GS_ORACLE_LIB", path)        # `make -C oracle asan-test`: the ASan/UBSan build of the same source
         L = C.CDLL(path)
         fp, u32p, u64p, dp = (C.POINTER(t) for t in (C.c_float, C.c_uint32, C.c_uint64, C.c_double))
         L.gso_expf.restype = C.c_float; L.gso_expf.argtypes = [C.c_float]

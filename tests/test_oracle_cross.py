@@ -80,3 +80,41 @@ def test_dense_literal_lists_equal_sparse_index_order(oracle):
         col = hit[:, t // gx, t % gx]
         lst = col[col != 0] - 1
         assert np.array_equal(lst, ids[ranges[t, 0]:ranges[t, 1]])
+
+
+def test_openmp_native_build_is_bit_identical_to_the_serial_build(oracle):
+    """The bench's cpu_baseline leg runs libgs_oracle_omp.so (-O3 -march=native -fopenmp, oracle/Makefile): same source,
+    -ffp-contract=off, lists built by threads that own bands of tile rows.  Every output must equal the serial -O2 build
+    whatever the thread count (ragged grid: more threads than tile rows included)."""
+    import ctypes as C
+    import os
+    O = oracle
+    if os.environ.get("GS_ORACLE_LIB"):
+        pytest.skip("one library forced through GS_ORACLE_LIB (sanitizer run)")
+    n, W, H, deg = 6000, 200, 72, 2
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 21)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    dC = np.random.default_rng(3).standard_normal((3, H, W)).astype(np.float32)
+    omp = C.CDLL("libgomp.so.1")
+
+    def run(par, threads):
+        if par:
+            omp.omp_set_num_threads(threads)
+        pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, omp=par)
+        perm = O.depth_order(pre["tps"], 1)
+        L = O.lib(par)
+        fp, u32, u64 = (lambda a, t=t: a.ctypes.data_as(C.POINTER(t)) for t in (C.c_float, C.c_uint32, C.c_uint64))
+        tot = L.gso_bin(n, fp(pre["bbs"]), fp(pre["tps"]), u32(perm), 1, 16, gx, gy, None, None, None, 0)
+        rg = np.zeros((gx * gy, 2), np.uint32); ids = np.zeros(tot, np.uint32); keys = np.zeros(tot, np.uint64)
+        L.gso_bin(n, fp(pre["bbs"]), fp(pre["tps"]), u32(perm), 1, 16, gx, gy, u32(rg), u32(ids), u64(keys), tot)
+        img, tr = O.composite_forward(pre, rg, ids, ocam, 16, gx, gy, t_min=1e-4, omp=par)
+        return pre, rg, ids, keys, img, tr
+
+    ref = run(False, 1)
+    for threads in (1, 3, 8, 13):
+        got = run(True, threads)
+        for k in ref[0]:
+            assert np.array_equal(ref[0][k], got[0][k], equal_nan=True), (threads, k)
+        for a, b in zip(ref[1:], got[1:]):
+            assert np.array_equal(a, b, equal_nan=True), threads
+    omp.omp_set_num_threads(os.cpu_count() or 1)
