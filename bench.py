@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X Gaussian-splat hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C3|C4|C1|C2|C5] [--views V]
 
 N > 1 either arrives already launched (python -m torch.distributed.run ... bench.py --gpus N: WORLD_SIZE == N) or, from a
 bare shell, starts its N ranks itself as child processes of `python -m torch.distributed.run` BEFORE anything touches the
 GPU (never an exec of a process that initialised HIP) and exits with their return code.
 
-A step = one fwd+bwd pass of the hot path over one camera view of the synthetic scene:
-preprocess -> tile|depth keys + radix sort -> composite forward -> composite backward ->
-per-gaussian backward (+ ONE RCCL all-reduce of the flat 59N-float gradient buffer when N > 1; the colour-factored
-exchange is timed beside it and reported under "factored_exchange").
-Weak scaling: every GPU renders its own view (one camera per GPU) of the replicated model.
-Inputs (model, dC) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over one VIEW BATCH of the synthetic scene; per view
+    preprocess -> depth sort + two-level tile lists -> composite forward -> composite backward -> per-gaussian backward
+with the parameter gradients ACCUMULATING over the views of the batch.
+
+  N = 1 (default config C3, BASELINE.json's headline): a batch is ONE camera view at 1 M gaussians / 1920x1080 / SH3.  The
+        steps cycle over two cameras (views 0 and 4: the scene seen from the front and from behind, same statistics), each
+        with its own view slot, so no step re-renders the view of the step before it -- a training loop cycles over a fixed
+        camera set in the same way -- and the forward's launch order comes from what the same camera measured two steps ago.
+  N > 1 (default config C4): a batch is the EIGHT views of the 8-GPU training batch.  Rank r renders its
+        8 / N views (gaussiansplat_amd.distributed.shard_views) one after the other, then the ranks sum the flat 59 N-float
+        gradient buffer over RCCL.  `--config C4 --gpus 1` is the same batch on one GPU (the anchor of the scaling curve; the
+        default N = 1 line carries it as "c4_batch").  Strong scaling: the batch is fixed, value = 8 n steps / time.
+
+Inputs (model, dC of every view) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -30,15 +38,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
-def algorithmic_bytes(stage: str, N: int, I: int, Iw_f: int, Iw_b: int, P: int, Tn: int, K: int) -> float:
-    """SURVEY.md section 8(d) per-unit figures (I = instances, Iw = list entries actually walked)."""
+def algorithmic_bytes(stage: str, N: int, I: int, I1: int, Iw_f: int, Iw_b: int, P: int, Tn: int, K: int) -> float:
+    """Algorithmic HBM bytes of one launch of a stage.  SURVEY.md section 8(d) figures for the per-gaussian and the composite
+    stages (I = tile instances, Iw = list entries actually walked).  For the binning the survey prices the reference-style
+    pipeline (12 I key build + 24 I sort + 8 I ranges); the two-level binning that replaced it has less to move, and its own
+    minimum is used so that the fractions cannot exceed 1: per gaussian the rectangle in and out of depth order, per coarse
+    instance I1 (gaussian x super-tile of 8x8 tiles) 6 B written once and read twice, per instance the 4-byte id."""
     per_g_params = 4 * (3 + 3 + 4 + 1 + 3 * K)
     return {
         "preprocess": (per_g_params + 48) * N,
         "depth_sort": 16 * N,                       # one read + one write of the 8-byte (depth|id) pair
-        "count_scan": 12 * N,
+        "count_scan": 20 * N,                       # level-1 histogram: perm 4 + rectangle 8 read, rectangle in list order 8 written
         "emit": 12 * I,
-        "tile_sort": 24 * I,
+        "tile_sort": 8 * N + 18 * I1 + 4 * I + 8 * Tn,   # level-1 scatter + level 2 (counts, ranges, lists)
         "ranges": 8 * I + 8 * Tn,
         "composite_fwd": 40 * Iw_f + 16 * P,
         "composite_bwd": 40 * Iw_b + 20 * P + 36 * Iw_b,
@@ -57,41 +69,41 @@ def csrc_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def _pmc_entry(kernel_stage: str, early: bool, config: str):
-    """The dominant kernel's entry in a committed rocprofv3 PMC summary (profiles/*pmc_summary.json, written by
-    tools/pmc_summary.py from separate --pmc passes of this same bench command: SQ/GRBM counters, FETCH_SIZE, WRITE_SIZE)
-    -- only a summary stamped with THIS build's csrc_sha and this config counts; a stale profile gives None."""
+STAGE_KERNELS = {"composite_fwd": "composite_fwd_kernel", "composite_bwd": "composite_bwd_kernel", "preprocess": "gs_preprocess_kernel"}
+
+
+def _pmc_summary(config: str):
+    """The committed rocprofv3 PMC summary (profiles/*pmc_summary.json, written by tools/pmc_summary.py from separate --pmc
+    passes of this same bench command) stamped with THIS build's csrc_sha and this config, else (None, None)."""
     import glob
     sha = csrc_sha()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):
         with open(f) as fh:
             d = json.load(fh)
-        if d.get("csrc_sha") != sha or d.get("config", "C3") != config:
-            continue
-        for name, v in d["kernels"].items():
-            if kernel_stage in name and (("<true" in name) == early):
-                return v, os.path.relpath(f, ROOT)
+        if d.get("csrc_sha") == sha and d.get("config", "C3") == config:
+            return d, os.path.relpath(f, ROOT)
     return None, None
 
 
-def measured_counters(kernel_stage: str, config: str, t_min: float, avg_ms: float):
-    """(traffic, valu) of the dominant kernel from the PMC summary of THIS build (else None, None).
-    traffic: HBM bytes per launch = FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE.
-    valu: the compute-side roofline -- SQ_INSTS_VALU wave-instructions per launch against the issue peak of 1024 SIMDs x
-    one wave64 VALU instruction per 2 cycles (v_fma_f32, MI355X_MICROARCH.md cycle constants)."""
-    if abs(t_min - 1e-5) > 1e-12 and t_min != 0.0:
-        return None, None
-    v, src = _pmc_entry(kernel_stage, t_min > 0, config)
-    if not v:
-        return None, None
-    valu = None
-    if "SQ_INSTS_VALU" in v and v.get("clock_GHz") and avg_ms > 0:
-        cyc = v["clock_GHz"] * 1e9 * avg_ms * 1e-3                   # kernel cycles at the clock measured under the counters
-        valu = {"valu_wave_insts": v["SQ_INSTS_VALU"], "clock_GHz": v["clock_GHz"],
-                "valu_issue_frac": v["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cyc),
-                "cycles_per_valu_inst_per_simd": 1024.0 * cyc / v["SQ_INSTS_VALU"],
-                "mean_waves_per_simd": v.get("mean_waves_per_simd"), "lds_insts": v.get("SQ_INSTS_LDS"), "source": src}
-    return v.get("hbm_bytes_total"), valu
+def _pmc_entry(summary, stage: str, early: bool):
+    if not summary or stage not in STAGE_KERNELS:
+        return None
+    for name, v in summary["kernels"].items():
+        if STAGE_KERNELS[stage] in name and (stage == "preprocess" or ("<true" in name) == early):
+            return v
+    return None
+
+
+def valu_view(v, avg_ms: float, src: str):
+    """Compute-side roofline of a kernel from its PMC entry: SQ_INSTS_VALU wave-instructions per launch against the issue peak
+    of 1024 SIMDs x one wave64 VALU instruction per 2 cycles (v_fma_f32, MI355X_MICROARCH.md cycle constants)."""
+    if not v or "SQ_INSTS_VALU" not in v or not v.get("clock_GHz") or avg_ms <= 0:
+        return None
+    cyc = v["clock_GHz"] * 1e9 * avg_ms * 1e-3                   # kernel cycles at the clock measured under the counters
+    return {"valu_wave_insts": v["SQ_INSTS_VALU"], "clock_GHz": v["clock_GHz"],
+            "valu_issue_frac": v["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cyc),
+            "cycles_per_valu_inst_per_simd": 1024.0 * cyc / v["SQ_INSTS_VALU"],
+            "mean_waves_per_simd": v.get("mean_waves_per_simd"), "lds_insts": v.get("SQ_INSTS_LDS"), "source": src}
 
 
 def loop_cost_model(kernel_stage: str, avg_ms: float, evaluated: int):
@@ -146,8 +158,9 @@ def cpu_baseline(t_min: float, order: int):
     O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, r["ranges"], r["ids"], dC, t_min=t_min, omp=True)
     dt = time.perf_counter() - t0
     return {"value": n / dt / 1e6, "unit": "Msplats/s", "cores": cores, "kind": "port",
-            "sample": f"{cfg}: {n} gaussians, {W}x{H}, SH{deg}, one fwd+bwd, t_min={t_min:g}, {dt:.2f} s wall "
-                      "(oracle/gs_oracle.c, OpenMP over gaussians/tiles; list building single-threaded; fp64 adjoint)"}
+            "sample": f"{cfg}: {n} gaussians, {W}x{H}, SH{deg}, one fwd+bwd of view 0, t_min={t_min:g}, {dt:.2f} s wall "
+                      "(oracle/gs_oracle.c built gcc -O3 -march=native -fopenmp -ffp-contract=off; OpenMP over gaussians, tile-row "
+                      "bands (lists) and tiles (composite); depth order by qsort on one thread; fp64 adjoint)"}
 
 
 def main():
@@ -155,22 +168,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="C3")
+    ap.add_argument("--config", default=None, help="C3 (default at --gpus 1), C4 = the 8-view batch (default at --gpus > 1), C1, C2, C5")
+    ap.add_argument("--views", type=int, default=0, help="views per step (default: 8 for C4, else 1)")
+    ap.add_argument("--view-cycle", default="0,4", help="single-view configs: the cameras the steps cycle over (view k = eye rotated by k x 45 degrees)")
     ap.add_argument("--t-min", type=float, default=1e-5, help="transmittance early-out (0 = literal reference)")
     ap.add_argument("--order", type=int, default=1)
-    ap.add_argument("--rank-mode", type=int, default=1, help="radix-sort stable ranks (depth sort): 1 wave64 ballots (default), 0 LDS atomic-add-return (probed at gs_create; -4 us per C3 frame)")
-    ap.add_argument("--schedule", type=int, default=3, help="gs_config.schedule (3 default; 4 = forward tiles ordered by the previous frame's per-tile work)")
+    ap.add_argument("--rank-mode", type=int, default=1, help="radix-sort stable ranks (depth sort): 1 wave64 ballots (default), 0 LDS atomic-add-return (probed at gs_create)")
+    ap.add_argument("--schedule", type=int, default=0, help="gs_config.schedule (0 = library default = 3; 1 = tile order; 4 = forward by the previous frame when its slot has no history)")
+    ap.add_argument("--no-view-slots", action="store_true", help="do not name view slots (the forward then launches in tile order)")
     ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal (t_min=0) measurement")
     ap.add_argument("--no-train-iteration", action="store_true", help="skip the extra training-iteration measurement (loss + SGD, N = 1)")
+    ap.add_argument("--no-c4-anchor", action="store_true", help="N = 1, C3: skip the extra 8-view batch (the N = 1 anchor of the C4 scaling curve)")
     ap.add_argument("--grad-sync", default="allreduce", choices=["factored", "allreduce"],
-                    help="N > 1, the exchange of the headline number: 'allreduce' (default, the north_star collective) = ONE all-reduce "
-                         "of the flat 59N-float gradient buffer; 'factored' = the same gradients from an all-reduce of the 11N geometry "
+                    help="N > 1, the exchange of the headline number: 'allreduce' (default, the north_star collective) = the sum of the "
+                         "flat 59N-float gradient buffer; 'factored' = the same gradients from an all-reduce of the 11N geometry "
                          "floats + an all-gather of 3N colour-gradient floats per view (gaussiansplat_amd/distributed.py), 2.6x less "
                          "xGMI traffic.  The other mode is timed as well and reported beside it.")
+    ap.add_argument("--no-overlap", action="store_true", help="allreduce: literally ONE collective after the last kernel (default: the Δshs "
+                    "segment starts as soon as the last view's SH kernel has run, beside the geometry chain)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = "C3" if args.gpus == 1 else "C4"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: start the N ranks as children of a fresh launcher process.  Nothing in THIS
@@ -187,6 +208,7 @@ def main():
     import torch
     import torch.distributed as dist
     from gaussiansplat_amd import renderer as R, synthetic
+    from gaussiansplat_amd import distributed as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -206,50 +228,50 @@ def main():
             dist.init_process_group(args.backend)
 
     n, W, H, deg = synthetic.CONFIGS[args.config]
-    seed = 1234 + list(synthetic.CONFIGS).index(args.config)
+    seed = 1234 + list(synthetic.CONFIGS).index("C3" if args.config == "C4" else args.config)     # C4 = C3's scene, eight views
     scene = synthetic.make_scene(n, W, H, deg, seed=seed)
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    view = int(os.environ.get("GS_BENCH_VIEW", rank % 8))      # one camera per GPU: eye rotated about +y by k*45 degrees
-    cam = synthetic.scene_camera(W, view=view)
-    dC = torch.as_tensor(synthetic.make_dC(W, H, seed + rank)).cuda()
+    views_per_step = args.views or (8 if args.config == "C4" else 1)
+    if views_per_step > 1:
+        batches = [list(range(views_per_step))]                                  # every step renders the same batch of views 0 .. V-1
+    else:
+        batches = [[int(v)] for v in args.view_cycle.split(",")]                 # step k renders view cycle[k % len]
+    if world > 1 and views_per_step % world:
+        raise SystemExit(f"--views {views_per_step} is not a multiple of --gpus {world}")
+    all_views = sorted({v for b in batches for v in b})
+
+    def camera_of(v):
+        cam = synthetic.scene_camera(W, view=v)                                  # eye rotated about +y by v * 45 degrees; cam.id = v
+        if args.no_view_slots:
+            cam.id = None
+        return cam
+
+    cams = {v: camera_of(v) for v in all_views}
+    dCs = {v: torch.as_tensor(synthetic.make_dC(W, H, seed + v)).cuda() for v in all_views}
 
     def make(t_min, profile_stages):
         return R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene, device=local, order=args.order, t_min=t_min,
                              profile_stages=profile_stages, alpha_cull=not args.no_cull, rank_mode=args.rank_mode, schedule=args.schedule)
 
-    from gaussiansplat_amd import distributed as D
     sync_mode = [args.grad_sync]                                                # the exchange `step` uses (N > 1)
-    all_cams = [synthetic.scene_camera(W, view=int(os.environ.get("GS_BENCH_VIEW", k % 8))) for k in range(world)]   # rank k renders view k
-    cam_records = D.view_records(all_cams, W, H)                                # host, once: the cameras of all ranks' views
 
-    def step(r):
-        R.resetGrads(r)
-        if not (world > 1 and sync_mode[0] == "factored"):
-            tps = R.preprocess(r, cam)
-            R.compactIdxs(r, (16, 16), (gx, gy))
-            R.forward(r, tps, (16, 16), (gx, gy))
-            R.backward(r, dC)
-            if world > 1:
-                dist.all_reduce(r.splatGrads.flat)       # ONE flat RCCL all-reduce (59 N floats at SH3)
-            return
-        # colour-factored exchange: same gradients, 11N floats all-reduced + 3N per view all-gathered; the gather
-        # overlaps the per-gaussian backward (gaussiansplat_amd/distributed.py)
-        if "_bench_hv" not in r.__dict__:                                   # (cycle r <-> hv: collected by gc below)
-            r._bench_hv = D.HipViewRenderer(r)
-            r._bench_allc = torch.empty(world * 3 * n, dtype=torch.float32, device="cuda")
-        D.factored_one_view_step(r._bench_hv, cam, dC, cam_records, r._bench_allc)
+    def step(r, k):
+        """one step = one view batch: this rank's views one after the other (gradients accumulate), then the exchange"""
+        batch = batches[k % len(batches)]
+        hv = r.__dict__.setdefault("_bench_hv", D.HipViewRenderer(r))            # (cycle r <-> hv: collected by gc below)
+        D.multi_view_step(hv, [cams[v] for v in batch], [dCs[v] for v in batch], sync=sync_mode[0], overlap=not args.no_overlap)
 
-    def timed(r, steps, warmup):
-        for _ in range(warmup):
-            step(r)
+    def timed(r, steps, warmup, k0=0):
+        for k in range(warmup):
+            step(r, k0 + k)
         torch.cuda.synchronize()
         r.ctx.stage_stats(reset=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step(r)
+        for k in range(steps):
+            step(r, k0 + warmup + k)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -266,8 +288,8 @@ def main():
     # kernel's pair (gs_config.profile_stages = 2 + stage).
     from gaussiansplat_amd.backend import STAGES
     ra = make(args.t_min, 1)
-    ka = max(2, min(args.steps, 5))
-    timed(ra, ka, max(1, args.warmup))
+    ka = max(2 * len(batches), min(args.steps, 6))
+    timed(ra, ka, max(len(batches), min(args.warmup, 4)))
     survey = ra.ctx.stage_stats()
     stage_ms = {k: (s / c if c else 0.0) for k, (s, c) in survey.items()}
     dom = max(stage_ms, key=stage_ms.get)
@@ -285,17 +307,18 @@ def main():
     dt = timed(r, args.steps, args.warmup)
     dom_sum, dom_cnt = r.ctx.stage_stats()[dom]
     dom_ms = dom_sum / dom_cnt if dom_cnt else 0.0
-    I = r.ctx.num_instances
+    I = r.ctx.num_instances                                  # of the last view rendered
+    I1 = r.ctx.num_coarse_instances
     wc = r.ctx.work_counters_ex()
     wf, wb = wc["walked_fwd"], wc["walked_bwd"]
-    value = world * n * args.steps / dt / 1e6
+    value = views_per_step * n * args.steps / dt / 1e6
     nranks = dist.get_world_size() if world > 1 else 1
     other = None
     if world > 1:                                              # the other exchange, same renderer, same K steps, beside the headline
         head = sync_mode[0]
         sync_mode[0] = "factored" if head == "allreduce" else "allreduce"
         dt_o = timed(r, args.steps, max(2, args.warmup // 2))
-        other = {"grad_sync": sync_mode[0], "value": world * n * args.steps / dt_o / 1e6, "unit": "Msplats/s",
+        other = {"grad_sync": sync_mode[0], "value": views_per_step * n * args.steps / dt_o / 1e6, "unit": "Msplats/s",
                  "ms_per_step": dt_o / args.steps * 1e3, "steps": args.steps,
                  "note": "same gradients (tests/test_distributed_gloo.py, tests/test_gpu_api.py); factored = all-reduce of the 11N geometry "
                          "floats + all-gather of 3N colour-gradient floats per view, rebuilt into the SH gradient locally"}
@@ -305,74 +328,129 @@ def main():
     out = None
     if rank == 0:
         P, Tn, K = W * H, gx * gy, (deg + 1) ** 2
-        by = algorithmic_bytes(dom, n, I, wf, wb, P, Tn, K)
+        early = args.t_min > 0
+        pmc, pmc_src = _pmc_summary(args.config) if (abs(args.t_min - 1e-5) < 1e-12 or args.t_min == 0.0) else (None, None)
+        by = algorithmic_bytes(dom, n, I, I1, wf, wb, P, Tn, K)
         ach = by / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        dom_pmc = _pmc_entry(pmc, dom, early)
+        dom_valu = valu_view(dom_pmc, dom_ms, pmc_src)
+        # a kernel is called VALU-bound only on counter evidence of THIS build: its share of the VALU issue peak above its share of HBM peak
+        bound = "valu" if dom_valu and dom_valu["valu_issue_frac"] > ach / HBM_PEAK_GBS else "hbm"
+        stages = {}
+        for st, ms in stage_ms.items():
+            if ms <= 0:
+                continue
+            b = algorithmic_bytes(st, n, I, I1, wf, wb, P, Tn, K)
+            e = {"algorithmic_bytes": b, "ms": round(ms, 5), "achieved_GBs": round(b / (ms * 1e-3) / 1e9, 1), "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            v = valu_view(_pmc_entry(pmc, st, early), ms, pmc_src)
+            if v:
+                e["valu_issue_frac"] = round(v["valu_issue_frac"], 4)
+                e["mean_waves_per_simd"] = v["mean_waves_per_simd"]
+                e["bound"] = "valu" if v["valu_issue_frac"] > e["frac"] else "hbm"
+            stages[st] = e
+        single = views_per_step == 1
+        if single:
+            what = (f"{args.config}: {n} gaussians, {W}x{H}, SH{deg}, ONE camera view per step, fwd+bwd; the steps cycle over the cameras "
+                    f"{[b[0] for b in batches]} (view k: eye rotated about +y by 45k degrees; one view slot per camera)")
+        else:
+            what = (f"{args.config}: {n} gaussians, {W}x{H}, SH{deg}, a batch of {views_per_step} camera views per step (view k: eye rotated about +y "
+                    f"by 45k degrees), fwd+bwd per view with the gradients accumulating; {views_per_step // world} view(s) per GPU"
+                    + ((", then all-reduce of 11N f32 + all-gather of 3N f32 per view (colour-factored) over RCCL" if factored
+                        else ", then the sum of the flat 59N-f32 gradient buffer over RCCL ("
+                             + ("ONE all-reduce" if args.no_overlap else "reduced as its two segments: Δshs starts behind the last SH kernel, beside the geometry chain")
+                             + ")") if world > 1 else ", no collective (one GPU)"))
         out = {
-            "metric": "fwd+bwd Msplats/sec at 1M Gaussians, 1920x1080, SH deg 3" if args.config == "C3" else f"fwd+bwd Msplats/sec ({args.config})",
+            "metric": "fwd+bwd Msplats/sec at 1M Gaussians, 1920x1080, SH deg 3" if args.config in ("C3", "C4") else f"fwd+bwd Msplats/sec ({args.config})",
             "value": value, "unit": "Msplats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n} gaussians, {W}x{H}, SH{deg}, one camera view per GPU per step, fwd+bwd"
-                                   + ((", RCCL all-reduce of 11N f32 + all-gather of 3N f32 per view (colour-factored)" if factored
-                                       else ", one RCCL all-reduce of 59N f32") if world > 1 else "")
-                                   + "; synthetic scene of SURVEY 8d with the quaternions NORMALISED (8d leaves N(0,1)^4 raw: the reference "
-                                     "never normalises q and |q| scales every footprint by |q|^4; un-normalised q is parity-tested, "
-                                     "tests/test_gpu_sizes.py)",
-                       "nranks": nranks, "grad_sync": args.grad_sync if world > 1 else None, "backend": args.backend if world > 1 else None,
-                       "rank_mode": int(r.ctx.cfg.rank_mode), "binning_rounds": r.ctx.num_rounds, "schedule": args.schedule,
+            "config": {"workload": what + "; synthetic scene of SURVEY 8d with the quaternions NORMALISED (8d leaves N(0,1)^4 raw: the reference "
+                                          "never normalises q and |q| scales every footprint by |q|^4; un-normalised q is parity-tested, "
+                                          "tests/test_gpu_sizes.py)",
+                       "views_per_step": views_per_step, "views_per_rank": views_per_step // world, "nranks": nranks,
+                       "ms_per_view": dt / args.steps * 1e3 / (views_per_step // world),
+                       "grad_sync": args.grad_sync if world > 1 else None, "allreduce_overlap": (not args.no_overlap) if world > 1 else None,
+                       "backend": args.backend if world > 1 else None,
+                       "rank_mode": int(r.ctx.cfg.rank_mode), "binning_rounds": r.ctx.num_rounds, "schedule": int(r.ctx.cfg.schedule) or 3,
+                       "view_slots": not args.no_view_slots,
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
-                       "instances": I, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
-                       "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "seed": seed},
+                       "instances": I, "coarse_instances": I1, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
+                       "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "counters_of": "the last view rendered",
+                       "seed": seed},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stage_ms_note": f"survey pass ({ka} steps, hipEvents around every stage, not the timed region)",
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": by, "avg_ms": dom_ms, "launches": dom_cnt, "valu": None,
-                         "csrc_sha": csrc_sha(),
-                         "note": "avg_ms: hipEvents around the kernel launch on the ctx stream, inside the timed region.  traffic (HBM "
-                                 "bytes per launch, FETCH_SIZE x2 + WRITE_SIZE) and valu (SQ_INSTS_VALU against the issue peak of 1024 "
-                                 "SIMDs x 1 wave64 instruction per 2 cycles) come from the rocprofv3 --pmc summary under profiles/ "
-                                 "stamped with this csrc_sha, else null.  The composite kernels are VALU-bound (DESIGN.md s5); the HBM "
-                                 "fraction is reported as measured"},
+            "stage_ms_note": f"survey pass ({ka} steps, hipEvents around every stage, averaged over the views rendered; not the timed region)",
+            "roofline": {"kernel": dom, "bound": bound, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": dom_pmc.get("hbm_bytes_total") if dom_pmc else None, "algorithmic_bytes": by, "avg_ms": dom_ms, "launches": dom_cnt,
+                         "valu": dom_valu, "csrc_sha": csrc_sha(), "stages": stages,
+                         "note": "achieved / frac: algorithmic HBM bytes over the kernel time, against the 8 TB/s spec peak, as BASELINE.json "
+                                 "asks -- for every stage under `stages`.  avg_ms: hipEvents around the kernel launch on the ctx stream, inside "
+                                 "the timed region.  traffic (HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE), valu and `bound` come from "
+                                 "the rocprofv3 --pmc summary under profiles/ stamped with this csrc_sha (else null / 'hbm'): bound = 'valu' when "
+                                 "the kernel's share of the VALU issue peak (1024 SIMDs x 1 wave64 instruction per 2 cycles) exceeds its share of "
+                                 "the HBM peak (DESIGN.md s5)"},
         }
-        out["roofline"]["traffic"], out["roofline"]["valu"] = measured_counters(dom, args.config, args.t_min, dom_ms)
         out["roofline"]["loop_cost"] = loop_cost_model(dom, dom_ms, wc["evaluated_bwd"] if dom == "composite_bwd" else wc["evaluated_fwd"])
         if other:
             out["factored_exchange" if other["grad_sync"] == "factored" else "allreduce_exchange"] = other
-    if not args.no_literal and args.t_min > 0 and world == 1:      # extra measurements only at N = 1
+    extras = world == 1 and views_per_step == 1
+    if extras and not args.no_c4_anchor and args.config == "C3":
+        # the N = 1 anchor of the C4 scaling curve, in the same run: the 8-view batch on one GPU, gradients accumulating
+        v8 = list(range(8))
+        cams8 = [camera_of(v) for v in v8]
+        dC8 = [torch.as_tensor(synthetic.make_dC(W, H, seed + v)).cuda() for v in v8]
+        hv = D.HipViewRenderer(r)
+        for _ in range(2):
+            D.multi_view_step(hv, cams8, dC8)
+        torch.cuda.synchronize()
+        k8 = max(2, min(args.steps // 4, 10))
+        t0 = time.perf_counter()
+        for _ in range(k8):
+            D.multi_view_step(hv, cams8, dC8)
+        torch.cuda.synchronize()
+        d8 = time.perf_counter() - t0
+        out["c4_batch"] = {"value": 8 * n * k8 / d8 / 1e6, "unit": "Msplats/s", "ms_per_step": d8 / k8 * 1e3, "ms_per_view": d8 / k8 / 8 * 1e3,
+                           "views_per_step": 8, "n_gpus": 1, "steps": k8,
+                           "what": "config C4 on ONE GPU: the eight views of the 8-GPU batch one after the other, gradients accumulating, no collective "
+                                   "(= `bench.py --config C4 --gpus 1`): the N = 1 point of the strong-scaling curve `--gpus 2/4/8` continues"}
+        del hv
+    if not args.no_literal and args.t_min > 0 and extras:          # extra measurements only at N = 1
         del r
+        gc.collect()
         torch.cuda.empty_cache()
         r0 = make(0.0, 1)
-        k0 = max(2, min(args.steps, 5))
-        dt0 = timed(r0, k0, 1)
+        k0 = max(2, min(args.steps, 4))
+        dt0 = timed(r0, k0, 2)
         st0 = r0.ctx.stage_stats()
         if rank == 0:
-            out["literal_t_min_0"] = {"value": world * n * k0 / dt0 / 1e6, "unit": "Msplats/s", "ms_per_step": dt0 / k0 * 1e3, "steps": k0,
+            out["literal_t_min_0"] = {"value": n * k0 / dt0 / 1e6, "unit": "Msplats/s", "ms_per_step": dt0 / k0 * 1e3, "steps": k0,
                                       "stage_ms": {k: round(s / c if c else 0.0, 4) for k, (s, c) in st0.items()}}
         del r0
-    if not args.no_train_iteration and world == 1 and args.config in ("C1", "C2", "C3"):
+    if not args.no_train_iteration and extras and args.config in ("C1", "C2", "C3"):
         # SURVEY 8(f).2 beside the headline: one iteration of src/train.jl as intended = the fwd+bwd step + the L1/DSSIM loss
         # with its image gradient (gs_loss.hip) + the SGD update; reported, never `value`
         from gaussiansplat_amd import train as TR
+        gc.collect()
         torch.cuda.empty_cache()
         rt = make(args.t_min, 0)
         gt = torch.rand((3, H, W), device="cuda")
         lf = TR.getLossFunction((W, H, 3), 11, 3, renderer=rt)
+        cam0 = cams[batches[0][0]]
         for _ in range(3):
-            TR.trainStep(rt, gt, 1e-4, lf, cam, want_loss=False)
+            TR.trainStep(rt, gt, 1e-4, lf, cam0, want_loss=False)
         torch.cuda.synchronize()
         kt = max(2, min(args.steps, 20))
         t0 = time.perf_counter()
         for _ in range(kt):
-            TR.trainStep(rt, gt, 1e-4, lf, cam, want_loss=False)
+            TR.trainStep(rt, gt, 1e-4, lf, cam0, want_loss=False)
         torch.cuda.synchronize()
         out["train_iteration"] = {"ms": (time.perf_counter() - t0) / kt * 1e3, "iterations": kt,
                                   "what": "preprocess, lists, forward, L1+DSSIM loss and image gradient, backward, SGD step (train.jl:33-56)"}
         for _ in range(2):
-            TR.trainStep(rt, gt, 1e-4, lf, cam, want_loss=False, fused_sgd=True)
+            TR.trainStep(rt, gt, 1e-4, lf, cam0, want_loss=False, fused_sgd=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(kt):
-            TR.trainStep(rt, gt, 1e-4, lf, cam, want_loss=False, fused_sgd=True)
+            TR.trainStep(rt, gt, 1e-4, lf, cam0, want_loss=False, fused_sgd=True)
         torch.cuda.synchronize()
         out["train_iteration"]["ms_with_fused_backward_sgd"] = (time.perf_counter() - t0) / kt * 1e3
         del rt

@@ -28,14 +28,19 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
-           "gs_debug_tile_clock", "gs_rank_probe_result", "gs_num_rounds")
+           "gs_debug_tile_clock", "gs_rank_probe_result", "gs_num_rounds", "gs_set_view_slot", "gs_num_coarse_instances")
+
+GS_ABI_VERSION = 2          # include/gsplat.h; load() refuses a library that reports another version
+GS_DEBUG_WIDE_CURSORS = 1
+GS_MAX_VIEW_SLOTS = 64
 
 
 class GsConfig(C.Structure):
-    _fields_ = [("struct_size", C.c_int32), ("tile_size", C.c_int32), ("order", C.c_int32), ("t_min", C.c_float),
+    _fields_ = [("struct_size", C.c_int32), ("abi_version", C.c_int32), ("tile_size", C.c_int32), ("order", C.c_int32), ("t_min", C.c_float),
                 ("deterministic", C.c_int32), ("export_debug", C.c_int32), ("profile_stages", C.c_int32),
                 ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("alpha_cull", C.c_int32), ("schedule", C.c_int32),
-                ("slab_mode", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("slab_mode", C.c_int32), ("slab_max_ratio", C.c_float), ("slab_fractions", C.c_float * 3), ("debug_flags", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class GsGrads(C.Structure):
@@ -109,6 +114,11 @@ def load():
     L.gs_debug_tile_clock.argtypes = [vp, C.c_int, C.c_int, vp]
     L.gs_rank_probe_result.argtypes = [vp]
     L.gs_num_rounds.argtypes = [vp]
+    L.gs_set_view_slot.argtypes = [vp, C.c_int32]
+    L.gs_num_coarse_instances.argtypes = [vp]; L.gs_num_coarse_instances.restype = C.c_int64
+    if L.gs_abi_version() != GS_ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {L.gs_abi_version()}, this binding is written for {GS_ABI_VERSION}: "
+                           "rebuild with `python -m gaussiansplat_amd.build --force`")
     _lib = L
     return L
 
@@ -124,11 +134,18 @@ class Context:
 
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
                  profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 1,
-                 alpha_cull: bool = True, schedule: int = 3, slab_mode: int = 1):
+                 alpha_cull: bool = True, schedule: int = 0, slab_mode: int = 1, slab_fractions=(), slab_max_ratio: float = 0.0,
+                 debug_flags: int = 0):
+        """schedule 0 = the library default (3); slab_fractions / slab_max_ratio / debug_flags: gs_config fields for tests."""
         self.L = load()
         cfg = default_config()
+        assert cfg.struct_size == C.sizeof(GsConfig) and cfg.abi_version == GS_ABI_VERSION
         cfg.schedule = int(schedule)
         cfg.slab_mode = int(slab_mode)
+        cfg.slab_max_ratio = float(slab_max_ratio)
+        for i, f in enumerate(tuple(slab_fractions)[:3]):
+            cfg.slab_fractions[i] = float(f)
+        cfg.debug_flags = int(debug_flags)
         cfg.order, cfg.t_min = int(order), float(t_min)
         cfg.export_debug, cfg.profile_stages, cfg.deterministic = int(export_debug), int(profile_stages), int(deterministic)
         cfg.bin_path, cfg.rank_mode, cfg.alpha_cull = int(bin_path), int(rank_mode), int(alpha_cull)
@@ -191,6 +208,10 @@ class Context:
                                        a[2].ctypes.data_as(fp), a[3].ctypes.data_as(fp), int(W), int(H)))
         self.W, self.H = int(W), int(H)
 
+    def set_view_slot(self, slot: int):
+        """gs_set_view_slot: name the view about to be rendered (e.g. the camera's id); -1 = none."""
+        self._chk(self.L.gs_set_view_slot(self.h, int(slot)))
+
     # -- pipeline
     def preprocess(self):
         self._chk(self.L.gs_preprocess(self.h))
@@ -213,8 +234,9 @@ class Context:
         self._chk(self.L.gs_forward(self.h, C.c_void_p(image_ptr), C.c_void_p(trans_ptr), GS_MEM_DEVICE))
 
     def backward(self, dC_ptr_or_array, grads: GsGrads, overwrite: bool = False, phase: str = "all"):
-        """phase: "all", "composite" (GS_BWD_COMPOSITE_ONLY) or "params" (GS_BWD_PARAMS_ONLY)."""
-        flags = (1 if overwrite else 0) | {"all": 0, "composite": 2, "params": 4}[phase]          # GS_BWD_*
+        """phase: "all", "composite" (GS_BWD_COMPOSITE_ONLY), "params" (GS_BWD_PARAMS_ONLY), or the chain in two steps:
+        "params_sh" (GS_BWD_PARAMS_ONLY | GS_BWD_PARAMS_SH) then "params_geom" (GS_BWD_PARAMS_ONLY | GS_BWD_PARAMS_GEOM)."""
+        flags = (1 if overwrite else 0) | {"all": 0, "composite": 2, "params": 4, "params_sh": 4 | 8, "params_geom": 4 | 16}[phase]   # GS_BWD_*
         if isinstance(dC_ptr_or_array, np.ndarray):
             a = np.ascontiguousarray(dC_ptr_or_array, np.float32)
             self._chk(self.L.gs_backward_ex(self.h, C.c_void_p(a.ctypes.data), GS_MEM_HOST, C.byref(grads), flags))
@@ -304,6 +326,11 @@ class Context:
     @property
     def num_instances(self) -> int:
         return int(self.L.gs_num_instances(self.h))
+
+    @property
+    def num_coarse_instances(self) -> int:
+        """two-level binning: (super-tile, gaussian) instances of the last bin()"""
+        return int(self.L.gs_num_coarse_instances(self.h))
 
     @property
     def num_rounds(self) -> int:

@@ -1,6 +1,11 @@
 """Build libgsplat_hip.so in-tree with hipcc for gfx950 (no CMake, no JIT cache).
 
-    python -m gaussiansplat_amd.build [--force]
+    python -m gaussiansplat_amd.build [--force] [--experiments]
+
+--experiments builds lib_exp/libgsplat_hip.so with -DGS_EXPERIMENTS: the kernel variants and schedules that lost their A/B
+(persistent ticket queues, the round-1 reduction tree, the software-pipelined backward, the 64-VGPR forward) and the
+environment switches of tools/abtest.py; load it with GSPLAT_HIP_LIB=.../lib_exp/libgsplat_hip.so.  The default library
+contains none of them.
 
 The preprocess translation unit is compiled with -ffp-contract=off (numeric spec: tile ids
 and depth keys must be bit-identical to the CPU oracle); the composite kernels keep hipcc's
@@ -46,14 +51,18 @@ def _deps() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OUT_DIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
+    out_dir = os.path.join(HERE, "lib_exp") if experiments else OUT_DIR
+    lib = os.path.join(out_dir, "libgsplat_hip.so")
+    os.makedirs(out_dir, exist_ok=True)
     hipcc = _hipcc()
     hdr_time = _deps()
     objs, jobs = [], []
     for src, extra in SOURCES.items():
+        if experiments:
+            extra = [*extra, "-DGS_EXPERIMENTS"]
         s = os.path.join(CSRC, src)
-        o = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(out_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
             jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
@@ -69,10 +78,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or not os.path.exists(LIB):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-ldl"])
-    return LIB
+    if jobs or force or not os.path.exists(lib):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs, "-ldl"])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

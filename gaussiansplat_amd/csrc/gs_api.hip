@@ -104,9 +104,25 @@ struct gs_ctx {
     int64_t ev_cnt[GS_STAGE_COUNT] = {};
     DevBuf counters;                         // 128 B: 4 x u64 entries walked, evaluated by the forward; walked, evaluated by the backward;
                                              // then 8 u32 per-XCD ticket counters of the forward (byte 32) and 8 of the backward (byte 64)
-    DevBuf tile_order_f, tile_order_b, tile_order_p, tile_work, tile_clock;   // longest-first tile orders (+ 9 segment bounds each), per-tile work, debug clocks
-    int waves_fwd = 0, waves_bwd = 0;        // resident waves of the persistent composite grids (occupancy x CUs)
-    int64_t tile_work_valid_tiles = 0;       // tile_work holds a forward's per-tile counts for a grid of this many tiles
+    DevBuf tile_order_f, tile_order_b, tile_order_p, tile_work, tile_clock;   // experiments: queue orders (+ 9 segment bounds each); per-tile work, debug clocks
+    int waves_fwd = 0, waves_bwd = 0;        // experiments: resident waves of the persistent composite grids (occupancy x CUs)
+    // ---- longest-first launch orders (gs_config.schedule 3 / 4).  After every forward ONE order kernel turns the frame's per-tile
+    // work into a launch order: this frame's backward uses it, and so does the NEXT forward rendered under the same view slot.
+    int view_slot = -1;                      // gs_set_view_slot: the slot of the frame being rendered (-1: none)
+    DevBuf slot_order[GS_MAX_VIEW_SLOTS];    // per slot: the order built after the slot's last forward
+    int64_t slot_tiles[GS_MAX_VIEW_SLOTS] = {};   // ... valid for a grid of this many tiles (0: no history)
+    DevBuf order_frame;                      // the order of a frame without a slot (schedule 4: also the next such forward's order)
+    int64_t order_frame_tiles = 0;
+    const uint32_t *frame_order = nullptr;   // the order built after THIS frame's forward (null: none, e.g. grid too large)
+    bool bwd_counters_zeroed = false;        // the order kernel zeroed the backward's work counters on its way
+    int lpt_buckets = 0;                     // experiments: work classes of the order kernel (0: default)
+    // ---- speculative binning: the lists are enqueued with the capacities of the buffers at hand while the frame's totals travel
+    bool pending_totals = false;             // ev_count recorded, pinned totals not read yet
+    bool spec_lists = false;                 // the lists of this frame were enqueued before the totals were known ...
+    size_t spec_cap_coarse = 0, spec_cap_fine = 0;   // ... against these capacities (entries)
+    int64_t n_coarse = 0;
+    DevBuf tile_dead;                        // slab frames: 4 lane masks per tile (frozen pixels between rounds)
+    int exp_bin_path = -1;                   // experiments: GS_BIN_PATH read once at gs_create
     int rank_probe = -1;                     // lane-order probe of the LDS atomic rank: -1 not run, 0 passed, 1 failed (ballots forced)
     // ---- binning in depth slabs (gs_config.slab_mode)
     int n_rounds = 1;                        // binning rounds of the current frame
@@ -132,6 +148,7 @@ struct gs_ctx {
     int64_t prev_n_inst = 0;
     bool prev_counters_valid = false;        // `counters` holds the walked count of a completed forward
     int64_t frame_id = 0, ev_frame[GS_STAGE_COUNT] = {};   // a stage may run once per binning round: ev_cnt counts frames, not launches
+    int64_t ev_counted[GS_STAGE_COUNT] = {};               // last frame whose pair of this stage was added to ev_cnt
     DevBuf grads_flat;                       // gs_grads_alloc
     DevBuf dpc;                              // 4 x n scratch between the two backward kernels
     DevBuf loss_maps, loss_acc, loss_in[2], loss_dc, view_cams;
@@ -155,11 +172,25 @@ int hipfail(gs_ctx *c, hipError_t e, const char *what) {
         if (e__ != hipSuccess) return hipfail((c), e__, #call);      \
     } while (0)
 
+// One recorded pair of a stage -> the accumulators; false when the pair has not completed yet (it stays `fresh`).
+bool harvest_stage(gs_ctx *c, int s) {
+    if (!c->ev_fresh[s]) return true;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) != hipSuccess) { (void)hipGetLastError(); return false; }
+    c->ev_sum[s] += ms;
+    if (c->ev_counted[s] != c->ev_frame[s]) { c->ev_counted[s] = c->ev_frame[s]; c->ev_cnt[s] += 1; }      // one count per frame
+    c->ev_fresh[s] = false;
+    return true;
+}
 struct StageTimer {
     gs_ctx *c; int st; bool on;
     StageTimer(gs_ctx *c_, int st_) : c(c_), st(st_), on(c_->cfg.profile_stages == 1 || c_->cfg.profile_stages == 2 + st_) {
         if (on) {
-            if (c->ev_frame[st] != c->frame_id) { c->ev_frame[st] = c->frame_id; c->ev_cnt[st] += 1; }      // one count per frame
+            if (c->ev_fresh[st] && !harvest_stage(c, st)) {            // about to re-record a pair nobody has read: wait for it (rare:
+                (void)hipEventSynchronize(c->ev[st][1]);               // the host ran a whole frame ahead of the GPU)
+                (void)harvest_stage(c, st);
+            }
+            c->ev_frame[st] = c->frame_id;
             (void)hipEventRecord(c->ev[st][0], c->stream);
         }
     }
@@ -168,15 +199,11 @@ struct StageTimer {
     }
 };
 
-// After a stream synchronise every recorded pair is complete: fold it into the accumulators.
+// Fold every pair that has completed into the accumulators (pairs still in flight stay fresh for the next call).
 void harvest_events(gs_ctx *c, int skip_stage = -1) {
     if (!c->cfg.profile_stages) return;
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
-        if (c->ev_fresh[s] && s != skip_stage) {
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) c->ev_sum[s] += ms;
-            c->ev_fresh[s] = false;
-        }
+        if (s != skip_stage) (void)harvest_stage(c, s);
 }
 
 int bind_device(gs_ctx *c) {
@@ -184,32 +211,40 @@ int bind_device(gs_ctx *c) {
     return GS_OK;
 }
 
-// Scheduling of a composite launch (gs_config.schedule): the ticket counter inside c->counters (zeroed by the caller's
-// memset of that buffer), the resident-wave grid and, for schedule 0, the longest-first tile order -- for the forward by
-// list length, for the backward by the forward's per-tile count of evaluated entries (its exact work).
-int composite_sched(gs_ctx *c, GsCompositeArgs &a, int which, bool *zeroed_bwd_counters = nullptr) {
+bool lpt_schedule(const gs_ctx *c) { return c->cfg.schedule == 3 || c->cfg.schedule == 4; }
+
+// Launch order of the forward about to be enqueued (gs_config.schedule 3 / 4): what the last forward under the same view slot
+// measured, else (schedule 4) what this ctx's previous forward measured; null = tile order.
+const uint32_t *forward_order(gs_ctx *c) {
+    const int64_t ntiles = (int64_t)c->gx * c->gy;
+    if (!lpt_schedule(c) || ntiles <= 0 || ntiles > GS_LPT_MAX_TILES) return nullptr;
+    if (c->view_slot >= 0 && c->slot_tiles[c->view_slot] == ntiles) return c->slot_order[c->view_slot].as<uint32_t>();
+    if (c->cfg.schedule == 4 && c->order_frame_tiles == ntiles) return c->order_frame.as<uint32_t>();
+    return nullptr;
+}
+
+// After the frame's (last) forward: ONE order kernel turns its per-tile work into the launch order of this frame's backward and
+// of the next forward under the same slot; on its way it zeroes the backward's work counters.
+int build_frame_order(gs_ctx *c) {
+    const int64_t ntiles = (int64_t)c->gx * c->gy;
+    c->frame_order = nullptr; c->bwd_counters_zeroed = false;
+    if (!lpt_schedule(c) || ntiles <= 0 || ntiles > GS_LPT_MAX_TILES) return GS_OK;
+    DevBuf &ob = c->view_slot >= 0 ? c->slot_order[c->view_slot] : c->order_frame;
+    HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
+    HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, (int)ntiles, ob.as<uint32_t>(), c->stream,
+                                       c->counters.as<unsigned long long>() + 2, c->lpt_buckets));
+    if (c->view_slot >= 0) c->slot_tiles[c->view_slot] = ntiles; else c->order_frame_tiles = ntiles;
+    c->frame_order = ob.as<uint32_t>();
+    c->bwd_counters_zeroed = true;
+    return GS_OK;
+}
+
+#ifdef GS_EXPERIMENTS
+// schedule 10 / 12: persistent waves pull tiles from per-XCD ticket counters inside c->counters (zeroed by the caller),
+// heaviest first (10: the forward by list length, the backward by the forward's per-tile work) or in tile order (12)
+int composite_sched_queue(gs_ctx *c, GsCompositeArgs &a, int which) {
     const int ntiles = c->gx * c->gy;
-    HIPCHK(c, c->tile_work.ensure(sizeof(uint32_t) * (size_t)(ntiles ? ntiles : 1)));
-    if (which == 0) a.tile_work = c->tile_work.as<uint32_t>();
-    if (c->cfg.schedule == 3 || c->cfg.schedule == 4) {                      // plain launch; the backward's tiles heaviest first (by the forward's count)
-        if (ntiles > 35000) return GS_OK;                                    // beyond the order kernel's LDS (8K-class images): launch order
-        if (which == 0 && c->cfg.schedule == 4 && c->tile_work_valid_tiles == ntiles && ntiles > 0) {
-            // opt-in: the forward's tiles by the work the PREVIOUS forward of this ctx measured on the same tile grid (pays when
-            // consecutive frames see similar views; with an unrelated view it degrades to an arbitrary order, which costs nothing)
-            HIPCHK(c, c->tile_order_f.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
-            HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, ntiles, c->tile_order_f.as<uint32_t>(), c->stream));
-            a.tile_order = c->tile_order_f.as<uint32_t>();
-        }
-        if (which == 1 && ntiles > 0) {
-            HIPCHK(c, c->tile_order_b.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
-            HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, ntiles, c->tile_order_b.as<uint32_t>(), c->stream,
-                                               zeroed_bwd_counters ? a.walked : nullptr));
-            if (zeroed_bwd_counters) *zeroed_bwd_counters = true;
-            a.tile_order = c->tile_order_b.as<uint32_t>();
-        }
-        return GS_OK;
-    }
-    if (c->cfg.schedule == 1 || ntiles <= 0) return GS_OK;                  // one wave per tile, launch order
+    if (ntiles <= 0) return GS_OK;
     int &waves = which == 0 ? c->waves_fwd : c->waves_bwd;
     if (waves == 0) {
         waves = gs_composite_resident_waves(which, c->cfg.t_min > 0.0f, c->cfg.deterministic != 0, c->cfg.alpha_cull != 0);
@@ -217,15 +252,15 @@ int composite_sched(gs_ctx *c, GsCompositeArgs &a, int which, bool *zeroed_bwd_c
     }
     a.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(c->counters.p) + (which == 0 ? 32 : 64));
     a.grid_waves = waves;
-    // order buffers: ntiles tile ids followed by the 9 segment bounds
-    DevBuf &ord = which == 0 ? c->tile_order_f : c->tile_order_b;
+    DevBuf &ord = which == 0 ? c->tile_order_f : c->tile_order_b;            // ntiles tile ids followed by the 9 segment bounds
     HIPCHK(c, ord.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
-    const uint32_t *src = c->cfg.schedule == 2 ? nullptr : which == 0 ? c->ranges.as<uint32_t>() : c->tile_work.as<uint32_t>();
+    const uint32_t *src = c->cfg.schedule == 12 ? nullptr : which == 0 ? c->ranges.as<uint32_t>() : c->tile_work.as<uint32_t>();
     HIPCHK(c, gs_launch_tile_order(src, which == 0 ? 1 : 0, ntiles, ord.as<uint32_t>(), ord.as<uint32_t>() + ntiles, c->stream));
     a.tile_order = ord.as<uint32_t>();
     a.queue_seg = ord.as<uint32_t>() + ntiles;
     return GS_OK;
 }
+#endif
 
 }  // namespace
 
@@ -235,6 +270,7 @@ void gs_default_config(gs_config *cfg) {
     if (!cfg) return;
     std::memset(cfg, 0, sizeof(*cfg));
     cfg->struct_size = (int32_t)sizeof(gs_config);
+    cfg->abi_version = GS_ABI_VERSION;
     cfg->tile_size = GS_TILE;
     cfg->order = GS_ORDER_DEPTH_DESC;
     cfg->t_min = 1e-5f;
@@ -257,14 +293,25 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     gs_config c0;
     gs_default_config(&c0);
     if (cfg) {
-        if (cfg->struct_size != (int32_t)sizeof(gs_config)) return fail(nullptr, GS_ERR_INVALID, "gs_create: gs_config.struct_size mismatch");
+        if (cfg->struct_size != (int32_t)sizeof(gs_config) || cfg->abi_version != GS_ABI_VERSION)
+            return fail(nullptr, GS_ERR_INVALID, "gs_create: gs_config.struct_size / abi_version mismatch (caller built against another gsplat.h)");
         c0 = *cfg;
     }
+    if (c0.schedule == 0) c0.schedule = 3;                               // 0 = the library default
     if (c0.tile_size != GS_TILE) return fail(nullptr, GS_ERR_UNSUPPORTED, "gs_create: only tile_size 16 is supported (reference threads=(16,16))");
     if (c0.order < GS_ORDER_INDEX || c0.order > GS_ORDER_DEPTH_ASC) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad order");
     if (!(c0.t_min >= 0.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: t_min must be >= 0");
-    if (c0.schedule < 0 || c0.schedule > 4) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad schedule");
+#ifdef GS_EXPERIMENTS
+    if (c0.schedule != 1 && c0.schedule != 3 && c0.schedule != 4 && c0.schedule != 10 && c0.schedule != 12) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad schedule");
+#else
+    if (c0.schedule != 1 && c0.schedule != 3 && c0.schedule != 4) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad schedule (0, 1, 3 or 4)");
+#endif
     if (c0.slab_mode < 0 || c0.slab_mode > 1) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad slab_mode");
+    if (c0.bin_path < 0 || c0.bin_path > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad bin_path");
+    if (!(c0.slab_max_ratio >= 0.0f && c0.slab_max_ratio <= 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_max_ratio must be in [0, 1]");
+    for (int i = 0; i < 3; ++i)
+        if (!(c0.slab_fractions[i] >= 0.0f && c0.slab_fractions[i] < 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_fractions must be in [0, 1)");
+    if (c0.debug_flags & ~GS_DEBUG_WIDE_CURSORS) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown debug_flags");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -274,9 +321,14 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (!c) return fail(nullptr, GS_ERR_OOM, "gs_create: host allocation failed");
     c->device = device;
     c->cfg = c0;
-    // kernel-variant override for A/B runs and for running the parity tests against a non-default variant
+#ifdef GS_EXPERIMENTS
+    // experiment switches, read ONCE here (never on the per-frame path): kernel-variant overrides for A/B runs, the binning
+    // path, the work classes of the tile order kernel
     if (const char *e = std::getenv("GS_VARIANT_FWD")) c->variant_fwd = std::atoi(e);
     if (const char *e = std::getenv("GS_VARIANT_BWD")) c->variant_bwd = std::atoi(e);
+    if (const char *e = std::getenv("GS_BIN_PATH")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) c->exp_bin_path = v; }
+    if (const char *e = std::getenv("GS_LPT_BUCKETS")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) c->lpt_buckets = v; }
+#endif
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipSetDevice"); }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipStreamCreate"); }
     c->own_stream = true;
@@ -309,8 +361,9 @@ int gs_destroy(gs_ctx *c) {
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
                       &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->tilecnt,
                       &c->ranges_r[0], &c->ranges_r[1], &c->ranges_r[2], &c->ranges_r[3],
-                      &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams};
+                      &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams, &c->order_frame, &c->tile_dead};
     for (DevBuf *b : bufs) b->release();
+    for (auto &b : c->slot_order) b.release();
     for (auto &b : c->model) b.release();
     for (auto &b : c->dbg) b.release();
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
@@ -429,10 +482,12 @@ int gs_set_camera(gs_ctx *c, const float T[16], const float P[16], float fx, flo
     return GS_OK;
 }
 
+static int settle_totals(gs_ctx *c, bool *redo, bool may_relist);
 int gs_preprocess(gs_ctx *c) {
     if (!c) return GS_ERR_INVALID;
     if (!c->have_cam) return fail(c, GS_ERR_INVALID, "gs_preprocess: gs_set_camera first");
     if (bind_device(c)) return GS_ERR_HIP;
+    if (int rc = settle_totals(c, nullptr, false)) return rc;               // totals of a frame that was binned but never rendered
     c->frame_id += 1;
     const size_t n = (size_t)c->n, n1 = n ? n : 1;
     HIPCHK(c, c->payload.ensure(sizeof(GsPayload) * n1));
@@ -497,20 +552,16 @@ int gs_preprocess(gs_ctx *c) {
 // three forward launches with their tails and three level-1 passes cost more than the 0.4 ms of list writes they save), so
 // the automatic mode now engages only below a share of 0.03 (GS_SLAB_MAX_RATIO overrides; the tests use 0.15).
 #define GS_SLAB_MAX_RATIO 0.03
-static double slab_max_ratio() {
-    if (const char *e = std::getenv("GS_SLAB_MAX_RATIO")) { const double v = std::atof(e); if (v > 0.0 && v <= 1.0) return v; }
-    return GS_SLAB_MAX_RATIO;
-}
+static double slab_max_ratio(const gs_ctx *c) { return c->cfg.slab_max_ratio > 0.0f ? (double)c->cfg.slab_max_ratio : GS_SLAB_MAX_RATIO; }
 static int plan_rounds(gs_ctx *c) {
     c->n_rounds = 1;
     c->slab_lo[0] = 0; c->slab_lo[1] = c->n;
     if (!c->fast_bin || c->cfg.t_min <= 0.0f || c->n < 1024 || c->order() == GS_ORDER_INDEX) return 1;
     double f[GS_MAX_ROUNDS] = {1.0, 1.0, 1.0, 1.0};
     int R = 1;
-    if (const char *e = std::getenv("GS_SLABS")) {                          // experiments: explicit fractions "f1[,f2[,f3]]", "" = classic
-        const char *p = e;
-        while (*p && R < GS_MAX_ROUNDS) { char *q = nullptr; const double v = std::strtod(p, &q); if (q == p) break; f[R - 1] = v; ++R; p = *q == ',' ? q + 1 : q; }
-    } else if (c->cfg.slab_mode == 1 && c->walked_ratio >= 0.0 && c->walked_ratio < slab_max_ratio()) {
+    if (c->cfg.slab_fractions[0] > 0.0f) {                                  // tests / experiments: explicit fractions
+        for (int k = 0; k < 3 && k + 1 < GS_MAX_ROUNDS && c->cfg.slab_fractions[k] > 0.0f; ++k) { f[k] = c->cfg.slab_fractions[k]; R = k + 2; }
+    } else if (c->cfg.slab_mode == 1 && c->walked_ratio >= 0.0 && c->walked_ratio < slab_max_ratio(c)) {
         const double rho = c->walked_ratio;
         f[0] = std::min(0.9, std::max(0.02, 2.0 * rho + 0.02));
         f[1] = std::min(0.95, std::max(f[0] + 0.05, 6.0 * rho + 0.05));
@@ -531,8 +582,10 @@ static int plan_rounds(gs_ctx *c) {
 
 // Two-level binning of one round (gs_bin3.hip).  two_level_count enqueues the level-1 histogram of the slab's gaussians
 // (after it the round's three totals are on the device: coarse instances listed, fine instances of the slab, of all n);
-// two_level_lists, once the host knows the coarse count, enqueues the super-tile lists and the tile lists.
-static GsBin3L1 two_level_args(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, const uint8_t *sdone) {
+// two_level_lists enqueues the super-tile lists and the tile lists for buffers that hold `coarse` / `fine` entries -- the
+// actual totals once the host knows them, or (speculative launch) the capacities of the buffers at hand: the kernels compare
+// the totals on the device with these numbers and list nothing when a buffer would overflow.
+static GsBin3L1 two_level_args(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, const uint8_t *sdone, size_t cap_coarse, size_t cap_fine) {
     GsBin3L1 b{};
     b.rect = c->rect.as<uint16_t>(); b.perm = perm_slab; b.sdone = sdone; b.n = n_all; b.n_slab = nr; b.sgx = c->sgx; b.ns = c->sgx * c->sgy;
     b.rect_sorted = c->rect_sorted.as<uint32_t>(); b.table = c->l1_table.as<uint32_t>(); b.row_total = c->l1_rows.as<uint32_t>();
@@ -540,6 +593,7 @@ static GsBin3L1 two_level_args(gs_ctx *c, const uint32_t *perm_slab, int64_t n_a
     b.cids = c->cids.as<uint32_t>(); b.clr = c->clr.as<uint16_t>();
     b.tilecnt = c->tilecnt.as<uint32_t>(); b.ntiles = c->gx * c->gy;
     b.zero_words = sdone ? nullptr : c->counters.as<uint32_t>();           // round 0 (no completed tiles yet): the forward's counters
+    b.cap_coarse = (uint32_t)std::min<size_t>(cap_coarse, 0xFFFFFFFEu); b.cap_fine = (uint32_t)std::min<size_t>(cap_fine, 0xFFFFFFFEu);
     return b;
 }
 static int two_level_count(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, const uint8_t *sdone) {
@@ -551,28 +605,28 @@ static int two_level_count(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, 
     HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
     HIPCHK(c, c->cranges.ensure(sizeof(uint32_t) * 2 * (size_t)ns));
     HIPCHK(c, c->tilecnt.ensure(sizeof(uint32_t) * (size_t)c->gx * c->gy));
-    HIPCHK(c, gs_bin3_l1_count(two_level_args(c, perm_slab, n_all, nr, sdone), c->stream));
+    HIPCHK(c, gs_bin3_l1_count(two_level_args(c, perm_slab, n_all, nr, sdone, 0, 0), c->stream));
     return GS_OK;
 }
-static int two_level_lists(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, int64_t coarse, uint32_t *ranges, uint32_t *ids_out,
+static int two_level_lists(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, size_t coarse, size_t fine, uint32_t *ranges, uint32_t *ids_out,
                            const uint8_t *done, const uint8_t *sdone) {
     const int ns = c->sgx * c->sgy;
-    c->coarse_listed = coarse;
-    if (coarse <= 0) {                                      // nothing listed: every tile range of the round is empty
+    if (coarse == 0) {                                      // nothing listed: every tile range of the round is empty
         HIPCHK(c, hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)c->gx * c->gy, c->stream));
         return GS_OK;
     }
-    const int64_t max_work = gs_bin3_max_work(coarse, ns);
-    HIPCHK(c, c->cids.ensure(sizeof(uint32_t) * (size_t)coarse));
-    HIPCHK(c, c->clr.ensure(sizeof(uint16_t) * (size_t)coarse));
+    const int64_t max_work = gs_bin3_max_work((int64_t)coarse, ns);
+    HIPCHK(c, c->cids.ensure(sizeof(uint32_t) * coarse));
+    HIPCHK(c, c->clr.ensure(sizeof(uint16_t) * coarse));
     HIPCHK(c, c->segcnt.ensure(sizeof(uint32_t) * 64 * (size_t)max_work));
-    HIPCHK(c, gs_bin3_l1_scatter(two_level_args(c, perm_slab, n_all, nr, sdone), c->stream));
+    HIPCHK(c, gs_bin3_l1_scatter(two_level_args(c, perm_slab, n_all, nr, sdone, coarse, fine), c->stream));
     if (!sdone) c->counters_zeroed = true;
     GsBin3Args a{};
     a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>(); a.ranges = ranges; a.tilecnt = c->tilecnt.as<uint32_t>();
     a.done = done; a.segcnt = c->segcnt.as<uint32_t>(); a.ids_out = ids_out;
     a.gx = c->gx; a.gy = c->gy; a.sgx = c->sgx; a.ns = ns; a.max_work = (int)max_work;
-    a.wide = (uint64_t)c->n_inst * 4ull >= (1ull << 32) || std::getenv("GS_BIN3_WIDE") != nullptr;   // env: tests force the 64-bit cursors
+    a.wide = (uint64_t)fine * 4ull >= (1ull << 32) || (c->cfg.debug_flags & GS_DEBUG_WIDE_CURSORS) != 0;
+    a.totals = c->bin_totals(); a.cap_coarse = (uint32_t)std::min<size_t>(coarse, 0xFFFFFFFEu); a.cap_fine = (uint32_t)std::min<size_t>(fine, 0xFFFFFFFEu);
     HIPCHK(c, gs_bin3_build_lists(a, c->stream));
     return GS_OK;
 }
@@ -600,7 +654,7 @@ static int bin_round_two_level(gs_ctx *c, int r) {
     if (c->round_ids_off[r] + (size_t)c->round_gen[r] > (size_t)c->n_inst) return fail(c, GS_ERR_HIP, "gs_forward: slab instance accounting out of range");
     {
         StageTimer t(c, GS_STAGE_TILE_SORT);
-        if (int rc = two_level_lists(c, perm, nr, nr, coarse, c->ranges_r[r].as<uint32_t>(), c->ids.as<uint32_t>() + c->round_ids_off[r],
+        if (int rc = two_level_lists(c, perm, nr, nr, (size_t)coarse, (size_t)c->round_gen[r], c->ranges_r[r].as<uint32_t>(), c->ids.as<uint32_t>() + c->round_ids_off[r],
                                      c->tile_done.as<uint8_t>(), c->sdone.as<uint8_t>())) return rc;
     }
     return GS_OK;
@@ -650,12 +704,53 @@ static int bin_round(gs_ctx *c, int r) {
     return GS_OK;
 }
 
+// The frame's totals arrive in pinned memory behind ev_count.  On the two-level path the host does not wait for them inside
+// gs_bin (speculative launch): it enqueues the lists against the CAPACITIES of the buffers it already has, the kernels compare
+// the totals on the device with those capacities (gs_bin3.hip: lists_overflow) and list nothing if a buffer is too small;
+// settle_totals, called once the host needs the numbers (after gs_forward has enqueued the composite), reads them and -- in
+// the rare frame whose lists outgrew a buffer -- grows the buffers and enqueues the lists again (returns 1: the caller
+// re-enqueues what it had enqueued on top of the empty lists).  The GPU never idles while the host wakes up, and there is no
+// stream synchronisation between gs_preprocess and the end of the frame.
+static int settle_totals(gs_ctx *c, bool *redo, bool may_relist) {
+    if (redo) *redo = false;
+    if (!c->pending_totals) return GS_OK;
+    HIPCHK(c, hipEventSynchronize(c->ev_count));
+    c->pending_totals = false;
+    harvest_events(c);
+    // pinned + 8: the counter block {walked_f, evaluated_f, walked_b, evaluated_b (u64) ... | byte 128: coarse listed, fine of the slab, fine of all}
+    unsigned long long walked_prev = 0;
+    std::memcpy(&walked_prev, c->pinned + 8, sizeof(walked_prev));
+    const uint32_t coarse = c->pinned[8 + 32], fine_slab = c->pinned[8 + 33], fine_all = c->pinned[8 + 34];
+    if (fine_all == 0xFFFFFFFFu)
+        return fail(c, GS_ERR_UNSUPPORTED, "gs_bin: more than 2^32 - 2 tile instances (32-bit list offsets); reduce the scene or the image");
+    if (c->prev_counters_valid && c->prev_n_inst > 0) c->walked_ratio = (double)walked_prev / (double)c->prev_n_inst;
+    c->prev_counters_valid = false;
+    c->n_inst = (int64_t)fine_all;
+    c->n_coarse = (int64_t)coarse;
+    c->round_gen[0] = c->n_rounds > 1 ? (int64_t)fine_slab : c->n_inst;
+    c->round_ids_off[0] = 0;
+    c->coarse_listed = (int64_t)coarse;
+    if (!c->spec_lists) return GS_OK;
+    c->spec_lists = false;
+    if ((size_t)coarse <= c->spec_cap_coarse && (size_t)fine_slab <= c->spec_cap_fine) return GS_OK;
+    if (!may_relist) { c->did_bin = false; return GS_OK; }                  // the frame is being abandoned (a new gs_preprocess / gs_bin follows)
+    // a list outgrew its buffer: nothing was listed (all ranges empty).  Grow and list again with the real totals.
+    HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * (size_t)(c->n_inst ? c->n_inst : 1)));
+    {
+        StageTimer t(c, GS_STAGE_TILE_SORT);
+        if (int rc = two_level_lists(c, c->perm_ptr, c->n, c->slab_lo[1], (size_t)coarse, (size_t)fine_slab, c->ranges.as<uint32_t>(), c->ids.as<uint32_t>(), nullptr, nullptr)) return rc;
+    }
+    if (redo) *redo = true;
+    return GS_OK;
+}
+
 int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_pre) return fail(c, GS_ERR_INVALID, "gs_bin: gs_preprocess first");
     if ((gx != 0 || gy != 0) && (gx != c->gx || gy != c->gy))
         return fail(c, GS_ERR_UNSUPPORTED, "gs_bin: blocks must equal ceil(W/16) x ceil(H/16)");
     if (bind_device(c)) return GS_ERR_HIP;
+    if (int rc = settle_totals(c, nullptr, false)) return rc;               // a frame that was binned but never rendered
     const size_t n = (size_t)c->n, n1 = n ? n : 1;
     const int64_t ntiles = (int64_t)c->gx * c->gy;
     uint32_t *perm = nullptr;
@@ -679,8 +774,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     while ((1LL << gid_bits) < c->n) ++gid_bits;
     const int passes = (tile_bits + 7) / 8;
     const int lo_bits = passes <= 1 ? tile_bits : (tile_bits + 1) / 2, hi_bits = tile_bits - lo_bits;
-    int bin_path = c->cfg.bin_path;
-    if (const char *e = std::getenv("GS_BIN_PATH")) bin_path = std::atoi(e);               // experiments
+    const int bin_path = c->exp_bin_path >= 0 ? c->exp_bin_path : c->cfg.bin_path;        // (GS_EXPERIMENTS builds: GS_BIN_PATH, read at gs_create)
     const bool fast = bin_path != 1 && passes <= 2 && hi_bits + gid_bits <= 32 && gs_tile_ranges_supported(c->gx, c->gy);
     // two-level path (gs_bin3.hip): lists per super-tile of 8 x 8 tiles first; its bitmap must fit in LDS
     const int sb = 1 << gs_bin3_sb_shift();
@@ -694,10 +788,34 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     const int R = plan_rounds(c);
     const int64_t n0 = c->slab_lo[1];                                       // list positions of round 0
     HIPCHK(c, c->block_sums.ensure(sizeof(uint32_t) * 3 * (n / 2048 + 2)));
+    c->spec_lists = false;
     if (c->two_level) {
-        StageTimer t(c, GS_STAGE_COUNT_SCAN);
-        if (int rc = two_level_count(c, perm, c->n, n0, nullptr)) return rc;
-    } else {
+        {
+            StageTimer t(c, GS_STAGE_COUNT_SCAN);
+            if (int rc = two_level_count(c, perm, c->n, n0, nullptr)) return rc;
+        }
+        // ONE copy carries the previous frame's walked count (bytes 0..7 of the counter block) and this frame's totals (bytes 128..139)
+        HIPCHK(c, hipMemcpyAsync(c->pinned + 8, c->counters.p, GS_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
+        c->pending_totals = true;
+        // speculative launch: one round, and buffers from an earlier frame to launch against
+        const size_t cap_coarse = std::min(c->cids.cap / sizeof(uint32_t), c->clr.cap / sizeof(uint16_t)), cap_fine = c->ids.cap / sizeof(uint32_t);
+        if (R == 1 && cap_coarse > 0 && cap_fine > 0) {
+            c->spec_lists = true; c->spec_cap_coarse = cap_coarse; c->spec_cap_fine = cap_fine;
+            StageTimer t(c, GS_STAGE_TILE_SORT);
+            if (int rc = two_level_lists(c, perm, c->n, n0, cap_coarse, cap_fine, c->ranges.as<uint32_t>(), c->ids.as<uint32_t>(), nullptr, nullptr)) return rc;
+        } else {                                                            // first frame of a ctx, or a slab frame: the host needs the totals now
+            if (int rc = settle_totals(c, nullptr, true)) return rc;
+            HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * (size_t)(c->n_inst ? c->n_inst : 1)));
+            StageTimer t(c, GS_STAGE_TILE_SORT);
+            if (int rc = two_level_lists(c, perm, c->n, n0, (size_t)c->coarse_listed, (size_t)c->round_gen[0], c->ranges.as<uint32_t>(), c->ids.as<uint32_t>(), nullptr, nullptr)) return rc;
+        }
+        c->did_bin = true; c->did_fwd = c->did_bwd = false;
+        return GS_OK;
+    }
+    // ---- radix paths (bin_path 2 / 1; grids the two-level path refuses): the host reads the instance count before the instance passes
+    c->n_coarse = 0;
+    {
         StageTimer t(c, GS_STAGE_COUNT_SCAN);
         HIPCHK(c, c->offsets.ensure(sizeof(uint32_t) * (n + 1)));
         HIPCHK(c, gs_launch_count_scan(c->rect.as<uint16_t>(), perm, c->offsets.as<uint32_t>(), c->block_sums.as<uint32_t>(), c->n, c->stream));
@@ -705,26 +823,18 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     // the one host read-back of the frame (the reference reads maxHits back, forward.jl:139): the instance count, the
     // generated positions of round 0 and the previous frame's walked count.  Work that does not need the count (the tile
     // ranges) is enqueued BEFORE the host waits, so the GPU stays busy while the host wakes up and launches the instance passes.
-    if (c->two_level) {       // one copy: the previous frame's walked count (bytes 0..7) and the totals (bytes 128..139)
-        HIPCHK(c, hipMemcpyAsync(c->pinned + 8, c->counters.p, GS_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
-    } else {
-        HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->pinned + 1, c->offsets.as<uint32_t>() + n0, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    }
-    if (c->prev_counters_valid && !c->two_level) HIPCHK(c, hipMemcpyAsync(c->pinned + 2, c->counters.p, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pinned + 1, c->offsets.as<uint32_t>() + n0, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->prev_counters_valid) HIPCHK(c, hipMemcpyAsync(c->pinned + 2, c->counters.p, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
-    if (fast && !c->two_level) {
+    if (fast) {
         HIPCHK(c, c->diff.ensure(sizeof(int) * gs_tile_ranges_scratch_ints(c->gx, c->gy)));
         StageTimer t(c, GS_STAGE_RANGES);
         HIPCHK(c, gs_launch_tile_ranges(c->rect.as<uint16_t>(), R > 1 ? perm : nullptr, R > 1 ? n0 : c->n, c->diff.as<int>(), c->gx, c->gy,
                                         c->ranges.as<uint32_t>(), nullptr, c->stream));
     }
     HIPCHK(c, hipEventSynchronize(c->ev_count));
-    harvest_events(c, fast && !c->two_level ? GS_STAGE_RANGES : -1);
-    if (c->two_level) {                                      // totals: coarse listed, fine of the slab, fine of all
-        c->pinned[2] = c->pinned[8]; c->pinned[3] = c->pinned[9];
-        c->pinned[4] = c->pinned[8 + 32]; c->pinned[1] = c->pinned[8 + 33]; c->pinned[0] = c->pinned[8 + 34];
-    }
+    harvest_events(c, fast ? GS_STAGE_RANGES : -1);
     if (c->pinned[0] == 0xFFFFFFFFu)
         return fail(c, GS_ERR_UNSUPPORTED, "gs_bin: more than 2^32 - 2 tile instances (32-bit list offsets); reduce the scene or the image");
     if (c->prev_counters_valid && c->prev_n_inst > 0) {
@@ -737,13 +847,9 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     c->round_gen[0] = R > 1 ? (int64_t)c->pinned[1] : c->n_inst;
     c->round_ids_off[0] = 0;
     const size_t ni1 = c->n_inst ? (size_t)c->n_inst : 1;
-    if (!c->two_level) HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
+    HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n_inst > c->n ? c->n_inst : c->n)));
     HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 4 * 256));
     HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * ni1));
-    if (c->two_level) {
-        StageTimer t(c, GS_STAGE_TILE_SORT);
-        if (int rc = two_level_lists(c, perm, c->n, n0, (int64_t)c->pinned[4], c->ranges.as<uint32_t>(), c->ids.as<uint32_t>(), nullptr, nullptr)) return rc;
-    } else
     if (fast) {
         // ---- generate-in-pass binning on 32-bit words (gs_bin2.hip)
         const size_t nchunks = ((size_t)c->n_inst + 4095) / 4096;
@@ -792,6 +898,38 @@ int gs_bind_outputs(gs_ctx *c, float *image, float *transmittance) {
     return GS_OK;
 }
 
+int gs_set_view_slot(gs_ctx *c, int32_t slot) {
+    if (!c) return GS_ERR_INVALID;
+    if (slot >= GS_MAX_VIEW_SLOTS) return fail(c, GS_ERR_INVALID, "gs_set_view_slot: slot must be below GS_MAX_VIEW_SLOTS (or negative: none)");
+    c->view_slot = slot < 0 ? -1 : (int)slot;
+    return GS_OK;
+}
+
+// the composite launch of round r of the frame (r = 0 unless the frame is binned in depth slabs)
+static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
+    const int R = c->n_rounds;
+    GsCompositeArgs a{};
+    a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
+    a.ranges = r == 0 ? c->ranges.as<uint32_t>() : c->ranges_r[r].as<uint32_t>();
+    a.ids = c->ids.as<uint32_t>() + c->round_ids_off[r]; a.payload = c->payload.as<GsPayload>();
+    a.image = c->img(); a.trans = c->tr();
+    a.walked = c->counters.as<unsigned long long>();
+    a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
+    a.resume = r > 0; a.final_round = r == R - 1;
+    a.tile_work = c->tile_work.as<uint32_t>();
+    a.tile_order = order;
+    if (R > 1) { a.tile_pos = c->tile_pos.as<uint32_t>(); a.tile_done = c->tile_done.as<uint8_t>(); a.tile_dead = c->tile_dead.as<unsigned long long>(); }
+#ifdef GS_EXPERIMENTS
+    if (c->cfg.schedule == 10 || c->cfg.schedule == 12) {
+        if (r > 0) HIPCHK(c, hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 32, c->stream));      // the forward's ticket counters
+        if (int rc = composite_sched_queue(c, a, 0)) return rc;
+    }
+#endif
+    StageTimer t(c, GS_STAGE_COMPOSITE_FWD);                               // the kernel alone
+    HIPCHK(c, gs_launch_composite_fwd(a, c->stream));
+    return GS_OK;
+}
+
 int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_bin) return fail(c, GS_ERR_INVALID, "gs_forward: gs_bin first");
@@ -804,39 +942,38 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
         HIPCHK(c, c->trans.ensure(sizeof(float) * px));
     }
     HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
+    HIPCHK(c, c->tile_work.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
     if (!c->counters_zeroed) HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 128, c->stream));   // work counters + both sets of ticket counters
     c->counters_zeroed = false;
     const int R = c->n_rounds;
     if (R > 1) {
         HIPCHK(c, c->tile_pos.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
         HIPCHK(c, c->tile_done.ensure(ntiles ? ntiles : 1));
+        HIPCHK(c, c->tile_dead.ensure(sizeof(unsigned long long) * 4 * (ntiles ? ntiles : 1)));
         HIPCHK(c, hipMemsetAsync(c->tile_pos.p, 0, sizeof(uint32_t) * ntiles, c->stream));
     }
+    const uint32_t *order = forward_order(c);
     for (int r = 0; r < R; ++r) {
         if (r > 0) { if (int rc = bin_round(c, r)) return rc; }
-        GsCompositeArgs a{};
-        a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
-        a.ranges = r == 0 ? c->ranges.as<uint32_t>() : c->ranges_r[r].as<uint32_t>();
-        a.ids = c->ids.as<uint32_t>() + c->round_ids_off[r]; a.payload = c->payload.as<GsPayload>();
-        a.image = c->img(); a.trans = c->tr();
-        a.walked = c->counters.as<unsigned long long>();
-        a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
-        a.resume = r > 0; a.final_round = r == R - 1;
-        if (R > 1) { a.tile_pos = c->tile_pos.as<uint32_t>(); a.tile_done = c->tile_done.as<uint8_t>(); }
-        if (r > 0) HIPCHK(c, hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 32, c->stream));      // the forward's ticket counters
-        if (int rc = composite_sched(c, a, 0)) return rc;
-        {
-            StageTimer t(c, GS_STAGE_COMPOSITE_FWD);                       // the kernel alone
-            HIPCHK(c, gs_launch_composite_fwd(a, c->stream));
+        if (int rc = enqueue_forward_round(c, r, order)) return rc;
+        if (r == 0) {
+            // the frame's totals: by now the composite is enqueued behind the lists, so the GPU has work while the host looks
+            bool redo = false;
+            if (int rc = settle_totals(c, &redo, true)) return rc;
+            if (redo) {                                                    // the lists outgrew a buffer and were rebuilt: composite again
+                HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 128, c->stream));
+                c->counters_zeroed = false;
+                if (int rc = enqueue_forward_round(c, 0, order)) return rc;
+            }
         }
     }
+    if (int rc = build_frame_order(c)) return rc;
     const hipMemcpyKind kind = mem == GS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     if (image && image != c->img()) HIPCHK(c, hipMemcpyAsync(image, c->img(), sizeof(float) * 3 * px, kind, c->stream));
     if (transmittance && transmittance != c->tr()) HIPCHK(c, hipMemcpyAsync(transmittance, c->tr(), sizeof(float) * px, kind, c->stream));
     if (mem == GS_MEM_HOST && (image || transmittance)) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->did_fwd = true; c->did_bwd = false; c->did_bwd_composite = false;
     c->prev_counters_valid = true; c->prev_n_inst = c->n_inst;
-    c->tile_work_valid_tiles = (int64_t)ntiles;
     return GS_OK;
 }
 
@@ -864,6 +1001,9 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_backward: gs_forward first");
     const bool params_only = (flags & GS_BWD_PARAMS_ONLY) != 0, composite_only = (flags & GS_BWD_COMPOSITE_ONLY) != 0;
     if (params_only && composite_only) return fail(c, GS_ERR_INVALID, "gs_backward: COMPOSITE_ONLY and PARAMS_ONLY exclude each other");
+    const int chain = (flags & (GS_BWD_PARAMS_SH | GS_BWD_PARAMS_GEOM)) >> 3;             // bit 0: SH kernel, bit 1: geometry chain; 0 = both
+    if (chain && !params_only) return fail(c, GS_ERR_INVALID, "gs_backward: GS_BWD_PARAMS_SH / _GEOM need GS_BWD_PARAMS_ONLY");
+    if (chain && c->kind != 0) return fail(c, GS_ERR_UNSUPPORTED, "gs_backward: GS_BWD_PARAMS_SH / _GEOM: 3-D renderer only");
     if (params_only && !c->did_bwd_composite) return fail(c, GS_ERR_INVALID, "gs_backward: GS_BWD_PARAMS_ONLY needs a GS_BWD_COMPOSITE_ONLY call on this frame");
     if ((!dC && !params_only) || (!grads && !composite_only)) return fail(c, GS_ERR_INVALID, "gs_backward: NULL argument");
     if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(c, GS_ERR_INVALID, "gs_backward: bad mem");
@@ -876,7 +1016,7 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         dC_dev = c->stage_in.as<float>();
     }
     const bool det = c->cfg.deterministic != 0;
-    HIPCHK(c, c->g2d.ensure((det ? sizeof(long long) : sizeof(float)) * 10 * n1));
+    HIPCHK(c, c->g2d.ensure((det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1));
     GsCompositeArgs a{};
     a.W = c->cam.W; a.H = c->cam.H; a.gx = c->gx; a.gy = c->gy; a.t_min = c->cfg.t_min;
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
@@ -893,10 +1033,14 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
     a.variant = c->variant_bwd; a.cull = c->cfg.alpha_cull != 0;
     if (!params_only) {
         c->last_dC = dC_dev;
-        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * 10 * n1, c->stream));
-        bool zeroed = false;                                           // the order kernel of schedule 3 / 4 zeroes the counters on its way
-        if (int rc = composite_sched(c, a, 1, &zeroed)) return rc;
-        if (!zeroed) HIPCHK(c, hipMemsetAsync(a.walked, 0, 112, c->stream));    // the backward's work counters + the ticket counters
+        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
+        // launch order: what the order kernel made of this frame's forward (it zeroed the counters on its way, once)
+        if (lpt_schedule(c)) a.tile_order = c->frame_order;
+        if (!c->bwd_counters_zeroed) HIPCHK(c, hipMemsetAsync(a.walked, 0, 112, c->stream));    // the backward's work counters + the ticket counters
+        c->bwd_counters_zeroed = false;
+#ifdef GS_EXPERIMENTS
+        if (c->cfg.schedule == 10 || c->cfg.schedule == 12) { if (int rc = composite_sched_queue(c, a, 1)) return rc; }
+#endif
         {
             StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                   // the kernel alone (what rocprof reports for it)
             HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
@@ -936,7 +1080,7 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
     b.d_opac = grads->d_opacities; b.d_shs = grads->d_shs;
     {
         StageTimer t(c, GS_STAGE_PREPROCESS_BWD);
-        HIPCHK(c, gs_launch_preprocess_bwd(b, c->cam, c->stream));
+        HIPCHK(c, gs_launch_preprocess_bwd(b, c->cam, c->stream, chain ? chain : 3));
     }
     if (mem == GS_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));   // dC host buffer no longer needed
     c->did_bwd = true;
@@ -1109,7 +1253,8 @@ int gs_grads_read(gs_ctx *c, const gs_grads *g, float *h_means, float *h_scales,
 }
 
 int64_t gs_num_gaussians(const gs_ctx *c) { return c ? c->n : 0; }
-int64_t gs_num_instances(const gs_ctx *c) { return c ? c->n_inst : 0; }
+int64_t gs_num_instances(gs_ctx *c) { if (!c) return 0; (void)settle_totals(c, nullptr, true); return c->n_inst; }
+int64_t gs_num_coarse_instances(gs_ctx *c) { if (!c) return 0; (void)settle_totals(c, nullptr, true); return c->two_level ? c->n_coarse : 0; }
 int gs_num_rounds(const gs_ctx *c) { return c ? c->n_rounds : 0; }
 
 int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
@@ -1124,6 +1269,7 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
     };
     if (which <= GS_ARR_TILE_RECT && !c->did_pre) return fail(c, GS_ERR_INVALID, "gs_get_array: gs_preprocess first");
     if (which >= GS_ARR_SORT_IDXS && which <= GS_ARR_SORTED_KEYS && !c->did_bin) return fail(c, GS_ERR_INVALID, "gs_get_array: gs_bin first");
+    if (which >= GS_ARR_TILE_RANGES && which <= GS_ARR_SORTED_KEYS) { if (int rc = settle_totals(c, nullptr, true)) return rc; }
     if (which >= GS_ARR_TILE_RANGES && which <= GS_ARR_SORTED_KEYS && c->n_rounds > 1)
         return fail(c, GS_ERR_INVALID, "gs_get_array: this frame was binned in depth slabs (lists spread over rounds); use gs_config.slab_mode = 0");
     switch (which) {
@@ -1142,7 +1288,7 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
             for (size_t g = 0; g < n; ++g) {
                 const GsPayload &p = h[g];
                 if (which == GS_ARR_MU) { o[2 * g] = p.mx; o[2 * g + 1] = p.my; }
-                else if (which == GS_ARR_INVCOV) { o[4 * g] = p.i0; o[4 * g + 1] = p.i1; o[4 * g + 2] = p.i2; o[4 * g + 3] = p.i3; }
+                else if (which == GS_ARR_INVCOV) { o[4 * g] = p.i0; o[4 * g + 1] = p.i1; o[4 * g + 2] = p.i2; o[4 * g + 3] = p.i3; }     // the raw conic (fourth quad of the row)
                 else if (which == GS_ARR_RGB) { o[3 * g] = p.r; o[3 * g + 1] = p.g; o[3 * g + 2] = p.b; }
                 else o[g] = p.sig;
             }
@@ -1183,13 +1329,17 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
             if ((size_t)bytes != sizeof(float) * 10 * n) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
             float *o = static_cast<float *>(dst);
             if (c->cfg.deterministic) {
-                std::vector<long long> fx(10 * (n ? n : 1));
-                if (n) HIPCHK(c, hipMemcpyAsync(fx.data(), c->g2d.p, sizeof(long long) * 10 * n, hipMemcpyDeviceToHost, c->stream));
+                std::vector<long long> fx((size_t)GS_G2D_STRIDE * (n ? n : 1));
+                if (n) HIPCHK(c, hipMemcpyAsync(fx.data(), c->g2d.p, sizeof(long long) * GS_G2D_STRIDE * n, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
-                for (size_t i = 0; i < 10 * n; ++i) o[i] = (float)((double)fx[i] * gs_fixed_inv((int)(i % 10)));
+                for (size_t g = 0; g < n; ++g)
+                    for (int i = 0; i < 10; ++i) o[10 * g + i] = (float)((double)fx[GS_G2D_STRIDE * g + i] * gs_fixed_inv(i));
             } else {
-                if (n) HIPCHK(c, hipMemcpyAsync(dst, c->g2d.p, sizeof(float) * 10 * n, hipMemcpyDeviceToHost, c->stream));
+                std::vector<float> fl((size_t)GS_G2D_STRIDE * (n ? n : 1));
+                if (n) HIPCHK(c, hipMemcpyAsync(fl.data(), c->g2d.p, sizeof(float) * GS_G2D_STRIDE * n, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
+                for (size_t g = 0; g < n; ++g)
+                    for (int i = 0; i < 10; ++i) o[10 * g + i] = fl[GS_G2D_STRIDE * g + i];
             }
             // the device rows hold raw moments: apply the per-gaussian factors with the view's payload (sig, conic)
             std::vector<GsPayload> pay(n ? n : 1);
@@ -1250,26 +1400,26 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
         ++a.nseg;
     }
     a.g2d = c->cfg.deterministic ? nullptr : c->g2d.as<float>(); a.g2d_fixed = c->cfg.deterministic ? c->g2d.as<long long>() : nullptr;
-    a.variant = variant % 100; a.map_mode = (variant / 100) % 10;
+    a.variant = variant % 100;
     a.cull = (c->cfg.alpha_cull != 0) != (variant >= 1000);                  // +1000: the other cull setting
-    // the queue + longest-first set-up regardless of gs_config.schedule: the variant's tens digit picks the scheduling
-    const int keep = c->cfg.schedule;
-    c->cfg.schedule = 0;
-    const int rc = composite_sched(c, a, which);
-    c->cfg.schedule = keep;
-    if (rc) return rc;
-    if (which == 0) a.tile_work = nullptr;                                   // keep the frame's per-tile work for the backward
-    const int ntiles = c->gx * c->gy;                                        // the same segments without longest-first (variant tens digit 2)
-    HIPCHK(c, c->tile_order_p.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
-    HIPCHK(c, gs_launch_tile_order(nullptr, 0, ntiles, c->tile_order_p.as<uint32_t>(), c->tile_order_p.as<uint32_t>() + ntiles, c->stream));
-    a.tile_order_plain = c->tile_order_p.as<uint32_t>();
-    {                                                                        // variant tens digit 3: longest-first permutation, plain launch
-        const int fwd_mode = std::getenv("GS_FWD_ORDER_BY_WORK") ? 0 : 1;     // forward: by list length, or (experiment) by the measured work of this frame
-        HIPCHK(c, c->tile_order_f.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
-        HIPCHK(c, gs_launch_tile_lpt_order(which == 0 && fwd_mode ? c->ranges.as<uint32_t>() : c->tile_work.as<uint32_t>(), which == 0 ? fwd_mode : 0, ntiles,
-                                           c->tile_order_f.as<uint32_t>(), c->stream));
-        a.tile_order_band = c->tile_order_f.as<uint32_t>();
+    // variant tens digit (gs_composite.hip: apply_sched_variant): 0 the frame's own launch order (what production uses for the
+    // backward and for the next forward of the slot), 1 tile order, 3 = 0 explicitly
+    a.tile_order = lpt_schedule(c) ? c->frame_order : nullptr;
+    a.tile_order_band = a.tile_order;
+#ifdef GS_EXPERIMENTS
+    a.map_mode = (variant / 100) % 10;
+    {   // tens digit 0 / 2 in experiment builds: the persistent queue, longest first / in tile order
+        const int keep = c->cfg.schedule;
+        c->cfg.schedule = 10;
+        const int rc = composite_sched_queue(c, a, which);
+        c->cfg.schedule = keep;
+        if (rc) return rc;
+        const int ntiles = c->gx * c->gy;
+        HIPCHK(c, c->tile_order_p.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
+        HIPCHK(c, gs_launch_tile_order(nullptr, 0, ntiles, c->tile_order_p.as<uint32_t>(), c->tile_order_p.as<uint32_t>() + ntiles, c->stream));
+        a.tile_order_plain = c->tile_order_p.as<uint32_t>();
     }
+#endif
     return GS_OK;
 }
 

@@ -40,7 +40,11 @@ int64_t gs_bin3_max_work(int64_t coarse_instances, int ns) { return coarse_insta
 static size_t l1_lds_bytes(int ns, int g) { return (size_t)ns * (g / 8 + g / 16 + 8) + 24 * (size_t)g; }
 int gs_bin3_group(int ns) {
     int g = 512;                                          // measured at C3 (135 super-tiles): 1024 -> 67 us, 512 -> 60 us, 256 -> 64 us for level 1
-    if (const char *e = getenv("GS_L1_G")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) g = v; }   // experiments
+#ifdef GS_EXPERIMENTS
+    static int forced = -1;                               // GS_L1_G, read once per process
+    if (forced < 0) { const char *e = getenv("GS_L1_G"); const int v = e ? atoi(e) : 0; forced = (v == 256 || v == 512 || v == 1024) ? v : 0; }
+    if (forced) g = forced;
+#endif
     while (g > 256 && l1_lds_bytes(ns, g) > 72 * 1024) g >>= 1;
     return g;
 }
@@ -84,7 +88,14 @@ struct L1Args {
     uint32_t *tilecnt;           // [ntiles] zeroed here for the level-2 count pass
     int ntiles;
     uint32_t *zero_words;        // 32 words zeroed by l1_scatter (the forward's work counters: saves a memset command); may be null
+    uint32_t cap_coarse, cap_fine; // entries the coarse lists (cids, clr) / the tile lists (ids) can hold: a frame whose totals exceed
+                                 // them writes no list at all (every range empty) and the host redoes it with larger buffers
 };
+// The lists are enqueued BEFORE the host has seen the frame's totals (speculative launch, gs_api.hip): every kernel that
+// writes them checks the totals against the capacities of the buffers it was given.
+__device__ __forceinline__ bool lists_overflow(const uint32_t *totals, uint32_t cap_coarse, uint32_t cap_fine) {
+    return totals[0] > cap_coarse || totals[1] > cap_fine;
+}
 
 // One list position per thread (blockDim = G): sets the position's bits in the LDS bitmap bm[ns][G / 32].
 template <bool FROM_SORTED>
@@ -227,6 +238,7 @@ __global__ __launch_bounds__(1024) void l1_scatter_kernel(L1Args a) {
     uint16_t *pre = reinterpret_cast<uint16_t *>(st_ls + cap);          // [ns][wpr] set bits of the row below word w
     const int64_t base = (int64_t)blockIdx.x * a.G;
     if (a.zero_words && blockIdx.x == 0 && tid < 32) a.zero_words[tid] = 0;
+    if (lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;     // uniform over the grid
     // issued first, used after the bitmap phase: the list-start operands of the first scan pass (all of them when ns <= G)
     const uint32_t v_first = tid < a.ns ? a.row_total[tid] : 0u;
     const uint32_t tb_first = tid < a.ns ? a.table[(size_t)tid * a.nwg + blockIdx.x] : 0u;
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(L2_THREADS) void l2_count_kernel(GsBin3Args a) {
     __shared__ int diff[CNT_COPIES * CNT_CELLS];
     __shared__ uint32_t sh[12];
     int S; uint32_t e0, e1, w0;
+    if (lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;
     if (!find_work<L2_THREADS>(a, sh, S, e0, e1, w0)) return;
     const int tid = threadIdx.x;
     for (int i = tid; i < CNT_COPIES * CNT_CELLS; i += L2_THREADS) diff[i] = 0;
@@ -374,9 +387,14 @@ __global__ __launch_bounds__(L2_THREADS) void l2_count_kernel(GsBin3Args a) {
 
 // tile ranges = exclusive scan of the tile counts in tile order (one workgroup); completed tiles get an empty range
 __global__ __launch_bounds__(1024) void l2_ranges_kernel(const uint32_t *__restrict__ tilecnt, int ntiles, const uint8_t *__restrict__ done,
-                                                          uint32_t *__restrict__ ranges) {
+                                                          uint32_t *__restrict__ ranges, const uint32_t *__restrict__ totals, uint32_t cap_coarse,
+                                                          uint32_t cap_fine) {
     __shared__ uint32_t sm[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (lists_overflow(totals, cap_coarse, cap_fine)) {                  // nothing was listed: every range empty
+        for (int t = tid; t < ntiles; t += 1024) { ranges[2 * t] = 0; ranges[2 * t + 1] = 0; }
+        return;
+    }
     uint32_t carry = 0;
     for (int b0 = 0; b0 < ntiles; b0 += 1024 * 4) {
         uint32_t v[4], tot = 0;
@@ -433,6 +451,7 @@ __global__ __launch_bounds__(L2W_THREADS) void l2_write_kernel(GsBin3Args a) {
     __shared__ uint32_t sh[12];
     __shared__ uint32_t sdead[2];
     int S; uint32_t e0, e1, w0;
+    if (lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;
     if (!find_work<L2W_THREADS>(a, sh, S, e0, e1, w0)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ox = (S % a.sgx) * SB, oy = (S / a.sgx) * SB;
@@ -527,6 +546,7 @@ static L1Args l1_args(const GsBin3L1 &b) {
     a.rect_sorted = reinterpret_cast<uint2 *>(b.rect_sorted); a.table = b.table; a.row_total = b.row_total;
     a.partials = b.partials; a.totals = b.totals; a.cranges = b.cranges; a.cids = b.cids; a.clr = b.clr;
     a.tilecnt = b.tilecnt; a.ntiles = b.ntiles; a.zero_words = b.zero_words;
+    a.cap_coarse = b.cap_coarse; a.cap_fine = b.cap_fine;
     return a;
 }
 size_t gs_bin3_table_words(int64_t n_slab, int ns) { const int G = gs_bin3_group(ns); return (size_t)ns * (size_t)((n_slab + G - 1) / G + 1); }
@@ -561,7 +581,7 @@ hipError_t gs_bin3_l1_scatter(const GsBin3L1 &b, hipStream_t s) {
 hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s) {
     if (a.max_work <= 0) return hipSuccess;
     hipLaunchKernelGGL(l2_count_kernel, dim3(a.max_work), dim3(L2_THREADS), 0, s, a);
-    hipLaunchKernelGGL(l2_ranges_kernel, dim3(1), dim3(1024), 0, s, a.tilecnt, a.gx * a.gy, a.done, a.ranges);
+    hipLaunchKernelGGL(l2_ranges_kernel, dim3(1), dim3(1024), 0, s, a.tilecnt, a.gx * a.gy, a.done, a.ranges, a.totals, a.cap_coarse, a.cap_fine);
     if (a.wide) hipLaunchKernelGGL(l2_write_kernel<true>, dim3(a.max_work), dim3(L2W_THREADS), 0, s, a);
     else hipLaunchKernelGGL(l2_write_kernel<false>, dim3(a.max_work), dim3(L2W_THREADS), 0, s, a);
     return hipGetLastError();

@@ -6,18 +6,25 @@
 #define GS_TILE 16
 #define GS_WAVE 64
 
-// Per-gaussian, per-view splat payload staged through LDS by the composite kernels.
-// 48 bytes, 16-byte aligned (three dwordx4 loads).  Replaces the 26 scattered floats the
-// reference gathers per (pixel, slot) (src/splat.jl:224-252).
+// Per-gaussian, per-view splat payload staged through LDS by the composite kernels: ONE 64-byte row per gaussian, 64-byte
+// aligned, so the random gather of a list entry touches a single 64-byte memory sector (the 48-byte rows of rounds 1-2
+// straddled two sectors for every second gaussian).  The composite kernels read the first three quads; everything in them
+// that is constant per (gaussian, view) is already in the form the inner loops use (log2 of the sigmoid, the conic scaled
+// by -1/2 log2 e), so the staging lane of a (tile, splat) entry has no v_log and no rescaling left to do.  Replaces the
+// 26 scattered floats the reference gathers per (pixel, slot) (src/splat.jl:224-252).
 struct __attribute__((aligned(16))) GsPayload {
     float mx, my;        // renderer.positions (mu')                      projection.jl:88-93
-    float sig;           // cusigmoid(opacity)                            splat.jl:175-178
+    float l2s;           // min(log2(cusigmoid(opacity)), -2.6e-7): alpha = exp2(pw + l2s) < 1 strictly   splat.jl:175-178,247
     uint32_t bbx;        // int16 xmin | int16 xmax << 16  (renderer.bbs)  boundingbox.jl:24-25
-    float i0, i1, i2, i3;// renderer.invCov2ds, column-major              cov2d.jl:30-45
-    float r, g, b;       // sh2color                                      splat.jl:180-193
+    float ka, kb, kc;    // k i0, k (i1 + i2), k i3 with k = -1/2 log2 e: pw = ka dX^2 + kb dX dY + kc dY^2   splat.jl:246
     uint32_t bby;        // int16 ymin | int16 ymax << 16                 boundingbox.jl:26-27
+    float r, g, b;       // sh2color                                      splat.jl:180-193
+    float sig;           // cusigmoid(opacity)                            splat.jl:175-178
+    float i0, i1, i2, i3;// renderer.invCov2ds, column-major              cov2d.jl:30-45   (introspection only: gs_get_array)
 };
-static_assert(sizeof(GsPayload) == 48, "payload must be 48 bytes");
+static_assert(sizeof(GsPayload) == 64, "payload must be 64 bytes");
+#define GS_NEG_HALF_LOG2E (-0.72134752044448170368f)
+#define GS_L2S_CAP (-2.6e-7f)
 
 struct GsCamera {
     float T[16], P[16];
@@ -143,6 +150,7 @@ struct GsBin3L1 {
     uint32_t *tilecnt;         // ntiles words: zeroed by gs_bin3_l1_count, accumulated and scanned by gs_bin3_build_lists
     int ntiles;
     uint32_t *zero_words;      // gs_bin3_l1_scatter zeroes these 32 words (may be null)
+    uint32_t cap_coarse, cap_fine; // entries cids / clr and ids_out can hold (lists are dropped, not overrun, when the totals exceed them)
 };
 struct GsBin3Args {
     const uint32_t *cranges;   // 2 x ns: [start, end) of every super-tile's list inside cids
@@ -156,6 +164,8 @@ struct GsBin3Args {
     int gx, gy, sgx, ns;
     int max_work;              // upper bound of the number of (super-tile, segment) work items
     int wide;                  // the lists reach beyond 4 GB from ids_out: 64-bit store addresses
+    const uint32_t *totals;    // the round's totals (GsBin3L1.totals) and the capacities they are checked against
+    uint32_t cap_coarse, cap_fine;
 };
 int gs_bin3_sb_shift();
 bool gs_bin3_supported(int ns);
@@ -168,7 +178,8 @@ hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s);
 hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, uint8_t *sdone, hipStream_t s);
 
 #define GS_MAX_ROUNDS 4   // binning rounds (depth slabs) of one frame
-#define GS_G2D_STRIDE 10   // floats (or fixed-point words) per gaussian row of the composite backward's sums
+#define GS_G2D_STRIDE 16   // floats (or fixed-point words) per gaussian row of the composite backward's sums: ten used, padded to ONE
+                           // 64-byte sector so that the 9-lane atomic of a (tile, splat) entry is a single memory-side request
 struct GsCompositeArgs {
     int W, H, gx, gy;
     float t_min;
@@ -201,13 +212,15 @@ struct GsCompositeArgs {
     const uint32_t *seg_ids[GS_MAX_ROUNDS];
     uint32_t *tile_pos;        // forward: per tile, list position reached by the earlier rounds (read, then += this round's segment); may be null
     uint8_t *tile_done;        // forward: per tile, 1 = every pixel frozen (written each round; read when `resume`); may be null
+    unsigned long long *tile_dead; // forward, slab frames: 4 lane masks per tile, bit l of word p = pixel slot p of lane l is frozen
     int resume;                // forward: continue from the pixel state the previous round left in image / trans
     int final_round;           // forward: last round of the frame: transmittance is written plain (no sign flag)
 };
-// tiles in decreasing order of work[] (a 256-bucket counting sort of work / max; one workgroup)
+// longest-first launch order of the tiles (keeps tile % 8; GS_LPT_BUCKETS work classes, tile order inside a class; one workgroup)
 // zero14 (may be null): fourteen 64-bit words zeroed on the way (the backward's work and ticket counters: saves a memset command)
+#define GS_LPT_MAX_TILES 35000
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s,
-                                    unsigned long long *zero14 = nullptr);
+                                    unsigned long long *zero14 = nullptr, int buckets = 0);
 hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s);
 int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body = 0);   // occupancy x CUs (body: A/B variant)
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
@@ -225,7 +238,8 @@ struct GsPreprocessBwdArgs {
     float sgd_scale;      // != 0 (accumulate mode only): target = fma(sgd_scale, gradient, target) -- with the parameter arrays as
                           // targets and sgd_scale = -lr this IS the SGD step, fused (gs_backward_sgd)
 };
-hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s);
+// phases: bit 0 the SH / colour kernel (d_shs, dpc), bit 1 the geometry chain (reads dpc); 3 = both, in that order
+hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s, int phases = 3);
 
 // colour-factored gradient exchange (gs_preprocess_bwd.hip)
 hipError_t gs_launch_pack_drgb(const float *g2d, const long long *g2d_fixed, float *out, int64_t n, hipStream_t s);
@@ -237,7 +251,7 @@ hipError_t gs_launch_sh_from_views(int64_t n, int sh_degree, const float *means,
 // major i0 i1 i2 i3, mc = (i1 + i2)/2):  dL/dsig = -S0/sig,  dL/dmu = -(i0 Sx + mc Sy, mc Sx + i3 Sy),
 // dL/dM = 1/2 [Sxx Sxy; Sxy Syy].  In place: row becomes [dr dg db dsig dmx dmy d00 d01 d10 d11].
 template <typename R>
-__host__ __device__ inline void gs_g2d_to_grads(R (&g2)[10], R sig, R i0, R mc, R i3) {
+__host__ __device__ inline void gs_g2d_to_grads(R (&g2)[10], R sig, R i0, R mc, R i3) {   // g2: the ten used words of a row
     const R S0 = g2[3], Sx = g2[4], Sy = g2[5], Sxx = g2[6], Sxy = g2[7], Syy = g2[9];
     g2[3] = sig > R(0) ? -S0 / sig : R(0);
     g2[4] = -(i0 * Sx + mc * Sy);

@@ -5,7 +5,7 @@
 // C += rgb*alpha*T, T *= 1-alpha, for list entries whose pixel box contains the pixel
 // (splat.jl:240); no alpha clamp / 1/255 cut (reference has none).  The reference gathers
 // 26 floats per (pixel, slot) from global memory and evaluates SH per pixel; here the per-view
-// payload (48 B) is gathered once per (tile, splat) with coalesced id loads, staged in LDS
+// payload (one 64-byte row) is gathered once per (tile, splat) with coalesced id loads, staged in LDS
 // and broadcast to the lanes.
 //
 // Mapping (wave64-first, not a 16x16 CUDA block): ONE wave per tile, lane l owns the four
@@ -61,6 +61,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float vgpr_const(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+#ifdef GS_EXPERIMENTS
 // Workgroup -> tile map of the non-queued launch (A/B only).  Measured on MI355X at C3 (tools/abtest.py): the plain
 // order is 5 % faster than giving each XCD a contiguous band of tiles or whole tile rows.  Speed only, never correctness.
 __device__ __forceinline__ int tile_of_block(int b, int ntiles, int gx, int mode) {
@@ -72,6 +73,7 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles, int gx, int mode
     const int per = (ntiles + 7) >> 3;             // mode 1: one contiguous band of tiles per XCD
     return (b & 7) * per + (b >> 3);
 }
+#endif
 
 // Next tile of this wave: a ticket from the work queue (persistent launch) or the block's own tile (first call only).
 // The queue is eight ticket counters, one per XCD, over eight segments of tile_order: segment x holds the tiles with
@@ -81,6 +83,7 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles, int gx, int mode
 // (profiles/: one shared counter vs plain launch).  When its segment is exhausted it steals from the next ones, so the
 // kernel ends balanced across the chip.  Placement is a speed matter only: any wave may process any tile.
 __device__ __forceinline__ int next_tile(const GsCompositeArgs &a, int ntiles, bool first) {
+#ifdef GS_EXPERIMENTS
     if (a.queue) {
         const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 7u;       // HW_REG_XCC_ID
         for (uint32_t i = 0; i < 8; ++i) {
@@ -94,9 +97,14 @@ __device__ __forceinline__ int next_tile(const GsCompositeArgs &a, int ntiles, b
         }
         return -1;
     }
+#endif
     if (!first) return -1;
-    if (a.tile_order) return (int)blockIdx.x < ntiles ? (int)a.tile_order[blockIdx.x] : -1;     // schedule 3: plain launch, permuted tiles
+    if (a.tile_order) return (int)blockIdx.x < ntiles ? (int)a.tile_order[blockIdx.x] : -1;     // schedule 3 / 4: plain launch, permuted tiles
+#ifdef GS_EXPERIMENTS
     const int tile = tile_of_block(blockIdx.x, ntiles, a.gx, a.map_mode);
+#else
+    const int tile = (int)blockIdx.x;
+#endif
     return tile < ntiles ? tile : -1;
 }
 
@@ -119,7 +127,7 @@ __device__ __forceinline__ unsigned long long wave_hw_id() {
 // and rgb*alpha*T is below 7.5e-9*|rgb|, under half an ulp of any accumulated colour above 1e-7.  Such
 // entries are dropped while staging (gs_config.alpha_cull, default on; lists stay the reference's).
 #define GS_ALPHA_CULL_LOG2 (-27.0f)
-// Lane-independent terms of one splat, computed once per (tile, splat) by the staging lane:
+// Lane-independent terms of one splat, formed once per (tile, splat) by the staging lane from the payload row:
 // q0 = {mu_x, mu_y, log2 sig, x_lo}, q1 = {k i0, k (i1+i2), k i3, x_hi}, q2 = {r, g, b, y_lo}, y_hi   (k = -1/2 log2 e)
 // Can any pixel of the rectangle [rx0,rx1] x [ry0,ry1] (relative to mu, already clipped to the splat's pixel box)
 // reach alpha >= 2^GS_ALPHA_CULL_LOG2?  f(dx,dy) = A dx^2 + B dx dy + C dy^2 (log2 units, concave) is maximised over
@@ -146,18 +154,19 @@ __device__ __forceinline__ bool rect_can_contribute(float A, float B, float C, f
 template <bool STRIPS>
 __device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2,
                                               const int tx0, const int ty0, bool &keep, uint32_t &strips) {
-    const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n2.w);
+    // payload quads (gs_common.h): n0 = {mu_x, mu_y, log2 sig (capped below 0), box x}, n1 = {k i0, k (i1+i2), k i3, box y}, n2 = {r, g, b, sig}
+    const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n1.w);
     const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
     const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
     const bool empty = xmax < xmin || ymax < ymin;
-    // log2(sig), capped three ulps below 0 so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic is PSD) even when
-    // v_exp_f32 returns a value one ulp high; only matters when sigmoid(o) > 1 - 1.8e-7 (o > 15.5): relative change 1.8e-7
-    const float l2s = fminf(__builtin_amdgcn_logf(n0.z), -2.6e-7f);
+    // log2(sig) arrives capped three ulps below 0 (gs_preprocess.hip), so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic
+    // is PSD) even when v_exp_f32 returns a value one ulp high; only matters when sigmoid(o) > 1 - 1.8e-7 (o > 15.5): relative change 1.8e-7
+    const float l2s = n0.z;
     // an empty box (near/far-culled splat) gets lo = hi = +BIG: every pixel is "outside"
     const float xlo = empty ? GS_BIG : ((float)xmin - n0.x) - 0.25f, xhi = empty ? GS_BIG : ((float)xmax - n0.x) + 0.25f;
     const float ylo = empty ? GS_BIG : ((float)ymin - n0.y) - 0.25f, yhi = empty ? GS_BIG : ((float)ymax - n0.y) + 0.25f;
     q0 = make_float4(n0.x, n0.y, l2s, xlo);
-    q1 = make_float4(NEG_HALF_LOG2E * n1.x, NEG_HALF_LOG2E * (n1.y + n1.z), NEG_HALF_LOG2E * n1.w, xhi);
+    q1 = make_float4(n1.x, n1.y, n1.z, xhi);
     q2 = make_float4(n2.x, n2.y, n2.z, ylo);
     {
         const float A = q1.x, B = q1.y, C = q1.z;
@@ -209,9 +218,11 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     if (a.tile_clock) clk0 = __builtin_amdgcn_s_memrealtime();
 
     // Slab frames (binning in depth slabs): the tile's list arrives in several rounds.  A later round resumes the
-    // pixel state the previous one left in image / trans (a frozen pixel is stored as -T, its sign is the flag), continues
-    // the list position (tile_pos) so that the 64-entry batch boundaries -- where the early-out rule freezes pixels -- stay
-    // those of the whole list, and a tile whose pixels are all frozen is marked done and takes no further instances.
+    // pixel state the previous one left in image / trans and in tile_dead (four 64-bit lane masks per tile: pixel slot p of
+    // lane l is frozen -- a flag of its own, because a LIVE pixel's T may be negative when a conic is not positive definite
+    // and then looks like nothing else than a negative T), continues the list position (tile_pos) so that the 64-entry batch
+    // boundaries -- where the early-out rule freezes pixels -- stay those of the whole list, and a tile whose pixels are all
+    // frozen is marked done and takes no further instances.
     if (a.resume && a.tile_done[tile]) return;
     const uint32_t gp0 = a.tile_pos ? a.tile_pos[tile] : 0u;
     const size_t plane = (size_t)a.W * a.H;
@@ -229,15 +240,15 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             const size_t o = (size_t)(px - 1) + (size_t)a.W * (py0 + 4 * p - 1);
             Cr[p] = a.image[o]; Cg[p] = a.image[o + plane]; Cb[p] = a.image[o + 2 * plane];
             const float t = a.trans[o];
-            dead[p] = (__float_as_uint(t) >> 31) != 0u;
-            Tdead[p] = fabsf(t);
+            dead[p] = ((a.tile_dead[4 * (size_t)tile + p] >> lane) & 1ull) != 0ull;
+            Tdead[p] = dead[p] ? t : 0.0f;
             T[p] = dead[p] ? 0.0f : t;
         }
     }
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t pos = s0 + lane;
-    if (!LEAN && pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+    if (!LEAN && pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
     uint32_t gp = gp0;                                                  // list position of `base` in the tile's whole list
     for (uint32_t base = s0; base < s1;) {
         const uint32_t phase = gp & (CB - 1);
@@ -257,7 +268,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         if (LEAN) {
             n0 = n1 = n2 = make_float4(0.f, 0.f, 0.f, 0.f);
             pos = base + lane;
-            if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+            if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
         }
         const float yhi_l = stage_record<false>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
         int slot = lane, nk = cnt;
@@ -275,7 +286,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         __syncthreads();
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
-        if (!LEAN && pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[3 * g]; n1 = pay4[3 * g + 1]; n2 = pay4[3 * g + 2]; }
+        if (!LEAN && pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
 #pragma clang loop unroll_count(LEAN ? 1 : 2)
         for (int k = 0; k < nk; ++k) {
             const Entry e = load_entry(sp, syhi, k);
@@ -301,7 +312,13 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
 #pragma unroll
     for (int p = 0; p < 4; ++p) anylive = anylive || !dead[p];
     const bool all_dead = __ballot(anylive) == 0ull;                    // complete: no pixel takes anything further
-    const bool plain = a.final_round || all_dead;                       // else frozen pixels are stored as -T for the next round
+    if (a.tile_dead && !a.final_round) {                                // the frozen flags travel to the next round beside the pixels
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned long long m = __ballot(dead[p]);
+            if (lane == 0) a.tile_dead[4 * (size_t)tile + p] = m;
+        }
+    }
     if (lane == 0) {
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
         if (a.tile_work) a.tile_work[tile] = a.resume ? a.tile_work[tile] + evaluated : evaluated;
@@ -315,7 +332,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             if (py <= a.H) {
                 const size_t o = (size_t)(px - 1) + (size_t)a.W * (py - 1);
                 if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p]; }
-                if (a.trans) a.trans[o] = (EARLY && dead[p]) ? (plain ? Tdead[p] : -Tdead[p]) : T[p];
+                if (a.trans) a.trans[o] = (EARLY && dead[p]) ? Tdead[p] : T[p];
             }
         }
     }
@@ -536,7 +553,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const uint32_t *ids = a.seg_ids[sg];
     const uint32_t s0 = a.seg_ranges[sg][2 * tile], s1 = a.seg_ranges[sg][2 * tile + 1];
     uint32_t pos = s0 + lane;
-    if (pos < s1) { nid = ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+    if (pos < s1) { nid = ids[pos]; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; }
     for (uint32_t base = s0; base < s1;) {
         const uint32_t phase = gp & (CB - 1);
         const int cnt = (int)min((uint32_t)CB - phase, s1 - base);
@@ -583,7 +600,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         };
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
-        if (pos < s1) { nid = ids[pos]; n0 = pay4[3 * (size_t)nid]; n1 = pay4[3 * (size_t)nid + 1]; n2 = pay4[3 * (size_t)nid + 2]; }
+        if (pos < s1) { nid = ids[pos]; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; }
         if (RED == 2) {
             // software pipeline: arithmetic of entry k | loads of entry k+1 | sums + atomic of entry k-1 (its sixteen
             // partials were read back during the arithmetic) | partials of entry k -> LDS, read back transposed
@@ -679,6 +696,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     }
 }
 
+#ifdef GS_EXPERIMENTS
 // ---------------------------------------------------------------- tile order (per XCD, longest first)
 // One workgroup: tiles are keyed by (tile % 8, work / max in 256 steps, descending) and counting-sorted; seg[0..8] are the
 // bounds of the eight per-XCD segments of `order`.  work = work[t], or the list length ranges[2t+1] - ranges[2t]
@@ -720,79 +738,95 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
     for (int t = tid; t < ntiles; t += 1024) order[atomicAdd(&hist[bucket(t)], 1u)] = (uint32_t)t;
 }
 
-// Longest-first order for a PLAIN launch (schedule 3, the backward's default).  The dispatcher hands workgroups out in
-// blockIdx order, round-robin over the XCDs, so order[b] keeps what the plain tile order has -- tile % 8 == b % 8: the same
-// tiles on the same XCD as in launch order, i.e. vertically adjacent tiles (tile + gx) share their splat payloads in one L2
-// -- and inside each residue class the heaviest tile comes first, so the workgroups that start last are the lightest ones
-// and the kernel ends without a tail (measured at C3: 0.84 -> 0.74 ms; the persistent ticket queues of schedule 0 / 2 balance
-// as well but lost more to their per-tile overhead and placement).  One workgroup: a counting sort per residue class on
-// work / max in 256 steps; tiles inside a bucket keep no particular order.  work = src[t], or the list length (ranges_mode).
-__global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles,
+#endif  // GS_EXPERIMENTS
+
+// Longest-first order for a PLAIN launch (gs_config.schedule 3 / 4).  The dispatcher hands workgroups out in blockIdx order,
+// round-robin over the XCDs, so order[b] keeps what the plain tile order has -- tile % 8 == b % 8: the same tiles on the same
+// XCD as in launch order -- and inside each residue class the heavier tiles come first, so the workgroups that start last are
+// the lightest ones and the kernel ends without a tail (C3 backward: 0.84 -> 0.74 ms).
+// Round 3: the order is a STABLE counting sort on NB work classes (work / max in NB steps), tiles of one class stay in tile
+// order.  Round 2 sorted on 256 classes with LDS atomics, i.e. in no particular order inside a class: vertically adjacent
+// tiles (tile + gx: same residue class for the 8-aligned grids of 1080p and 4K), which share most of their splats, no longer
+// ran together and the composite's payload gathers missed the XCD's L2 twice as often (r02c PMC: 961 MB fetched by the
+// permuted backward against 457 MB by the forward in tile order, same lists).  Only the START order of the light tail
+// matters for the balance -- with 5 waves per SIMD the first 5120 of C3's 8160 tiles start at once whatever their order --
+// so a few classes lose nothing.  Ranks come from an LDS bitmap [class row][tile of the residue class]: atomic OR (order
+// free), word prefix, popcount below the own bit -- the same construction as the level-1 binning (gs_bin3.hip).
+// One workgroup; work = src[t], or the list length (ranges_mode).
+#define GS_LPT_BUCKETS 16
+__global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int nb,
                                                                uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14) {
-    extern __shared__ uint32_t wk[];                                     // the tiles' work, read from memory once
-    __shared__ uint32_t hist[2048];                                      // [residue][bucket], bucket 0 = heaviest
+    extern __shared__ uint32_t lds[];
     __shared__ uint32_t wmax;
+    __shared__ uint32_t rowtot[8 * 32], rowstart[8 * 32];
     const int tid = threadIdx.x;
-    hist[tid] = 0; hist[tid + 1024] = 0;
+    const int per = (ntiles + 7) >> 3;                                   // tiles per residue class (upper bound)
+    const int W = (per + 31) >> 5;                                       // bitmap words per row
+    const int rows = 8 * nb;                                             // row = residue * nb + class
+    uint32_t *bm = lds;                                                  // [rows][W]
+    uint16_t *pre = reinterpret_cast<uint16_t *>(bm + rows * W);         // [rows][W] set bits of the row below word w
+    uint8_t *cls = reinterpret_cast<uint8_t *>(pre + rows * W + ((rows * W) & 1));   // [ntiles]
+    for (int i = tid; i < rows * W; i += 1024) bm[i] = 0;
     if (tid == 0) wmax = 1;
     if (zero14 && tid < 14) zero14[tid] = 0ull;
     __syncthreads();
+    auto work = [&](int t) -> uint32_t { return ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t]; };
     uint32_t m = 0;
-    for (int t0 = 0; t0 < ntiles; t0 += 8 * 1024) {                     // eight independent loads in flight per thread
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int t = t0 + k * 1024 + tid;
-            v[k] = 0;
-            if (t < ntiles) v[k] = ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int t = t0 + k * 1024 + tid;
-            if (t < ntiles) { wk[t] = v[k]; m = max(m, v[k]); }
-        }
-    }
+    for (int t = tid; t < ntiles; t += 1024) m = max(m, work(t));
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
     if ((tid & 63) == 0) atomicMax(&wmax, m);
     __syncthreads();
-    const float scale = 255.0f / (float)wmax;
-    auto bucket = [&](int t) -> int { return (t & 7) * 256 + 255 - (int)((float)wk[t] * scale); };
-    for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[bucket(t)], 1u);
-    __syncthreads();
-    if (tid < 512) {                                                     // eight independent exclusive scans of 256 counters: one wave each
-        const int r = tid >> 6, lane = tid & 63;
-        uint32_t c[4], sm = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { c[i] = hist[r * 256 + 4 * lane + i]; sm += c[i]; }
-        uint32_t incl = sm;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
-        uint32_t run = incl - sm;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { hist[r * 256 + 4 * lane + i] = run; run += c[i]; }
+    const float scale = (float)nb / (float)wmax;
+    for (int t = tid; t < ntiles; t += 1024) {
+        const int c = min(nb - 1, max(0, nb - 1 - (int)((float)work(t) * scale)));     // class 0 = heaviest
+        cls[t] = (uint8_t)c;
+        const int i = t >> 3;
+        atomicOr(&bm[((t & 7) * nb + c) * W + (i >> 5)], 1u << (i & 31));
     }
     __syncthreads();
-    for (int t = tid; t < ntiles; t += 1024) order[8u * atomicAdd(&hist[bucket(t)], 1u) + (uint32_t)(t & 7)] = (uint32_t)t;
+    for (int r = tid; r < rows; r += 1024) {                             // word prefix of every row (W <= 137 words)
+        uint32_t run = 0;
+        for (int w = 0; w < W; ++w) { pre[r * W + w] = (uint16_t)run; run += (uint32_t)__popc(bm[r * W + w]); }
+        rowtot[r] = run;
+    }
+    __syncthreads();
+    if (tid < 8) {                                                       // class starts inside each residue class
+        uint32_t run = 0;
+        for (int c = 0; c < nb; ++c) { rowstart[tid * nb + c] = run; run += rowtot[tid * nb + c]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += 1024) {
+        const int r = (t & 7) * nb + cls[t], i = t >> 3;
+        const uint32_t pos = rowstart[r] + pre[r * W + (i >> 5)] + (uint32_t)__popc(bm[r * W + (i >> 5)] & ((1u << (i & 31)) - 1u));
+        order[8u * pos + (uint32_t)(t & 7)] = (uint32_t)t;
+    }
 }
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s,
-                                    unsigned long long *zero14) {
+                                    unsigned long long *zero14, int buckets) {
     if (ntiles <= 0) return hipSuccess;
-    const size_t lds = sizeof(uint32_t) * (size_t)ntiles;
-    if (lds > 140 * 1024) return hipErrorInvalidValue;                   // 35 840 tiles: beyond 8K images
+    if (ntiles > GS_LPT_MAX_TILES) return hipErrorInvalidValue;          // beyond 8K-class images: the callers keep launch order
+    int nb = buckets > 0 && buckets <= 32 ? buckets : GS_LPT_BUCKETS;
+    const int per = (ntiles + 7) >> 3, W = (per + 31) >> 5;
+    auto lds_of = [&](int b) { return (size_t)8 * b * W * 4 + ((size_t)8 * b * W + 1) * 2 + (size_t)ntiles + 16; };
+    while (nb > 2 && lds_of(nb) > 150 * 1024) nb >>= 1;                  // very large grids: fewer work classes
+    const size_t lds = lds_of(nb);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_lpt_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, order, zero14);
+    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, nb, order, zero14);
     return hipGetLastError();
 }
 
+#ifdef GS_EXPERIMENTS
 hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, work_or_ranges, ranges_mode, ntiles, order, seg);
     return hipGetLastError();
 }
+#endif
 
 // ---------------------------------------------------------------- launchers
 // variant (A/B, tools/abtest.py; 0 = default): units digit = kernel body (backward: 3 transposed LDS reduction (default); 2 the same,
@@ -807,16 +841,27 @@ static size_t debug_extra_lds() {
 }
 
 static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {
+#ifdef GS_EXPERIMENTS
     if (a.queue) return dim3((unsigned)max(1, min(a.grid_waves > 0 ? a.grid_waves : ntiles, ntiles)));
     return dim3(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8);
+#else
+    return dim3(((ntiles + 7) / 8) * 8);
+#endif
 }
 
 static GsCompositeArgs apply_sched_variant(const GsCompositeArgs &a0) {
     GsCompositeArgs a = a0;
+#ifdef GS_EXPERIMENTS
     const int sched = (a.variant / 10) % 10;
     if (sched == 1) { a.queue = nullptr; a.tile_order = nullptr; }
     else if (sched == 2 && a.tile_order_plain) a.tile_order = a.tile_order_plain;      // per-XCD segments in tile order
     else if (sched == 3) { a.queue = nullptr; a.tile_order = a.tile_order_band; }       // plain launch, longest first inside the residue classes
+#else
+    const int sched = (a.variant / 10) % 10;                                            // debug launches (gs_debug_*): 1 = tile order, 3 = the given order
+    a.queue = nullptr;
+    if (sched == 1) a.tile_order = nullptr;
+    else if (sched == 3 && a.tile_order_band) a.tile_order = a.tile_order_band;
+#endif
     return a;
 }
 
@@ -826,9 +871,14 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
+#ifdef GS_EXPERIMENTS
 #define GS_F(E) do { if (a.variant % 10 == 2 && a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 8, true, true>), grid, block, debug_extra_lds(), s, a); \
                      else if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
                      else hipLaunchKernelGGL((composite_fwd_kernel<E, 5, false>), grid, block, debug_extra_lds(), s, a); } while (0)
+#else
+#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
+                     else hipLaunchKernelGGL((composite_fwd_kernel<E, 5, false>), grid, block, debug_extra_lds(), s, a); } while (0)
+#endif
     if (early) GS_F(true); else GS_F(false);
 #undef GS_F
     return hipGetLastError();
@@ -839,25 +889,31 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
     const bool early = a.t_min > 0.0f;
+#ifdef GS_EXPERIMENTS
     if (a.queue && a.variant % 10 != 0 && a.variant % 10 != 3) {           // A/B body: its own resident-wave count
         const int w = gs_composite_resident_waves(1, early, a.g2d_fixed != nullptr, a.cull != 0, a.variant % 10);
         if (w > 0) a.grid_waves = w;
     }
+#endif
     const dim3 grid = composite_grid(a, ntiles), block(64);
-    const int body = (a.variant % 10 == 1 || a.variant % 10 == 2) ? a.variant % 10 : 3;
 #define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, debug_extra_lds(), s, a); \
                                else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, debug_extra_lds(), s, a); } while (0)
 #define GS_B(E, M, Z) do { if (a.g2d_fixed) GS_B2(E, M, true, Z); else GS_B2(E, M, false, Z); } while (0)
+#ifdef GS_EXPERIMENTS
+    const int body = (a.variant % 10 == 1 || a.variant % 10 == 2) ? a.variant % 10 : 3;
     // body 2 holds the sixteen partials of the previous entry across the pixel arithmetic: 96 VGPRs, 5 waves/SIMD (measured slower
-    // than body 3 at 78 VGPRs / 6 waves: the kernel gains more from the sixth wave than from the hidden LDS round trip)
+    // than body 3: the loop gains nothing from the hidden LDS round trip); body 1 is round 1's reduce-scatter tree
     if (body == 2) { if (early) GS_B(true, 5, 2); else GS_B(false, 5, 2); }
-    else if (body == 3) { if (early) GS_B(true, GS_BWD3_MINW, 3); else GS_B(false, GS_BWD3_MINW, 3); }
-    else { if (early) GS_B(true, 1, 1); else GS_B(false, 1, 1); }
+    else if (body == 1) { if (early) GS_B(true, 1, 1); else GS_B(false, 1, 1); }
+    else
+#endif
+    { if (early) GS_B(true, GS_BWD3_MINW, 3); else GS_B(false, GS_BWD3_MINW, 3); }
 #undef GS_B
 #undef GS_B2
     return hipGetLastError();
 }
 
+#ifdef GS_EXPERIMENTS
 // Resident waves of a kernel on this device: occupancy (waves of 64 per CU) x CUs.  The persistent grid is exactly this
 // size, so every launched wave is resident from the start and the queue is the only scheduler.  body: 0 = default.
 typedef void (*CompositeKernel)(GsCompositeArgs);
@@ -891,3 +947,4 @@ int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int 
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(f), 64, 0) != hipSuccess || per_cu <= 0) return 0;
     return per_cu * cus;
 }
+#endif  // GS_EXPERIMENTS

@@ -227,6 +227,10 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, 
     const bool pay_ok = isfinite(rgb[0]) && isfinite(rgb[1]) && isfinite(rgb[2]) && isfinite(sg) && isfinite(mux) && isfinite(muy) &&
                         isfinite(inv0) && isfinite(inv1) && isfinite(inv2) && isfinite(inv3);
     p.mx = mux; p.my = muy; p.sig = sg;
+    // what the composite kernels' inner loops consume, formed once per (gaussian, view) instead of once per (tile, splat):
+    // alpha = exp2(ka dX^2 + kb dX dY + kc dY^2 + l2s)   (same single fp32 operations the staging lanes performed in rounds 1-2)
+    p.l2s = fminf(__builtin_amdgcn_logf(sg), GS_L2S_CAP);
+    p.ka = GS_NEG_HALF_LOG2E * inv0; p.kb = GS_NEG_HALF_LOG2E * (inv1 + inv2); p.kc = GS_NEG_HALF_LOG2E * inv3;
     p.i0 = inv0; p.i1 = inv1; p.i2 = inv2; p.i3 = inv3;
     p.r = rgb[0]; p.g = rgb[1]; p.b = rgb[2];
     if (finite_bb && depth_ok && pay_ok) { p.bbx = gs_pack_i16(bxmin, bxmax); p.bby = gs_pack_i16(bymin, bymax); }

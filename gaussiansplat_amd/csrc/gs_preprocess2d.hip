@@ -3,7 +3,7 @@
 // Forward: preprocess(::GaussianRenderer2D) (reference src/forward.jl:9-33) = computeCov2d_kernel
 // (src/cov2d.jl:3-28: Sigma = R(theta) diag(exp s)^2 R' with +0.3 on the diagonal), computeInvCov2d
 // (src/cov2d.jl:30-45) and computeBB (src/boundingbox.jl:4-36), three launches with a device sync each in the
-// reference, one kernel here.  It emits the SAME 48-byte payload as the 3-D preprocess, so binning and both
+// reference, one kernel here.  It emits the SAME 64-byte payload as the 3-D preprocess, so binning and both
 // composite kernels are shared.  SplatData2D (src/splat.jl:20-26): means 2xN in [0,1]^2 (pixel position
 // (w*mx, h*my), splat.jl:337-339), scales 2xN (log), rotations 1xN, opacities 1xN (used raw, splat.jl:341),
 // colors 3xN.  The reference hands the [0,1] means to computeBB (forward.jl:25-31), which would pin every box
@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_kernel(GsPreprocess2DArgs
     const bool pay_ok = isfinite(cr) && isfinite(cg) && isfinite(cb) && isfinite(sg) && isfinite(mux) && isfinite(muy) &&
                         isfinite(inv0) && isfinite(inv1) && isfinite(inv2) && isfinite(inv3);
     p.mx = mux; p.my = muy; p.sig = sg;
+    p.l2s = fminf(__builtin_amdgcn_logf(sg), GS_L2S_CAP);             // log2; sg == 0 gives -inf: alpha = exp2(-inf) = 0
+    p.ka = GS_NEG_HALF_LOG2E * inv0; p.kb = GS_NEG_HALF_LOG2E * (inv1 + inv2); p.kc = GS_NEG_HALF_LOG2E * inv3;
     p.i0 = inv0; p.i1 = inv1; p.i2 = inv2; p.i3 = inv3;
     p.r = cr; p.g = cg; p.b = cb;
     if (finite_bb && pay_ok) { p.bbx = gs2_pack_i16(bxmin, bxmax); p.bby = gs2_pack_i16(bymin, bymax); }
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_bwd_kernel(GsPreprocess2D
     float g2[10];
     if (a.g2d_fixed) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) g2[i] = (float)((double)a.g2d_fixed[10 * g + i] * gs_fixed_inv(i));
+        for (int i = 0; i < 10; ++i) g2[i] = (float)((double)a.g2d_fixed[GS_G2D_STRIDE * g + i] * gs_fixed_inv(i));
     } else {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) g2[i] = a.g2d[10 * g + i];
+        for (int i = 0; i < 10; ++i) g2[i] = a.g2d[GS_G2D_STRIDE * g + i];
     }
     // forward pieces again (cheaper than storing them): Sigma = Wm Wm' + 0.3 I, M = Sigma^-1
     float sn, cs;

@@ -36,10 +36,11 @@ __constant__ float bC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457045
 __device__ __forceinline__ void load_g2(const GsPreprocessBwdArgs &a, int64_t g, float (&o)[10]) {
     if (a.g2d_fixed) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) o[i] = (float)((double)a.g2d_fixed[10 * g + i] * gs_fixed_inv(i));
-    } else {
-#pragma unroll
-        for (int i = 0; i < 10; ++i) o[i] = a.g2d[10 * g + i];
+        for (int i = 0; i < 10; ++i) o[i] = (float)((double)a.g2d_fixed[GS_G2D_STRIDE * g + i] * gs_fixed_inv(i));
+    } else {                                                           // one 64-byte row: three 16-byte loads
+        const float4 *r = reinterpret_cast<const float4 *>(a.g2d + GS_G2D_STRIDE * g);
+        const float4 v0 = r[0], v1 = r[1], v2 = r[2];
+        o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w; o[8] = v2.x; o[9] = v2.y;
     }
 }
 
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void gs_pack_drgb_kernel(const float *__restri
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over 3n
     if (i >= 3 * n) return;
     const int64_t g = i / 3; const int c = (int)(i - 3 * g);
-    out[i] = g2d_fixed ? (float)((double)g2d_fixed[10 * g + c] * GS_FIXED_INV) : g2d[10 * g + c];
+    out[i] = g2d_fixed ? (float)((double)g2d_fixed[GS_G2D_STRIDE * g + c] * GS_FIXED_INV) : g2d[GS_G2D_STRIDE * g + c];
 }
 
 // cams: nviews records of 38 floats {T[16], P[16], eye[3], lookAt[3]}; drgb: [nviews][3n]; the direction and the
@@ -416,13 +417,14 @@ hipError_t gs_launch_sh_from_views(int64_t n, int sh_degree, const float *means,
     return hipGetLastError();
 }
 
-hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s) {
+hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s, int phases) {
     if (a.n <= 0) return hipSuccess;
     const dim3 block(256), grid((unsigned)((a.n + 255) / 256));
     const int K = (a.sh_degree + 1) * (a.sh_degree + 1);
     const size_t lds = sizeof(float) * 256 * (3 * K + 1);
 #define GS_SH(D) do { if (a.overwrite) hipLaunchKernelGGL((gs_sh_bwd_kernel<D, true>), grid, block, lds, s, a, cam); \
                       else hipLaunchKernelGGL((gs_sh_bwd_kernel<D, false>), grid, block, lds, s, a, cam); } while (0)
+    if (phases & 1)
     switch (a.sh_degree) {
         case 0: GS_SH(0); break;
         case 1: GS_SH(1); break;
@@ -430,7 +432,9 @@ hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera
         case 3: GS_SH(3); break;
         default: return hipErrorInvalidValue;
     }
-    if (a.overwrite) hipLaunchKernelGGL(gs_geom_bwd_kernel<true>, grid, block, 0, s, a, cam);
-    else hipLaunchKernelGGL(gs_geom_bwd_kernel<false>, grid, block, 0, s, a, cam);
+    if (phases & 2) {
+        if (a.overwrite) hipLaunchKernelGGL(gs_geom_bwd_kernel<true>, grid, block, 0, s, a, cam);
+        else hipLaunchKernelGGL(gs_geom_bwd_kernel<false>, grid, block, 0, s, a, cam);
+    }
     return hipGetLastError();
 }

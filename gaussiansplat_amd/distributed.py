@@ -39,11 +39,19 @@ def shard_views(num_views: int, world: int, rank: int) -> list[int]:
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
-def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=None, sync: str = "allreduce") -> "torch.Tensor":
-    """One data-parallel step over a view batch.  Returns the flat gradient buffer summed over all views
-    (identical on every rank; the caller applies its optimiser and the next step starts with reset()).
-    sync = "allreduce": one all-reduce of the whole buffer; "factored": see the module docstring (needs a renderer
-    with render_view_factored / color_slots / sh_from_views, and the same number of views on every rank)."""
+def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=None, sync: str = "allreduce",
+                    overlap: bool = True) -> "torch.Tensor":
+    """One data-parallel step over a view batch (8 views on 1 / 2 / 4 / 8 GPUs = 8 / 4 / 2 / 1 views per rank, rendered
+    one after the other with the gradients ACCUMULATING, then the exchange).  Returns the flat gradient buffer summed over all
+    views (identical on every rank; the caller applies its optimiser and the next step starts with reset()).
+    sync = "allreduce": the sum of the whole flat buffer.  With `overlap` and a renderer that can split its last backward
+    (render_view_until_sh / finish_geometry: the HIP renderer) the buffer is reduced as its two contiguous segments: the Δshs
+    segment (81 % of the bytes at SH degree 3) is final as soon as the last view's SH kernel has run, so its all-reduce is
+    started there (async: RCCL's own stream, event-ordered behind the kernel) and runs beside the geometry chain; the
+    all-reduce of the 11 N geometry floats follows.  Same sums, bit for bit, as ONE all-reduce of the whole buffer -- an
+    all-reduce is element-wise.  overlap = False: literally one collective.
+    sync = "factored": see the module docstring (needs a renderer with render_view_factored / color_slots / sh_from_views, and
+    the same number of views on every rank)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -51,9 +59,17 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
     mine = shard_views(len(cameras), world, rank)
     r.reset()
     if sync == "allreduce":
-        for v in mine:
+        split = world > 1 and overlap and len(mine) > 0 and hasattr(r, "render_view_until_sh")
+        for v in (mine[:-1] if split else mine):
             r.render_view(cameras[v], dCs[v])
-        if world > 1:
+        if split:
+            geo = r.geometry_floats
+            r.render_view_until_sh(cameras[mine[-1]], dCs[mine[-1]])        # ... composite adjoint, SH kernel: Δshs is final
+            work = dist.all_reduce(r.flat[geo:], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            r.finish_geometry()                                             # the geometry chain runs beside the collective
+            dist.all_reduce(r.flat[:geo], op=dist.ReduceOp.SUM, group=group)
+            work.wait()
+        elif world > 1:
             dist.all_reduce(r.flat, op=dist.ReduceOp.SUM, group=group)      # the ONE collective of the step
         return r.flat
     if sync != "factored":
@@ -95,6 +111,20 @@ class HipViewRenderer:
         R.compactIdxs(self.r)
         R.forward(self.r, tps)
         R.backward(self.r, dC)
+
+    # ---- the last view of a rank in two steps (multi_view_step(overlap=True))
+    def render_view_until_sh(self, camera, dC) -> None:
+        from . import renderer as R
+        tps = R.preprocess(self.r, camera)
+        R.compactIdxs(self.r)
+        R.forward(self.r, tps)
+        self._dC = dC
+        R.backward(self.r, dC, phase="composite")
+        R.backward(self.r, dC, phase="params_sh")
+
+    def finish_geometry(self) -> None:
+        from . import renderer as R
+        R.backward(self.r, self._dC, phase="params_geom")
 
     # ---- colour-factored exchange
     @property

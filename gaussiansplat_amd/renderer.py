@@ -105,7 +105,7 @@ def initGrads(splatData: SplatData3D) -> SplatGrads3D:
 class GaussianRenderer3D:               # renderer.jl:205-219
     def __init__(self, splatData: SplatData3D, imgSize, sh_degree: int, device: int = 0, order: int = B.ORDER_DEPTH_DESC,
                  t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False, deterministic: bool = False,
-                 alpha_cull: bool = True, rank_mode: int = 1, slab_mode: int = 1, schedule: int = 3):
+                 alpha_cull: bool = True, rank_mode: int = 1, slab_mode: int = 1, schedule: int = 0, **ctx_kw):
         import torch
         self.splatData = splatData
         self._splatGrads = initGrads(splatData)
@@ -118,7 +118,7 @@ class GaussianRenderer3D:               # renderer.jl:205-219
         self.sh_degree = sh_degree
         self.camera: Camera | None = None
         self.ctx = B.Context(device=device, order=order, t_min=t_min, export_debug=export_debug, profile_stages=profile_stages,
-                             deterministic=deterministic, alpha_cull=alpha_cull, rank_mode=rank_mode, slab_mode=slab_mode, schedule=schedule)
+                             deterministic=deterministic, alpha_cull=alpha_cull, rank_mode=rank_mode, slab_mode=slab_mode, schedule=schedule, **ctx_kw)
         # the library enqueues on the caller's CURRENT torch stream (re-read at every API call), like any torch
         # op: no cross-stream fences, so consecutive calls run back to back on the GPU
         self._stream_handle = None
@@ -157,6 +157,13 @@ class GaussianRenderer3D:               # renderer.jl:205-219
         H, W = self.transmittance.shape
         self.ctx.set_camera(compute_transform(cam), compute_projection(cam, W, H), float(np.float32(cam.fx)), float(np.float32(cam.fy)),
                             float(np.float32(cam.near)), float(np.float32(cam.far)), cam.eye, cam.lookAt, W, H)
+        # the camera's id (camera.jl:10-22; `id` of cameras.json) names the view slot: a training loop cycles over a fixed
+        # camera set and the library launches the forward's tiles heaviest-first by what the same view measured last time
+        slot = getattr(cam, "id", None)
+        slot = int(slot) if isinstance(slot, (int, np.integer)) and 0 <= int(slot) < B.GS_MAX_VIEW_SLOTS else -1
+        if slot != getattr(self, "_view_slot", None):
+            self.ctx.set_view_slot(slot)
+            self._view_slot = slot
 
     # scratch arrays of the reference struct, fetched on demand (export_debug for the fp32 ones)
     @property
@@ -315,31 +322,49 @@ def compactIdxs(renderer, threads=(16, 16), blocks=None):
     renderer.ctx.bin(int(gx), int(gy))
 
 
+def _bind_outputs(renderer):
+    """renderer.imageData / renderer.transmittance ARE the library's output buffers (gs_bind_outputs: no copy).  The raw
+    pointers are re-read at every forward / backward: if the caller replaced a tensor since, the new one is bound (and a
+    backward then refuses to run on a forward that wrote somewhere else)."""
+    img, tr = renderer.imageData, renderer.transmittance
+    H, W = tr.shape
+    if tuple(img.shape) != (3, H, W) or not img.is_contiguous() or not tr.is_contiguous():
+        raise ValueError("renderer.imageData must be a contiguous [3, H, W] tensor matching renderer.transmittance [H, W]")
+    key = (img.data_ptr(), tr.data_ptr())
+    if getattr(renderer, "_bound_out", None) != key:
+        renderer.ctx.bind_outputs(*key)                         # (invalidates the ctx's forward state: did_fwd = false)
+        renderer._bound_out = key
+    return key
+
+
 def forward(renderer, tps=None, threads=(16, 16), blocks=None):
-    """forward.jl:163-198: writes renderer.imageData and renderer.transmittance in place."""
+    """forward.jl:163-198: writes renderer.imageData and renderer.transmittance in place.
+    Contract: the two tensors stay the library's buffers until the frame's last backward -- the backward reads the rendered
+    colours from renderer.imageData, so editing it in place between forward and backward changes the gradients, and
+    replacing it makes backward() raise (render again first)."""
     renderer._begin()
-    ip, tp = renderer.imageData.data_ptr(), renderer.transmittance.data_ptr()
-    if getattr(renderer, "_bound_out", None) != (ip, tp):       # imageData / transmittance ARE the library's output buffers: no copy
-        renderer.ctx.bind_outputs(ip, tp)
-        renderer._bound_out = (ip, tp)
+    ip, tp = _bind_outputs(renderer)
     renderer.ctx.forward_device(ip, tp)
 
 
 def backward(renderer, ΔC, skip_shs: bool = False, phase: str = "all"):
     """backward.jl:3-38: ΔC has the shape of imageData; accumulates into renderer.splatGrads.
     skip_shs (3-D renderer, colour-factored multi-GPU exchange): leave Δshs alone -- the caller rebuilds it from the
-    per-view colour gradients (distributed.multi_view_step(sync="factored"))."""
+    per-view colour gradients (distributed.multi_view_step(sync="factored")).
+    phase: "all" (default); "composite" then "params" (split backward); or "composite", "params_sh", "params_geom": the
+    per-gaussian chain in two steps, so that the all-reduce of Δshs can start while the geometry chain still runs."""
     import torch
     dC = ΔC if isinstance(ΔC, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(ΔC, np.float32))
     dC = dC.to(renderer.imageData.device, torch.float32).contiguous()
     assert dC.shape == renderer.imageData.shape
     renderer._dC_keepalive = dC
     renderer._begin()
+    _bind_outputs(renderer)                                     # a replaced imageData is caught here: the ctx then reports "gs_forward first"
     grads = renderer._grads
     if skip_shs:
         grads = B.GsGrads(grads.d_means, grads.d_scales, grads.d_quats, grads.d_opacities, None)
     renderer.ctx.backward(dC.data_ptr(), grads, overwrite=renderer._grads_lazy_zero, phase=phase)
-    if phase != "composite":
+    if phase not in ("composite", "params_sh"):                 # "params_sh" is followed by "params_geom" with the same overwrite flag
         renderer._grads_lazy_zero = False
 
 

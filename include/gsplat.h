@@ -29,7 +29,10 @@
  *     no per-frame allocation once sizes are stable).
  *   - one ctx = one GPU = one stream; a ctx is not thread-safe, different ctxs are.
  *   - all work is enqueued on the ctx stream; functions that return data to HOST buffers
- *     synchronise that stream before returning, device-buffer variants do not.
+ *     synchronise that stream before returning, device-buffer variants do not.  gs_bin does not wait for the GPU either
+ *     (from a ctx's second frame on): the tile lists are enqueued with the buffer sizes of the previous frame while the
+ *     frame's instance counts are still on their way to the host; gs_forward reads them after it has enqueued the
+ *     composite and, in the rare case that a list outgrew its buffer, rebuilds lists and image with larger ones.
  *   - there is NO CPU fallback: without a HIP device gs_create fails with GS_ERR_NO_DEVICE.
  */
 #ifndef GSPLAT_H
@@ -41,7 +44,10 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+/* 2: gs_config carries abi_version (gs_create refuses any other value: a caller built against another header fails loudly
+ *    instead of running with shifted fields); schedule 0 now means "library default"; view slots (gs_set_view_slot);
+ *    speculative binning (no host wait inside gs_bin); GS_BWD_PARAMS_SH / _GEOM; 64-byte payload and gradient rows. */
+#define GS_ABI_VERSION 2
 
 typedef enum {
     GS_OK = 0,
@@ -64,6 +70,7 @@ typedef enum { GS_ORDER_INDEX = 0, GS_ORDER_DEPTH_DESC = 1, GS_ORDER_DEPTH_ASC =
 
 typedef struct {
     int32_t struct_size;      /* = sizeof(gs_config); ABI guard                              */
+    int32_t abi_version;      /* = GS_ABI_VERSION of the header the caller was built with    */
     int32_t tile_size;        /* threads=(16,16) of examples/main.jl:9; only 16 is supported */
     int32_t order;            /* gs_order; default GS_ORDER_DEPTH_DESC                       */
     float   t_min;            /* transmittance early-out: a pixel stops taking splats once
@@ -91,14 +98,17 @@ typedef struct {
                                  -- a no-op in the reference's own fp32 arithmetic (T*(1-alpha) == T, colour term
                                  < 7.5e-9*|rgb|).  The lists (gs_bin) are unchanged.  0: evaluate every entry. */
     int32_t schedule;         /* composite kernels (speed only: every mode gives the same image and, up to atomic order, gradients):
-                                 3 (default) one wave per tile, plain launch; the backward's tiles are permuted heaviest first
-                                   (by the forward's per-tile count of evaluated entries) inside each class tile % 8, i.e. on the
-                                   XCD the launch order would have used -- no tail, same L2 sharing (C3: 0.84 -> 0.74 ms);
-                                 4 as 3, and the forward's tiles by the work the PREVIOUS forward of this ctx measured (opt-in:
-                                   pays when consecutive frames see similar views, C3 same view: forward 0.38 -> 0.33 ms);
-                                 1 one wave per tile in launch order;
-                                 0 persistent waves pull tiles from per-XCD ticket counters, heaviest first; 2 the same in
-                                   arbitrary order (both measured slower: profiles/)                           */
+                                 0 the library default (= 3);
+                                 3 one wave per tile, plain launch over a longest-first permutation of the tiles that keeps
+                                   tile % 8 (the XCD a block lands on): the backward by the forward's per-tile count of evaluated
+                                   entries of the same frame (C3: 0.84 -> 0.74 ms); the forward by the count the last forward
+                                   rendered under the same VIEW SLOT measured (gs_set_view_slot: training cycles over a fixed
+                                   camera set), in tile order when the slot has no history yet;
+                                 4 as 3, and a forward without slot history uses the work of this ctx's PREVIOUS forward
+                                   (pays when consecutive frames see similar views);
+                                 1 one wave per tile in launch (tile) order.
+                                 Builds with -DGS_EXPERIMENTS also have 10 / 12: persistent waves pulling tiles from per-XCD ticket
+                                 counters, heaviest first / in tile order (both measured slower: profiles/)     */
     int32_t slab_mode;        /* binning in depth slabs (speed only; image, transmittance and deterministic-mode gradients are
                                  bit-identical either way): 1 (default) automatic -- when the previous frame walked under 3 % of
                                  its tile instances before the transmittance early-out stopped every tile (with the two-level
@@ -107,8 +117,14 @@ typedef struct {
                                  slabs; 0 always one round (the classic full lists).  In a slab frame the per-tile lists are
                                  spread over the rounds, so GS_ARR_TILE_RANGES / SORTED_IDS / SORTED_KEYS are unavailable (a
                                  ctx's first frame is always a classic one).                                              */
-    int32_t reserved[4];
+    float   slab_max_ratio;   /* slab_mode 1 engages when the previous frame walked less than this share of its tile instances;
+                                 0 = the library default (0.03, where three rounds start to beat one with the two-level binning)  */
+    float   slab_fractions[3];/* tests / experiments: != 0 forces depth slabs that end at these fractions of the depth order
+                                 (0 < f1 [< f2 [< f3]] < 1), whatever the previous frame walked                               */
+    int32_t debug_flags;      /* GS_DEBUG_* bits; 0 in production                                                              */
+    int32_t reserved[6];      /* sizeof(gs_config) == 96                                                                       */
 } gs_config;
+#define GS_DEBUG_WIDE_CURSORS 1   /* two-level binning: 64-bit list cursors although the lists fit 32-bit byte offsets (tests)    */
 
 typedef struct gs_ctx gs_ctx;
 
@@ -155,6 +171,14 @@ int gs_set_camera(gs_ctx *ctx, const float T[16], const float P[16], float fx, f
                   float near_, float far_, const float eye[3], const float lookAt[3],
                   int32_t W, int32_t H);
 
+/* Optional: name the view about to be rendered (call before gs_preprocess; e.g. the `id` of the camera in cameras.json,
+ * camera.jl:119-151).  A training loop cycles over a fixed camera set, and how the work of a frame is spread over the tiles is a
+ * property of the view: the ctx keeps, per slot 0 .. GS_MAX_VIEW_SLOTS - 1, the longest-first tile order of the last frame
+ * rendered under that slot and launches the next forward of the same slot in that order (gs_config.schedule 3 / 4).  Speed
+ * only -- a stale or wrong slot costs nothing but the benefit.  slot < 0 (default): the frame belongs to no slot. */
+#define GS_MAX_VIEW_SLOTS 64
+int gs_set_view_slot(gs_ctx *ctx, int32_t slot);
+
 /* preprocess(renderer): projection, 2-D covariance + inverse, bounding box, SH colour,
  * sigmoid, depth key, tile rectangle. */
 int gs_preprocess(gs_ctx *ctx);
@@ -198,6 +222,12 @@ int gs_backward(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads);
  * GS_ARR_GRAD2D; grads may be NULL); GS_BWD_PARAMS_ONLY runs only the chain from those sums to `grads` (dC may be NULL). */
 #define GS_BWD_COMPOSITE_ONLY 2
 #define GS_BWD_PARAMS_ONLY 4
+/* With GS_BWD_PARAMS_ONLY, the chain in two steps so that a multi-GPU host can start the all-reduce of d_shs (81 % of the
+ * gradient buffer at SH degree 3) while the geometry chain still runs: GS_BWD_PARAMS_SH runs only the SH / colour kernel
+ * (d_shs and the colour -> position term), GS_BWD_PARAMS_GEOM only the geometry chain (after a GS_BWD_PARAMS_SH call of the
+ * same frame).  Neither bit = both, in that order. */
+#define GS_BWD_PARAMS_SH 8
+#define GS_BWD_PARAMS_GEOM 16
 int gs_backward_ex(gs_ctx *ctx, const float *dC, int mem, const gs_grads *grads, int flags);
 /* Backward AND the optimiser step of train.jl:39-46 in one pass (3-D renderer, single-view steps): the per-gaussian kernels apply
  * param = fma(-lr, gradient, param) to the resident model instead of storing gradients -- bit-identical to gs_backward
@@ -276,7 +306,8 @@ typedef enum {
 } gs_array;
 
 int64_t gs_num_gaussians(const gs_ctx *ctx);
-int64_t gs_num_instances(const gs_ctx *ctx);      /* I of the last gs_bin */
+int64_t gs_num_instances(gs_ctx *ctx);            /* I of the last gs_bin (waits for the frame's totals if they are still in flight) */
+int64_t gs_num_coarse_instances(gs_ctx *ctx);      /* two-level binning: (super-tile, gaussian) instances of the last gs_bin, else 0 */
 int gs_num_rounds(const gs_ctx *ctx);             /* binning rounds of the last gs_bin: 1 = classic full lists, 2..4 = depth slabs */
 
 /* Copy an internal array to a HOST buffer of `bytes` bytes (synchronises). */
@@ -313,8 +344,8 @@ int gs_debug_time_composite(gs_ctx *ctx, int which, int variant, int reps, float
  * walked << 32 | evaluated}.  tools/tile_tail.py turns it into the occupancy-over-time and tail summary under profiles/. */
 int gs_debug_tile_clock(gs_ctx *ctx, int which, int variant, uint64_t *out);
 
-/* 0: the LDS-atomic rank passed the lane-order probe at gs_create (or rank_mode = 1 was asked for: -1); 1: the probe
- * failed on this device and ballots were forced. */
+/* -1: the lane-order probe of the LDS-atomic rank was not run (rank_mode = 1 was asked for); 0: it ran at gs_create and
+ * passed; 1: it failed on this device and ballots were forced. */
 int gs_rank_probe_result(const gs_ctx *ctx);
 
 #ifdef __cplusplus

@@ -18,8 +18,11 @@ const GS_MEM_HOST = Cint(0)
 const GS_MEM_DEVICE = Cint(1)
 @enum GsOrder::Cint GS_ORDER_INDEX = 0 GS_ORDER_DEPTH_DESC = 1 GS_ORDER_DEPTH_ASC = 2
 
-mutable struct GsConfig                      # must mirror gs_config (64 bytes)
+const GS_ABI_VERSION = Cint(2)               # include/gsplat.h: the header this glue is written against
+
+mutable struct GsConfig                      # must mirror gs_config (96 bytes)
     struct_size::Int32
+    abi_version::Int32
     tile_size::Int32
     order::Int32
     t_min::Float32
@@ -31,7 +34,10 @@ mutable struct GsConfig                      # must mirror gs_config (64 bytes)
     alpha_cull::Int32
     schedule::Int32
     slab_mode::Int32
-    reserved::NTuple{4, Int32}
+    slab_max_ratio::Float32
+    slab_fractions::NTuple{3, Float32}
+    debug_flags::Int32
+    reserved::NTuple{6, Int32}
 end
 
 struct GsGrads                               # gs_grads: device pointers, may be C_NULL
@@ -57,8 +63,11 @@ function check(r::HipRenderer, rc::Cint)
 end
 
 function defaultConfig()
-    cfg = GsConfig(0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, ntuple(_ -> Int32(0), 4))
+    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, ntuple(_ -> Int32(0), 6))
     ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
+    # a library built from another header would read this struct with shifted fields: refuse it here, loudly
+    (hip_abiVersion() == GS_ABI_VERSION && cfg.abi_version == GS_ABI_VERSION && cfg.struct_size == sizeof(GsConfig)) ||
+        error("libgsplat_hip reports ABI $(hip_abiVersion()), this glue is written for $(GS_ABI_VERSION): rebuild one of them")
     return cfg
 end
 
@@ -109,6 +118,12 @@ function hip_preprocess(r::HipRenderer, camera, T::AbstractMatrix, P::AbstractMa
                    r.ctx, Tm, Pm, camera.fx, camera.fy, camera.near, camera.far, eye, lookAt, r.W, r.H))
     check(r, ccall((:gs_preprocess, libgs), Cint, (Ptr{Cvoid},), r.ctx))
 end
+
+# optional, before hip_preprocess: name the view about to be rendered (e.g. the `id` of the camera, src/camera.jl:10-22,119-151).
+# A training loop cycles over a fixed camera set; the library launches the forward's tiles heaviest-first by what the last frame
+# rendered under the same slot measured.  Speed only; slot < 0: none.
+hip_setViewSlot(r::HipRenderer, slot::Integer) =
+    check(r, ccall((:gs_set_view_slot, libgs), Cint, (Ptr{Cvoid}, Int32), r.ctx, slot))
 
 # compactIdxs(renderer, threads, blocks)  (src/forward.jl:118-161)
 hip_compactIdxs(r::HipRenderer, threads, blocks) =
@@ -180,6 +195,8 @@ hip_resetGrads!(r::HipRenderer, grads::GsGrads) =
 const GS_BWD_OVERWRITE = Cint(1)
 const GS_BWD_COMPOSITE_ONLY = Cint(2)
 const GS_BWD_PARAMS_ONLY = Cint(4)
+const GS_BWD_PARAMS_SH = Cint(8)        # with GS_BWD_PARAMS_ONLY: only the SH / colour kernel (then all-reduce Δshs while ...)
+const GS_BWD_PARAMS_GEOM = Cint(16)     # ... with GS_BWD_PARAMS_ONLY: only the geometry chain
 hip_backwardEx!(r::HipRenderer, ΔC::Ptr{Float32}, grads::GsGrads, flags::Integer) =
     check(r, ccall((:gs_backward_ex, libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}, Cint, Ref{GsGrads}, Cint),
                    r.ctx, ΔC, GS_MEM_DEVICE, grads, flags))
@@ -207,6 +224,7 @@ hip_commDestroy(r::HipRenderer) = check(r, ccall((:gs_comm_destroy, libgs), Cint
 
 hip_numGaussians(r::HipRenderer) = ccall((:gs_num_gaussians, libgs), Int64, (Ptr{Cvoid},), r.ctx)
 hip_numInstances(r::HipRenderer) = ccall((:gs_num_instances, libgs), Int64, (Ptr{Cvoid},), r.ctx)
+hip_numCoarseInstances(r::HipRenderer) = ccall((:gs_num_coarse_instances, libgs), Int64, (Ptr{Cvoid},), r.ctx)
 hip_abiVersion() = ccall((:gs_abi_version, libgs), Cint, ())
 hip_numRounds(r::HipRenderer) = ccall((:gs_num_rounds, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 

@@ -37,6 +37,24 @@ class OracleViewRenderer:
         self.flat += torch.from_numpy(np.concatenate([g[k].reshape(-1) for k in ("means", "scales", "quats", "opacities", "shs")]))
 
 
+class OracleSplitRenderer(OracleViewRenderer):
+    """The two-step last view of distributed.multi_view_step(overlap=True): Δshs is final after the SH step (its all-reduce
+    is started there), the geometry part lands afterwards."""
+
+    @property
+    def geometry_floats(self):
+        return 11 * N
+
+    def render_view_until_sh(self, cam, dC):
+        before = self.flat.clone()
+        OracleViewRenderer.render_view(self, cam, dC)
+        self._geo = self.flat[:11 * N] - before[:11 * N]
+        self.flat[:11 * N] = before[:11 * N]                          # the geometry chain has not run yet
+
+    def finish_geometry(self):
+        self.flat[:11 * N] += self._geo
+
+
 class OracleFactoredRenderer(OracleViewRenderer):
     """The colour-factored protocol of distributed.multi_view_step on the CPU: geometry gradients and d rgb per view
     from the oracle's adjoint, SH gradients rebuilt as sum_v basis(dir_v) (x) d rgb_v in NumPy (fp64)."""
@@ -94,6 +112,18 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_split(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cams, dCs = _views()
+        flat = D.multi_view_step(OracleSplitRenderer(), cams, dCs, overlap=True)
+        if rank == 1:
+            np.save(out, flat.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker_factored(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -141,3 +171,18 @@ def test_two_rank_gloo_allreduce_equals_single_process(tmp_path):
     got = np.load(out)
     assert np.allclose(got, single.flat.numpy(), rtol=1e-12, atol=1e-14)
     assert np.abs(got).max() > 0
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_segment_allreduce_equals_one_allreduce(tmp_path):
+    """overlap=True reduces the flat buffer as its two segments (Δshs started before the geometry part of the last view exists):
+    the result must equal the single all-reduce of the whole buffer bit for bit (an all-reduce is element-wise)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out_a, out_b = str(tmp_path / "flat_split.npy"), str(tmp_path / "flat_one.npy")
+    mp.spawn(_worker_split, args=(2, port, out_a), nprocs=2, join=True)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, out_b), nprocs=2, join=True)
+    a, b = np.load(out_a), np.load(out_b)
+    assert np.array_equal(a[11 * N:], b[11 * N:])                        # the Δshs segment: the same two-rank sums
+    assert np.allclose(a[:11 * N], b[:11 * N], rtol=1e-13, atol=1e-15)   # the split renderer forms the geometry part as (x + g) - x + ...
+    assert np.abs(a).max() > 0

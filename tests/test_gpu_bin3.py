@@ -17,16 +17,17 @@ from common import hip_context, scene_and_cameras
 pytestmark = pytest.mark.gpu
 
 
-def _check_lists(O, B, sc, cam, T, P, ocam, W, H, deg, order, bin_path=0):
+def _check_lists(O, B, sc, cam, T, P, ocam, W, H, deg, order, bin_path=0, **kw):
     gx, gy = (W + 15) // 16, (H + 15) // 16
     pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam)
-    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0, bin_path=bin_path)
-    ctx.preprocess(); ctx.bin()
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0, bin_path=bin_path, **kw)
     ranges, ids, okeys = O.bin_lists(pre["bbs"], pre["tps"], order, 16, gx, gy)
-    assert ctx.num_instances == len(ids)
-    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ranges)
-    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ids)
-    assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), okeys)
+    for frame in range(2):          # frame 0: the host reads the totals before the lists; frame 1: lists enqueued speculatively
+        ctx.preprocess(); ctx.bin()
+        assert ctx.num_instances == len(ids)
+        assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ranges), frame
+        assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ids), frame
+        assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), okeys), frame
     n_inst = ctx.num_instances
     ctx.close()
     return n_inst
@@ -79,23 +80,18 @@ def test_4k_grid_small_scene(oracle):
 
 def test_8k_grid_and_wide_cursors(oracle):
     """7680 x 4320: 480 x 270 tiles = 60 x 34 super-tiles (2040: 256 positions per level-1 workgroup, > 64 KB of LDS; the
-    backward's tile order kernel is beyond its LDS and the launch order is used).  GS_BIN3_WIDE forces the 64-bit cursors
-    that lists beyond 4 GB take."""
-    import os
+    backward's tile order kernel is beyond its LDS and the launch order is used).  GS_DEBUG_WIDE_CURSORS (gs_config.debug_flags)
+    forces the 64-bit cursors that lists beyond 4 GB take."""
     from gaussiansplat_amd import backend as B, synthetic
     n, W, H = 3_000, 7680, 4320
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, 0, 78)
     sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(2.0)).astype(np.float32)
     a = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
-    os.environ["GS_BIN3_WIDE"] = "1"
-    try:
-        b = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
-        n2, W2, H2 = 5_000, 640, 480
-        sc2, cam2, T2, P2, ocam2 = scene_and_cameras(n2, W2, H2, 0, 79)
-        sc2 = dict(sc2); sc2["scales"] = (sc2["scales"] + np.float32(1.5)).astype(np.float32)
-        _check_lists(oracle, B, sc2, cam2, T2, P2, ocam2, W2, H2, 0, 1)
-    finally:
-        os.environ.pop("GS_BIN3_WIDE", None)
+    b = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, debug_flags=B.GS_DEBUG_WIDE_CURSORS)
+    n2, W2, H2 = 5_000, 640, 480
+    sc2, cam2, T2, P2, ocam2 = scene_and_cameras(n2, W2, H2, 0, 79)
+    sc2 = dict(sc2); sc2["scales"] = (sc2["scales"] + np.float32(1.5)).astype(np.float32)
+    _check_lists(oracle, B, sc2, cam2, T2, P2, ocam2, W2, H2, 0, 1, debug_flags=B.GS_DEBUG_WIDE_CURSORS)
     assert a == b
     # forward + backward run at this size (plain tile order in the backward)
     ctx = hip_context(sc, cam, T, P, W, H, 0, t_min=1e-5)
@@ -126,3 +122,38 @@ def test_render_through_two_level_lists_matches_radix_lists(oracle):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     for k in out[0][2]:
         assert np.array_equal(out[0][2][k], out[1][2][k]), k        # deterministic mode: bitwise
+
+
+def test_speculative_lists_survive_growth_and_shrinkage(oracle):
+    """From a ctx's second frame on gs_bin enqueues the tile lists against the capacities of the buffers it has, before the
+    host has seen the frame's instance counts; gs_forward reads them after it has enqueued the composite.  A frame whose
+    lists outgrow a buffer must list nothing (no out-of-bounds store), be detected, and be redone with larger buffers --
+    lists, image and gradients equal to the oracle's for a scene that grows 30-fold, shrinks again and grows a little."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = 6000, 480, 352, 1
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 123)
+    dC = synthetic.make_dC(W, H, 9)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, deterministic=True)
+    base = sc["scales"].copy()
+    counts = []
+    for shift in (0.0, 1.8, -0.5, 0.1, 0.12):
+        s2 = dict(sc); s2["scales"] = (base + np.float32(shift)).astype(np.float32)
+        ctx.set_model_host(s2["means"], s2["scales"], s2["quats"], s2["opacities"], s2["shs"].reshape(n, -1), deg)
+        ctx.preprocess(); ctx.bin()
+        img, tr = ctx.forward_host()
+        g = ctx.grads_alloc(); ctx.backward(dC, g)
+        grads = ctx.grads_read(g, deg)
+        ref = O.render(s2["means"], s2["scales"], s2["quats"], s2["opacities"], s2["shs"], deg, ocam, order=1, t_min=1e-5)
+        assert ctx.num_instances == len(ref["ids"])
+        assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ref["ranges"]), shift
+        assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ref["ids"]), shift
+        assert np.all(np.abs(img - ref["image"]) <= 1e-4 + 1e-4 * np.abs(ref["image"])), shift
+        gref = O.backward(s2["means"], s2["scales"], s2["quats"], s2["opacities"], s2["shs"], deg, ocam, ref["ranges"], ref["ids"], dC, t_min=1e-5)
+        for k in ("means", "scales", "quats", "opacities", "shs"):
+            a, b = grads[k].astype(np.float64).reshape(-1), gref[k].reshape(-1)
+            assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(b), 1e-30), (shift, k)
+        counts.append(ctx.num_instances)
+    assert counts[1] > 8 * counts[0] and counts[2] < counts[0]             # the growth really outran the 12.5 % slack of the buffers
+    ctx.close()

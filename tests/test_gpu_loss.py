@@ -28,6 +28,34 @@ def test_loss_and_gradient_match_oracle(W, H):
     ctx.close()
 
 
+@pytest.mark.parametrize("W,H", [(1920, 1080), (1921, 1081)])
+def test_loss_at_the_size_it_is_quoted_for(W, H):
+    """The loss kernels own four outputs per thread, fold the 11 x 11 window to 6 x 6 weights and read LDS in 16-byte pieces
+    (gs_loss.hip); they are timed at 1920x1080x3.  Parity at that size and at a ragged one (neither dimension a
+    multiple of the kernels' tile): loss vs the loss.jl restatement, gradient vs fp64 torch autograd."""
+    import torch
+    from gaussiansplat_amd import backend as B
+    from oracle import loss_oracle_np as LO
+    from test_loss import torch_loss
+    rng = np.random.default_rng(W * 7 + H)
+    gt = rng.random((3, H, W), dtype=np.float32)
+    img = np.clip(gt + 0.15 * rng.standard_normal((3, H, W)).astype(np.float32), 0.0, 1.0).astype(np.float32)    # a render near its target
+    img[1, -7:, -9:] = gt[1, -7:, -9:]                                       # exact ties in the ragged corner: sign(0) = 0
+    ctx = B.Context()
+    loss, dC = ctx.loss_host(img, gt, 0.1)
+    k = LO.kernel_window()
+    assert abs(loss - LO.loss(img, gt, k)) <= 2e-6
+    x = torch.tensor(img, dtype=torch.float64, requires_grad=True)
+    torch_loss(x, torch.tensor(gt, dtype=torch.float64), k, fft=True).backward()
+    want = x.grad.numpy()
+    assert np.abs(dC - want).max() <= 1e-4 * np.abs(want).max() + 1e-12
+    assert np.linalg.norm(dC - want) <= 1e-4 * np.linalg.norm(want)
+    # the borders see a truncated window: compare them on their own
+    for sl in (np.s_[:, :6, :], np.s_[:, -6:, :], np.s_[:, :, :6], np.s_[:, :, -6:]):
+        assert np.linalg.norm(dC[sl] - want[sl]) <= 1e-4 * np.linalg.norm(want[sl])
+    ctx.close()
+
+
 def test_sgd_step_and_training_reduces_loss():
     import torch
     from gaussiansplat_amd import renderer as R, synthetic, train as TR

@@ -22,10 +22,11 @@ def test_all_schedules_agree(n, W, H, deg, scale_shift, t_min):
     dC = synthetic.make_dC(W, H, 31)
     ref = {}
     for det in (True, False):
-        for schedule in (1, 3, 4, 0, 2):
+        for schedule, slot in ((1, -1), (3, -1), (3, 5), (4, -1), (0, 7)):
             ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=t_min, deterministic=det, schedule=schedule, slab_mode=0)
+            ctx.set_view_slot(slot)
             out = None
-            for frame in range(2 if schedule == 4 else 1):               # schedule 4 orders the forward by the previous frame
+            for frame in range(1 if schedule == 1 else 3):               # later frames launch the forward by what the slot / the previous frame measured
                 ctx.preprocess(); ctx.bin()
                 img, tr = ctx.forward_host()
                 g = ctx.grads_alloc(); ctx.backward(dC, g)

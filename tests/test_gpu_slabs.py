@@ -22,19 +22,9 @@ def _frame(ctx, dC, deg):
     return rounds, img, tr, grads, ctx.work_counters_ex()
 
 
-@pytest.fixture
-def slabs_env():
-    old = os.environ.get("GS_SLABS")
-    yield lambda v: os.environ.__setitem__("GS_SLABS", v)
-    if old is None:
-        os.environ.pop("GS_SLABS", None)
-    else:
-        os.environ["GS_SLABS"] = old
-
-
-@pytest.mark.parametrize("fractions,rounds", [("0.3", 2), ("0.15,0.5", 3), ("0.1,0.2,0.4", 4), ("0.999", 2), ("0.0005,0.6", 3)])
+@pytest.mark.parametrize("fractions,rounds", [((0.3,), 2), ((0.15, 0.5), 3), ((0.1, 0.2, 0.4), 4), ((0.999,), 2), ((0.0005, 0.6), 3)])
 @pytest.mark.parametrize("t_min", [1e-3, 1e-5])
-def test_forced_slabs_bit_identical_to_classic(oracle, slabs_env, fractions, rounds, t_min):
+def test_forced_slabs_bit_identical_to_classic(oracle, fractions, rounds, t_min):
     from gaussiansplat_amd import synthetic
     O = oracle
     n, W, H, deg = 5000, 112, 72, 2                                          # ragged: 7 x 4.5 tiles
@@ -43,12 +33,10 @@ def test_forced_slabs_bit_identical_to_classic(oracle, slabs_env, fractions, rou
     dC = synthetic.make_dC(W, H, 17)
     res = {}
     for det in (True, False):
-        os.environ.pop("GS_SLABS", None)
         c0 = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=t_min, deterministic=det, slab_mode=0)
         r0 = _frame(c0, dC, deg); c0.close()
         assert r0[0] == 1
-        slabs_env(fractions)
-        c1 = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=t_min, deterministic=det, slab_mode=1)
+        c1 = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=t_min, deterministic=det, slab_mode=1, slab_fractions=fractions)
         r1 = _frame(c1, dC, deg)
         assert r1[0] == rounds, r1[0]
         with pytest.raises(Exception):
@@ -76,24 +64,14 @@ def test_forced_slabs_bit_identical_to_classic(oracle, slabs_env, fractions, rou
 def test_auto_slabs_after_a_dense_frame():
     """Automatic mode: the first frames of a ctx are classic (no history); once a frame walked less than the threshold share
     of its instances the binning switches to slabs; every frame gives the same bits.  The shipped threshold is 0.03 (with the
-    two-level binning slabs no longer pay at C5's 0.06); the test raises it to round 2's 0.15 to exercise the switch, then
+    two-level binning slabs no longer pay at C5's 0.06); the test raises it to round 2's 0.15 (gs_config.slab_max_ratio) to exercise the switch, then
     checks that the same scene and the headline workload C3 (28 %) stay classic at the shipped threshold."""
-    from gaussiansplat_amd import synthetic
-    os.environ.pop("GS_SLABS", None)
-    os.environ["GS_SLAB_MAX_RATIO"] = "0.15"
-    try:
-        _auto_slabs_body()
-    finally:
-        os.environ.pop("GS_SLAB_MAX_RATIO", None)
-
-
-def _auto_slabs_body():
     from gaussiansplat_amd import synthetic
     n, W, H, deg = 300_000, 800, 608, 3
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 77)
     sc["scales"] = sc["scales"] + np.float32(1.5)                           # dense: under 10 % of the instances are walked
     dC = synthetic.make_dC(W, H, 3)
-    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, deterministic=True)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, deterministic=True, slab_max_ratio=0.15)
     frames = [_frame(ctx, dC, deg) for _ in range(4)]
     share = frames[0][4]["walked_fwd"] / ctx.num_instances
     assert share < 0.15, share
@@ -104,7 +82,6 @@ def _auto_slabs_body():
             assert np.array_equal(f[3][k], frames[0][3][k]), k
         assert f[4]["evaluated_fwd"] == frames[0][4]["evaluated_fwd"]
     ctx.close()
-    os.environ.pop("GS_SLAB_MAX_RATIO", None)
     ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, deterministic=True)
     again = [_frame(ctx, dC, deg) for _ in range(3)]
     assert [f[0] for f in again] == [1, 1, 1] and share > 0.03
@@ -121,7 +98,6 @@ def _auto_slabs_body():
 def test_sparse_scene_stays_classic():
     """No tile saturates (tiny footprints): the walked share is ~1, so the automatic mode never leaves the single round."""
     from gaussiansplat_amd import synthetic
-    os.environ.pop("GS_SLABS", None)
     n, W, H, deg = 20000, 320, 208, 1
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 5)
     sc["scales"] = sc["scales"] - np.float32(1.5)
@@ -130,3 +106,29 @@ def test_sparse_scene_stays_classic():
     rounds = [_frame(ctx, dC, deg)[0] for _ in range(4)]
     assert rounds == [1, 1, 1, 1], rounds
     ctx.close()
+
+
+def test_slab_resume_with_negative_transmittance():
+    """A live pixel's T can go (slightly) negative: rounding in the exponent of a near-singular, elongated, fully opaque splat
+    can push alpha past 1.  Round 2 carried the `frozen` flag of a pixel in the sign of its stored T between slab rounds, so
+    such a pixel was resumed as frozen; the flags now travel in per-tile lane masks.  Elongated splats with sigmoid(o) = 1:
+    forced slabs must stay bit-identical to the classic single list, including the pixels whose T is negative."""
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg = 6000, 160, 112, 0
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 23)
+    sc = dict(sc)
+    s = sc["scales"].copy()
+    s[:, 0] += np.float32(3.0); s[:, 1:] -= np.float32(3.5)                  # needles: 600 : 1 axis ratios, conics close to singular
+    sc["scales"] = s
+    sc["opacities"] = np.full(n, 30.0, np.float32)                          # cusigmoid(30) rounds to 1.0f
+    dC = synthetic.make_dC(W, H, 23)
+    res = []
+    for kw in (dict(slab_mode=0), dict(slab_mode=1, slab_fractions=(0.07, 0.3)), dict(slab_mode=1, slab_fractions=(0.01, 0.02, 0.5))):
+        ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5, deterministic=True, **kw)
+        res.append(_frame(ctx, dC, deg))
+        ctx.close()
+    assert res[0][0] == 1 and res[1][0] == 3 and res[2][0] == 4
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2], equal_nan=True)
+        for k in GRADS:
+            assert np.array_equal(r[3][k], res[0][3][k], equal_nan=True), k

@@ -173,10 +173,10 @@ def test_config_and_grads_structs_mirror_the_header():
     for (cn, ct, cnt), (jn, jt) in zip(cf, jf):
         total += size[ct] * cnt
         if cnt > 1:
-            assert jt == f"NTuple{{{cnt}, Int32}}", (cn, jt)
+            assert jt == f"NTuple{{{cnt}, {'Int32' if ct == 'int32_t' else 'Float32'}}}", (cn, jt)
         else:
             assert jt == {"int32_t": "Int32", "float": "Float32"}[ct], (cn, jt)
-    assert total == 64, "sizeof(gs_config) must stay 64 (struct_size ABI guard)"
+    assert total == 96, "sizeof(gs_config) is 96 in ABI version 2 (struct_size + abi_version guard)"
     src = open(os.path.join(ROOT, "julia", "backend.jl")).read()
     ctor = re.search(r"GsConfig\(([^\n]*)\)\n", src).group(1)
     assert len(_split_top(ctor)) == len(jf), "defaultConfig(): GsConfig constructor arity"
@@ -187,5 +187,5 @@ def test_config_and_grads_structs_mirror_the_header():
     # the Python mirror agrees as well
     import ctypes as C
     from gaussiansplat_amd import backend
-    assert [f[0] for f in backend.GsConfig._fields_] == [f[0] for f in cf] and C.sizeof(backend.GsConfig) == 64
+    assert [f[0] for f in backend.GsConfig._fields_] == [f[0] for f in cf] and C.sizeof(backend.GsConfig) == 96
     assert [f[0] for f in backend.GsGrads._fields_] == [f[0] for f in gf]

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 CFG=C3
 for a in "$@"; do case "$prev" in --config) CFG=$a;; esac; prev=$a; done
-B="python3 $PWD/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train-iteration $*"
+B="python3 $PWD/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-train-iteration --no-c4-anchor $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B > "$OUT/bench_stats.log" 2>&1
 echo "stats done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_valu" -- $B > "$OUT/bench_pmc_valu.log" 2>&1
@@ -18,7 +18,7 @@ echo "pmc valu done"
 # where the wave cycles go: parked on s_waitcnt (WAIT_ANY), issue stalls (WAIT_INST_ANY), issuing (ACTIVE_INST_ANY)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM --output-format csv -d "$OUT/pmc_wait" -- $B > "$OUT/bench_pmc_wait.log" 2>&1 || echo "pmc wait pass failed"
 echo "pmc wait done"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$OUT/pmc_tcc" -- $B > "$OUT/bench_pmc_tcc.log" 2>&1 || echo "pmc tcc pass failed"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_ATOMIC_sum --output-format csv -d "$OUT/pmc_tcc" -- $B > "$OUT/bench_pmc_tcc.log" 2>&1 || echo "pmc tcc pass failed"
 echo "pmc tcc done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $B > "$OUT/bench_pmc_fetch.log" 2>&1
 echo "pmc fetch done"
