@@ -377,10 +377,10 @@ class Context:
         return float(ms.value)
 
     def tile_clock(self, which: int, variant: int = 0) -> np.ndarray:
-        """[ntiles, 4] uint64 per tile {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, walked << 32 | evaluated} of one
-        composite launch (which: 0 forward, 1 backward)."""
+        """[ntiles, 6] uint64 per tile {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, walked << 32 | evaluated, shader cycles
+        inside the per-entry loops, shader cycles outside them} of one composite launch (which: 0 forward, 1 backward)."""
         ntiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-        out = np.zeros((ntiles, 4), np.uint64)
+        out = np.zeros((ntiles, 6), np.uint64)
         self._chk(self.L.gs_debug_tile_clock(self.h, which, variant, C.c_void_p(out.ctypes.data)))
         return out
 

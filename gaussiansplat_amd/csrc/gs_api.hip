@@ -1459,14 +1459,14 @@ int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
     const size_t ntiles = (size_t)c->gx * c->gy;
     GsCompositeArgs a{};
     if (int rc = debug_composite_args(c, which, variant, a)) return rc;
-    HIPCHK(c, c->tile_clock.ensure(sizeof(uint64_t) * 4 * (ntiles ? ntiles : 1)));
-    HIPCHK(c, hipMemsetAsync(c->tile_clock.p, 0, sizeof(uint64_t) * 4 * ntiles, c->stream));
+    HIPCHK(c, c->tile_clock.ensure(sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * (ntiles ? ntiles : 1)));
+    HIPCHK(c, hipMemsetAsync(c->tile_clock.p, 0, sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * ntiles, c->stream));
     a.tile_clock = c->tile_clock.as<unsigned long long>();
     for (int rep = 0; rep < 2; ++rep) {                                       // the second launch (warm) is the one kept
         HIPCHK(c, hipMemsetAsync(static_cast<char *>(c->counters.p) + 32, 0, 96, c->stream));
         HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(out, c->tile_clock.p, sizeof(uint64_t) * 4 * ntiles, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->tile_clock.p, sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * ntiles, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GS_OK;
 }

@@ -177,6 +177,7 @@ hipError_t gs_bin3_l1_scatter(const GsBin3L1 &b, hipStream_t s);
 hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s);
 hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, uint8_t *sdone, hipStream_t s);
 
+#define GS_TILE_CLOCK_WORDS 6
 #define GS_MAX_ROUNDS 4   // binning rounds (depth slabs) of one frame
 #define GS_G2D_STRIDE 16   // floats (or fixed-point words) per gaussian row of the composite backward's sums: ten used, padded to ONE
                            // 64-byte sector so that the 9-lane atomic of a (tile, splat) entry is a single memory-side request
@@ -204,7 +205,8 @@ struct GsCompositeArgs {
     const uint32_t *tile_order_plain; // A/B: the same segments in tile order (no longest-first)
     const uint32_t *tile_order_band;  // A/B: longest-first permutation for a plain launch (schedule 3), tile % 8 preserved
     uint32_t *tile_work;       // forward: evaluated entries per tile (the backward's exact work measure); may be null
-    unsigned long long *tile_clock; // debug: per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated}
+    unsigned long long *tile_clock; // debug: GS_TILE_CLOCK_WORDS per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated,
+                                    // shader cycles (s_memtime) inside the per-entry loops, shader cycles outside them (staging, waiting for the gathers)}
     int grid_waves;            // waves to launch in queue mode
     // frames binned in depth slabs (several rounds of binning + forward)
     int nseg;                  // backward: number of list segments per tile (= rounds of the frame, >= 1)

@@ -202,7 +202,10 @@ __device__ __forceinline__ Entry load_entry(const float4 *sp, const float *syhi,
 }
 
 // ---------------------------------------------------------------- forward
-template <bool EARLY, bool CULL, bool LEAN>
+template <bool EARLY, bool CULL, bool LEAN, bool CLK, bool SLAB>
+// SLAB: the frame is binned in depth slabs (several rounds; resume / tile_pos / tile_done / tile_dead): its own instantiation, the
+// single-round kernel carries none of that state (with it the compiler spilled: 96 VGPRs + 28 bytes of scratch against 90).
+// CLK: per-tile debug clocks (gs_debug_tile_clock); a separate instantiation so that the production kernel carries none of it.
 // LEAN (A/B variant 2 of the forward): no register prefetch of the next batch and no 2-entry interleave, to fit 64 VGPRs =
 // eight waves per SIMD, i.e. every tile of a 1080p frame resident at once.
 // (Skipping the dead 16 x 4 strips of an entry with wave-uniform branches, as the backward does, was measured on the forward
@@ -215,7 +218,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);     // first pixel of the tile (1-based)
     unsigned long long clk0 = 0;
-    if (a.tile_clock) clk0 = __builtin_amdgcn_s_memrealtime();
+    if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
 
     // Slab frames (binning in depth slabs): the tile's list arrives in several rounds.  A later round resumes the
     // pixel state the previous one left in image / trans and in tile_dead (four 64-bit lane masks per tile: pixel slot p of
@@ -223,8 +226,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     // and then looks like nothing else than a negative T), continues the list position (tile_pos) so that the 64-entry batch
     // boundaries -- where the early-out rule freezes pixels -- stay those of the whole list, and a tile whose pixels are all
     // frozen is marked done and takes no further instances.
-    if (a.resume && a.tile_done[tile]) return;
-    const uint32_t gp0 = a.tile_pos ? a.tile_pos[tile] : 0u;
+    if (SLAB && a.resume && a.tile_done[tile]) return;
+    const uint32_t gp0 = SLAB && a.tile_pos ? a.tile_pos[tile] : 0u;
     const size_t plane = (size_t)a.W * a.H;
     float Cr[4], Cg[4], Cb[4], T[4], Tdead[4], fy[4];
     bool dead[4];
@@ -236,7 +239,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         const bool in = (px <= a.W && py0 + 4 * p <= a.H);
         T[p] = in ? 1.0f : 0.0f;
         Tdead[p] = 0.0f; dead[p] = !in;
-        if (a.resume && in) {
+        if (SLAB && a.resume && in) {
             const size_t o = (size_t)(px - 1) + (size_t)a.W * (py0 + 4 * p - 1);
             Cr[p] = a.image[o]; Cg[p] = a.image[o + plane]; Cb[p] = a.image[o + 2 * plane];
             const float t = a.trans[o];
@@ -248,8 +251,19 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
     uint32_t pos = s0 + lane;
-    if (!LEAN && pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
+    // Gathers run ahead of their use: the payload rows one batch (held in n0..n2 while the previous batch is composited), the
+    // ids they are addressed by TWO batches (id2), so that the row loads of the next batch are issued from a register instead of
+    // behind a second dependent round trip to memory.  A tile whose batches keep few entries (light tiles, the ones that run
+    // when the chip is emptying) is bound by exactly this chain: one exposed load latency per batch instead of two.
+    uint32_t id2 = 0;
+    if (!LEAN) {
+        const uint32_t pos2 = pos + min((uint32_t)CB - (gp0 & (CB - 1)), s1 - s0);      // first position of the second batch + lane
+        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
+        if (pos2 < s1) id2 = a.ids[pos2];
+    }
     uint32_t gp = gp0;                                                  // list position of `base` in the tile's whole list
+    unsigned long long t_loop = 0, t_stage = 0, t_mark = 0;             // debug clocks (a.tile_clock): shader cycles inside / outside the per-entry loops
+    if (CLK) t_mark = __builtin_amdgcn_s_memtime();
     for (uint32_t base = s0; base < s1;) {
         const uint32_t phase = gp & (CB - 1);
         const int cnt = (int)min((uint32_t)CB - phase, s1 - base);      // batches end at multiples of CB of the WHOLE list
@@ -286,7 +300,12 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         __syncthreads();
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
-        if (!LEAN && pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
+        if (!LEAN) {
+            if (pos < s1) { const size_t g = id2; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
+            const uint32_t pos2 = pos + min((uint32_t)CB, s1 - base);                   // (batches after the first start at multiples of CB)
+            if (base < s1 && pos2 < s1) id2 = a.ids[pos2];
+        }
+        if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
 #pragma clang loop unroll_count(LEAN ? 1 : 2)
         for (int k = 0; k < nk; ++k) {
             const Entry e = load_entry(sp, syhi, k);
@@ -307,12 +326,13 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             }
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
+        if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t; }
     }
     bool anylive = false;
 #pragma unroll
     for (int p = 0; p < 4; ++p) anylive = anylive || !dead[p];
     const bool all_dead = __ballot(anylive) == 0ull;                    // complete: no pixel takes anything further
-    if (a.tile_dead && !a.final_round) {                                // the frozen flags travel to the next round beside the pixels
+    if (SLAB && a.tile_dead && !a.final_round) {                        // the frozen flags travel to the next round beside the pixels
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const unsigned long long m = __ballot(dead[p]);
@@ -321,9 +341,9 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     }
     if (lane == 0) {
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
-        if (a.tile_work) a.tile_work[tile] = a.resume ? a.tile_work[tile] + evaluated : evaluated;
-        if (a.tile_done) a.tile_done[tile] = all_dead ? 1 : 0;
-        if (a.tile_pos) a.tile_pos[tile] = gp0 + (s1 - s0);
+        if (a.tile_work) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + evaluated : evaluated;
+        if (SLAB && a.tile_done) a.tile_done[tile] = all_dead ? 1 : 0;
+        if (SLAB && a.tile_pos) a.tile_pos[tile] = gp0 + (s1 - s0);
     }
     if (px <= a.W) {
 #pragma unroll
@@ -336,21 +356,22 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             }
         }
     }
-    if (a.tile_clock && lane == 0) {
-        unsigned long long *c = a.tile_clock + 4 * (size_t)tile;
+    if (CLK && a.tile_clock && lane == 0) {
+        unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)tile;
         c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
         c[3] = ((unsigned long long)walked << 32) | evaluated;
+        c[4] = t_loop; c[5] = t_stage;
     }
 }
 
-template <bool EARLY, int MINW, bool CULL, bool LEAN = false>
+template <bool EARLY, int MINW, bool CULL, bool LEAN = false, bool CLK = false, bool SLAB = false>
 __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
-        forward_tile<EARLY, CULL, LEAN>(a, tile, sp, syhi, nbig);
+        forward_tile<EARLY, CULL, LEAN, CLK, SLAB>(a, tile, sp, syhi, nbig);
         __syncthreads();                                                // the next tile restages sp[]
     }
 }
@@ -489,7 +510,7 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
 // pixel-box penalty (v_med3 + sub + fma per axis), 32 reuses one staged entry (no LDS reads of the payload).  Outputs are wrong
 // by construction.
 // RED: 2 transposed LDS reduction, software pipelined (default); 1 reduce-scatter tree on ds_swizzle / ds_bpermute
-template <bool EARLY, bool DET, int RED, bool CULL>
+template <bool EARLY, bool DET, int RED, bool CULL, bool CLK>
 __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, uint32_t *sid, uint32_t *sstrip,
                                               float *red, const float nbig) {
     const int lane = threadIdx.x;
@@ -499,7 +520,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const size_t plane = (size_t)a.W * a.H;
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);
     unsigned long long clk0 = 0;
-    if (a.tile_clock) clk0 = __builtin_amdgcn_s_memrealtime();
+    if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
     // tree variant
     const int ocomp_tree = out_component_tree(lane);
     const int xaddr = (lane ^ 32) << 2;                                  // ds_bpermute address of the partner lane
@@ -549,11 +570,18 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     uint32_t gp = 0;
     uint32_t alive = 0xFu;                                                // strips with a live pixel (refreshed at every batch boundary)
     bool stop = false;
+    unsigned long long t_loop = 0, t_stage = 0, t_mark = 0;               // debug clocks (a.tile_clock)
+    if (CLK) t_mark = __builtin_amdgcn_s_memtime();
     for (int sg = 0; sg < a.nseg && !stop; ++sg) {
     const uint32_t *ids = a.seg_ids[sg];
     const uint32_t s0 = a.seg_ranges[sg][2 * tile], s1 = a.seg_ranges[sg][2 * tile + 1];
     uint32_t pos = s0 + lane;
-    if (pos < s1) { nid = ids[pos]; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; }
+    uint32_t id2 = 0;                                                     // ids run two batches ahead, payload rows one (see the forward)
+    {
+        const uint32_t pos2 = pos + min((uint32_t)CB - (gp & (CB - 1)), s1 - s0);
+        if (pos < s1) { nid = ids[pos]; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; }
+        if (pos2 < s1) id2 = ids[pos2];
+    }
     for (uint32_t base = s0; base < s1;) {
         const uint32_t phase = gp & (CB - 1);
         const int cnt = (int)min((uint32_t)CB - phase, s1 - base);
@@ -600,7 +628,12 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         };
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
-        if (pos < s1) { nid = ids[pos]; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; }
+        if (pos < s1) { nid = id2; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; }
+        {
+            const uint32_t pos2 = pos + min((uint32_t)CB, s1 - base);
+            if (base < s1 && pos2 < s1) id2 = ids[pos2];
+        }
+        if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
         if (RED == 2) {
             // software pipeline: arithmetic of entry k | loads of entry k+1 | sums + atomic of entry k-1 (its sixteen
             // partials were read back during the arithmetic) | partials of entry k -> LDS, read back transposed
@@ -670,18 +703,20 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             }
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
+        if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t; }
     }
     }
     if (RED == 2 && pend) finish();
     if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
-    if (a.tile_clock && lane == 0) {
-        unsigned long long *c = a.tile_clock + 4 * (size_t)tile;
+    if (CLK && a.tile_clock && lane == 0) {
+        unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)tile;
         c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
         c[3] = ((unsigned long long)walked << 32) | evaluated;
+        c[4] = t_loop; c[5] = t_stage;
     }
 }
 
-template <bool EARLY, int MINW, bool DET, int RED, bool CULL>
+template <bool EARLY, int MINW, bool DET, int RED, bool CULL, bool CLK = false>
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[(CB + 1) * 3];                                  // one spare slot: the pipelined loop loads entry k+1
     __shared__ float syhi[CB + 1];
@@ -691,7 +726,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
-        backward_tile<EARLY, DET, RED, CULL>(a, tile, sp, syhi, sid, sstrip, red, nbig);
+        backward_tile<EARLY, DET, RED, CULL, CLK>(a, tile, sp, syhi, sid, sstrip, red, nbig);
         __syncthreads();
     }
 }
@@ -753,13 +788,13 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 // so a few classes lose nothing.  Ranks come from an LDS bitmap [class row][tile of the residue class]: atomic OR (order
 // free), word prefix, popcount below the own bit -- the same construction as the level-1 binning (gs_bin3.hip).
 // One workgroup; work = src[t], or the list length (ranges_mode).
-#define GS_LPT_BUCKETS 16
+#define GS_LPT_BUCKETS 32
 __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int nb,
                                                                uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14) {
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wmax;
     __shared__ uint32_t rowtot[8 * 32], rowstart[8 * 32];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (ntiles + 7) >> 3;                                   // tiles per residue class (upper bound)
     const int W = (per + 31) >> 5;                                       // bitmap words per row
     const int rows = 8 * nb;                                             // row = residue * nb + class
@@ -770,25 +805,55 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
     if (tid == 0) wmax = 1;
     if (zero14 && tid < 14) zero14[tid] = 0ull;
     __syncthreads();
-    auto work = [&](int t) -> uint32_t { return ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t]; };
+    // the tiles' work is read twice (maximum, then classes), eight independent loads in flight per thread each time: the
+    // second read comes from L2, and a copy in LDS would not fit beside the bitmap for 4K-class grids
+    auto load8 = [&](int t0, uint32_t (&v)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * 1024 + tid;
+            v[k] = 0;
+            if (t < ntiles) v[k] = ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t];
+        }
+    };
     uint32_t m = 0;
-    for (int t = tid; t < ntiles; t += 1024) m = max(m, work(t));
+    for (int t0 = 0; t0 < ntiles; t0 += 8 * 1024) {
+        uint32_t v[8];
+        load8(t0, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = max(m, v[k]);
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-    if ((tid & 63) == 0) atomicMax(&wmax, m);
+    if (lane == 0) atomicMax(&wmax, m);
     __syncthreads();
     const float scale = (float)nb / (float)wmax;
-    for (int t = tid; t < ntiles; t += 1024) {
-        const int c = min(nb - 1, max(0, nb - 1 - (int)((float)work(t) * scale)));     // class 0 = heaviest
-        cls[t] = (uint8_t)c;
-        const int i = t >> 3;
-        atomicOr(&bm[((t & 7) * nb + c) * W + (i >> 5)], 1u << (i & 31));
+    for (int t0 = 0; t0 < ntiles; t0 += 8 * 1024) {
+        uint32_t v[8];
+        load8(t0, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * 1024 + tid;
+            if (t < ntiles) {
+                const int c = min(nb - 1, max(0, nb - 1 - (int)((float)v[k] * scale)));        // class 0 = heaviest
+                cls[t] = (uint8_t)c;
+                const int i = t >> 3;
+                atomicOr(&bm[((t & 7) * nb + c) * W + (i >> 5)], 1u << (i & 31));
+            }
+        }
     }
     __syncthreads();
-    for (int r = tid; r < rows; r += 1024) {                             // word prefix of every row (W <= 137 words)
-        uint32_t run = 0;
-        for (int w = 0; w < W; ++w) { pre[r * W + w] = (uint16_t)run; run += (uint32_t)__popc(bm[r * W + w]); }
-        rowtot[r] = run;
+    for (int r = wv; r < rows; r += 16) {                                // one wave per row: exclusive scan of the word popcounts
+        uint32_t carry = 0;
+        for (int w0 = 0; w0 < W; w0 += 64) {
+            const int w = w0 + lane;
+            const uint32_t c = w < W ? (uint32_t)__popc(bm[r * W + w]) : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+            if (w < W) pre[r * W + w] = (uint16_t)(carry + incl - c);
+            carry += (uint32_t)__shfl((int)incl, 63);
+        }
+        if (lane == 0) rowtot[r] = carry;
     }
     __syncthreads();
     if (tid < 8) {                                                       // class starts inside each residue class
@@ -873,12 +938,25 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     const bool early = a.t_min > 0.0f;
 #ifdef GS_EXPERIMENTS
 #define GS_F(E) do { if (a.variant % 10 == 2 && a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 8, true, true>), grid, block, debug_extra_lds(), s, a); \
+                     else if (a.variant % 10 == 6 && a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 6, true>), grid, block, debug_extra_lds(), s, a); \
                      else if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
                      else hipLaunchKernelGGL((composite_fwd_kernel<E, 5, false>), grid, block, debug_extra_lds(), s, a); } while (0)
 #else
 #define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
                      else hipLaunchKernelGGL((composite_fwd_kernel<E, 5, false>), grid, block, debug_extra_lds(), s, a); } while (0)
 #endif
+    if (a.tile_pos) {                                                     // a round of a slab frame (t_min > 0 by construction: plan_rounds)
+        if (!early || a.tile_clock) return hipErrorInvalidValue;
+        if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<true, 5, true, false, false, true>), grid, block, debug_extra_lds(), s, a);
+        else hipLaunchKernelGGL((composite_fwd_kernel<true, 5, false, false, false, true>), grid, block, debug_extra_lds(), s, a);
+        return hipGetLastError();
+    }
+    if (a.tile_clock) {                                                   // debug clocks: instantiations of their own (alpha_cull on only)
+        if (!a.cull) return hipErrorInvalidValue;
+        if (early) hipLaunchKernelGGL((composite_fwd_kernel<true, 5, true, false, true>), grid, block, debug_extra_lds(), s, a);
+        else hipLaunchKernelGGL((composite_fwd_kernel<false, 5, true, false, true>), grid, block, debug_extra_lds(), s, a);
+        return hipGetLastError();
+    }
     if (early) GS_F(true); else GS_F(false);
 #undef GS_F
     return hipGetLastError();
@@ -899,6 +977,12 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
 #define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, debug_extra_lds(), s, a); \
                                else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, debug_extra_lds(), s, a); } while (0)
 #define GS_B(E, M, Z) do { if (a.g2d_fixed) GS_B2(E, M, true, Z); else GS_B2(E, M, false, Z); } while (0)
+    if (a.tile_clock) {                                                   // debug clocks: instantiations of their own (alpha_cull on, float atomics only)
+        if (!a.cull || a.g2d_fixed) return hipErrorInvalidValue;
+        if (early) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_BWD3_MINW, false, 3, true, true>), grid, block, debug_extra_lds(), s, a);
+        else hipLaunchKernelGGL((composite_bwd_kernel<false, GS_BWD3_MINW, false, 3, true, true>), grid, block, debug_extra_lds(), s, a);
+        return hipGetLastError();
+    }
 #ifdef GS_EXPERIMENTS
     const int body = (a.variant % 10 == 1 || a.variant % 10 == 2) ? a.variant % 10 : 3;
     // body 2 holds the sixteen partials of the previous entry across the pixel arithmetic: 96 VGPRs, 5 waves/SIMD (measured slower

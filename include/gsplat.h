@@ -340,8 +340,9 @@ int gs_get_work_counters_ex(gs_ctx *ctx, int64_t out[4]);
 int gs_debug_time_composite(gs_ctx *ctx, int which, int variant, int reps, float *mean_ms);
 
 /* Profiling aid: one launch of the composite forward (which=0) or backward (which=1) kernel of the current frame with
- * per-tile clocks.  out (HOST): 4 x gx*gy uint64 per tile {start, end (100 MHz s_memrealtime ticks), HW_ID | XCC_ID << 32,
- * walked << 32 | evaluated}.  tools/tile_tail.py turns it into the occupancy-over-time and tail summary under profiles/. */
+ * per-tile clocks.  out (HOST): 6 x gx*gy uint64 per tile {start, end (100 MHz s_memrealtime ticks), HW_ID | XCC_ID << 32,
+ * walked << 32 | evaluated, shader cycles inside the per-entry loops, shader cycles outside them (staging a batch and waiting
+ * for its gathers)}.  tools/tile_tail.py turns it into the occupancy-over-time and tail summary under profiles/. */
 int gs_debug_tile_clock(gs_ctx *ctx, int which, int variant, uint64_t *out);
 
 /* -1: the lane-order probe of the LDS-atomic rank was not run (rank_mode = 1 was asked for); 0: it ran at gs_create and

@@ -261,7 +261,7 @@ function hip_debugTimeComposite(r::HipRenderer, which::Integer, variant::Integer
     return ms[]
 end
 function hip_debugTileClock(r::HipRenderer, which::Integer, variant::Integer, ntiles::Integer)
-    out = zeros(UInt64, 4, ntiles)
+    out = zeros(UInt64, 6, ntiles)
     check(r, ccall((:gs_debug_tile_clock, libgs), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), r.ctx, which, variant, out))
     return out
 end

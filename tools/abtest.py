@@ -9,10 +9,12 @@ from gaussiansplat_amd import synthetic, backend as B
 import torch
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
-# variant = body + 10 * scheduling (gs_composite.hip launchers): body bwd 2 pipelined transposed reduction (default), 3 transposed,
-# 1 reduce-scatter tree; scheduling 0 ticket queue heaviest first (default), 1 one wave per tile, 2 ticket queue in tile order
-variants_f = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "10", "20"])]
-variants_b = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "10", "20", "2", "12", "1", "11"])]
+# variant = body + 10 * scheduling (gs_composite.hip launchers).  Scheduling: 1 one wave per tile in tile order, 3 plain launch over
+# the frame's longest-first order (production).  Bodies other than the default and the queue schedules 0 / 2 exist only in
+# GS_EXPERIMENTS builds (GSPLAT_HIP_LIB=gaussiansplat_amd/lib_exp/libgsplat_hip.so): forward 2 = 64-VGPR lean loop, 6 = the
+# default loop built for six waves per SIMD; backward 1 = reduce-scatter tree, 2 = software-pipelined transposed reduction.
+variants_f = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["10", "30"])]
+variants_b = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["10", "30"])]
 n, W, H, deg = synthetic.CONFIGS[cfg]
 sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1234 + list(synthetic.CONFIGS).index(cfg))
 dC = synthetic.make_dC(W, H, 1)

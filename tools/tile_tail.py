@@ -3,10 +3,9 @@
 
     python3 tools/tile_tail.py [C3] [out.json]
 
-For every scheduling variant (tens digit: 1 = one wave per tile in launch order; 3 = plain launch over the longest-first
-permutation that keeps tile % 8 (the default of the backward); 0 = persistent waves on per-XCD ticket queues, heaviest first;
-2 = the same queues in arbitrary order; units digit 1 = the reduce-scatter-tree backward body) and both kernels it launches
-once with gs_debug_tile_clock and reports
+For every scheduling variant (tens digit: 1 = one wave per tile in launch (tile) order; 3 = plain launch over the frame's
+longest-first order (gs_config.schedule 3: what the backward and the next forward of the view slot use); GS_EXPERIMENTS builds
+also 0 / 2 = persistent waves on per-XCD ticket queues) and both kernels it launches once with gs_debug_tile_clock and reports
   * kernel span (first start .. last end, 100 MHz s_memrealtime ticks -> microseconds),
   * the concurrency profile: time-weighted mean of waves in flight, and the share of the span spent below 50 % / 25 % of
     the peak concurrency (the tail),
@@ -51,8 +50,27 @@ def analyse(clk):
     per_simd = np.bincount(inv, weights=evaluated.astype(np.float64))
     per_simd_end = np.zeros(len(keys)); np.maximum.at(per_simd_end, inv, (end - t0).astype(np.float64))
     dur = (end - start).astype(np.float64)
+    # SIMD-time by the number of waves resident on the SIMD (the kernels are built for five): a SIMD issues for one wave at
+    # roughly half the rate it reaches with several, and not at all with none
+    occ_hist = np.zeros(9)
+    for k in range(len(keys)):
+        m = inv == k
+        e2 = np.concatenate([np.stack([start[m] - t0, np.ones(m.sum(), np.int64)], 1), np.stack([end[m] - t0, -np.ones(m.sum(), np.int64)], 1)])
+        e2 = e2[np.lexsort((e2[:, 1], e2[:, 0]))]
+        c2 = np.cumsum(e2[:, 1])
+        d2 = np.diff(np.concatenate([e2[:, 0], [span]]))
+        occ_hist[0] += e2[0, 0]                                          # before its first wave
+        np.add.at(occ_hist, np.clip(c2, 0, 8), d2)
+    occ_hist = occ_hist / max(occ_hist.sum(), 1)
     order = np.argsort(evaluated)
     dec = np.array_split(order, 10)
+    # in-kernel shader-cycle stamps: per-entry loops vs everything else (staging a batch, waiting for its gathers, prologue/epilogue)
+    loop_cyc = clk[ran, 4].astype(np.float64) if clk.shape[1] > 4 else np.zeros(len(dur))
+    stage_cyc = clk[ran, 5].astype(np.float64) if clk.shape[1] > 5 else np.zeros(len(dur))
+    # least squares: tile duration ~ a * walked + b * evaluated + c  (what a launch order should sort by)
+    A = np.stack([walked.astype(np.float64), evaluated.astype(np.float64), np.ones(len(dur))], 1)
+    coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
+    resid = dur - A @ coef
     return {
         "tiles": int(ran.sum()), "span_us": span * TICK_US, "peak_waves_in_flight": peak, "mean_waves_in_flight": mean_conc,
         "mean_over_peak": mean_conc / max(peak, 1), "share_of_span_below_50pct_of_peak": below50, "share_of_span_below_25pct_of_peak": below25,
@@ -63,6 +81,14 @@ def analyse(clk):
         "evaluated_per_tile_percentiles": [int(np.percentile(evaluated, q)) for q in (0, 10, 50, 90, 99, 100)],
         "tile_duration_us_percentiles": [float(np.percentile(dur, q)) * TICK_US for q in (0, 10, 50, 90, 99, 100)],
         "ticks_per_evaluated_entry_by_decile": [float(dur[d].sum() / max(evaluated[d].sum(), 1)) for d in dec],
+        "simd_time_share_by_resident_waves_0_to_8": [round(float(x), 4) for x in occ_hist],
+        "loop_cycles_per_evaluated_entry_by_decile": [float(loop_cyc[d].sum() / max(evaluated[d].sum(), 1)) for d in dec],
+        "stage_cycles_per_walked_entry_by_decile": [float(stage_cyc[d].sum() / max(walked[d].sum(), 1)) for d in dec],
+        "stage_share_of_stamped_cycles_by_decile": [float(stage_cyc[d].sum() / max((stage_cyc[d] + loop_cyc[d]).sum(), 1)) for d in dec],
+        "stage_share_of_stamped_cycles": float(stage_cyc.sum() / max((stage_cyc + loop_cyc).sum(), 1)),
+        "walked_per_evaluated_by_decile": [float(walked[d].sum() / max(evaluated[d].sum(), 1)) for d in dec],
+        "duration_fit_ticks": {"per_walked": float(coef[0]), "per_evaluated": float(coef[1]), "const": float(coef[2]),
+                               "rms_residual_over_mean": float(np.sqrt((resid ** 2).mean()) / dur.mean())},
     }
 
 
@@ -76,7 +102,10 @@ def main():
     ctx.preprocess(); ctx.bin(); ctx.forward_host()
     g = ctx.grads_alloc(); ctx.backward(dC, g); ctx.synchronize()
     res = {"config": cfg, "instances": ctx.num_instances, "work": ctx.work_counters_ex()}
-    variants = {"fwd": [10, 30, 0], "bwd": [10, 30, 0, 20, 11, 31]}
+    variants = {"fwd": [10, 30], "bwd": [10, 30]}
+    if "lib_exp" in os.environ.get("GSPLAT_HIP_LIB", ""):
+        variants["fwd"] += [36]                                          # the forward built for six waves per SIMD
+    res["lpt_buckets_env"] = os.environ.get("GS_LPT_BUCKETS")
     for which, name in ((0, "fwd"), (1, "bwd")):
         for v in variants[name]:
             a = analyse(ctx.tile_clock(which, v))
@@ -84,7 +113,9 @@ def main():
             res[f"{name}_v{v}"] = a
             print(name, v, json.dumps({k: a[k] for k in ("span_us", "mean_ms_of_8_launches", "peak_waves_in_flight", "mean_over_peak",
                                                          "share_of_span_below_50pct_of_peak", "t90_over_span",
-                                                         "evaluated_per_simd_max_over_mean")}), flush=True)
+                                                         "evaluated_per_simd_max_over_mean", "simd_finish_spread_us",
+                                                         "simd_time_share_by_resident_waves_0_to_8", "stage_share_of_stamped_cycles",
+                                                         "duration_fit_ticks")}), flush=True)
     os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)
