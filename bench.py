@@ -188,6 +188,8 @@ def main():
                          "xGMI traffic.  The other mode is timed as well and reported beside it.")
     ap.add_argument("--no-overlap", action="store_true", help="allreduce: literally ONE collective after the last kernel (default: the Δshs "
                     "segment starts as soon as the last view's SH kernel has run, beside the geometry chain)")
+    ap.add_argument("--no-pipeline", action="store_true", help="view batches: one renderer, one stream (default: the views of a rank alternate between "
+                    "two renderers / streams over the same model, so the lists of view k+1 are built beside the composite kernels of view k)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
     if args.config is None:
@@ -259,7 +261,8 @@ def main():
         """one step = one view batch: this rank's views one after the other (gradients accumulate), then the exchange"""
         batch = batches[k % len(batches)]
         hv = r.__dict__.setdefault("_bench_hv", D.HipViewRenderer(r))            # (cycle r <-> hv: collected by gc below)
-        D.multi_view_step(hv, [cams[v] for v in batch], [dCs[v] for v in batch], sync=sync_mode[0], overlap=not args.no_overlap)
+        D.multi_view_step(hv, [cams[v] for v in batch], [dCs[v] for v in batch], sync=sync_mode[0], overlap=not args.no_overlap,
+                          pipeline=not args.no_pipeline)
 
     def timed(r, steps, warmup, k0=0):
         for k in range(warmup):
@@ -355,6 +358,8 @@ def main():
         else:
             what = (f"{args.config}: {n} gaussians, {W}x{H}, SH{deg}, a batch of {views_per_step} camera views per step (view k: eye rotated about +y "
                     f"by 45k degrees), fwd+bwd per view with the gradients accumulating; {views_per_step // world} view(s) per GPU"
+                    + (" (consecutive views alternate between two renderers / HIP streams over the same model: the lists of view k+1 are built beside "
+                       "the composite kernels of view k)" if views_per_step // world > 1 and not args.no_pipeline else "")
                     + ((", then all-reduce of 11N f32 + all-gather of 3N f32 per view (colour-factored) over RCCL" if factored
                         else ", then the sum of the flat 59N-f32 gradient buffer over RCCL ("
                              + ("ONE all-reduce" if args.no_overlap else "reduced as its two segments: Δshs starts behind the last SH kernel, beside the geometry chain")
@@ -369,6 +374,7 @@ def main():
                                           "tests/test_gpu_sizes.py)",
                        "views_per_step": views_per_step, "views_per_rank": views_per_step // world, "nranks": nranks,
                        "ms_per_view": dt / args.steps * 1e3 / (views_per_step // world),
+                       "pipeline": (not args.no_pipeline) if views_per_step // world > 1 else None,
                        "grad_sync": args.grad_sync if world > 1 else None, "allreduce_overlap": (not args.no_overlap) if world > 1 else None,
                        "backend": args.backend if world > 1 else None,
                        "rank_mode": int(r.ctx.cfg.rank_mode), "binning_rounds": r.ctx.num_rounds, "schedule": int(r.ctx.cfg.schedule) or 3,
@@ -400,16 +406,16 @@ def main():
         dC8 = [torch.as_tensor(synthetic.make_dC(W, H, seed + v)).cuda() for v in v8]
         hv = D.HipViewRenderer(r)
         for _ in range(2):
-            D.multi_view_step(hv, cams8, dC8)
+            D.multi_view_step(hv, cams8, dC8, pipeline=not args.no_pipeline)
         torch.cuda.synchronize()
         k8 = max(2, min(args.steps // 4, 10))
         t0 = time.perf_counter()
         for _ in range(k8):
-            D.multi_view_step(hv, cams8, dC8)
+            D.multi_view_step(hv, cams8, dC8, pipeline=not args.no_pipeline)
         torch.cuda.synchronize()
         d8 = time.perf_counter() - t0
         out["c4_batch"] = {"value": 8 * n * k8 / d8 / 1e6, "unit": "Msplats/s", "ms_per_step": d8 / k8 * 1e3, "ms_per_view": d8 / k8 / 8 * 1e3,
-                           "views_per_step": 8, "n_gpus": 1, "steps": k8,
+                           "views_per_step": 8, "n_gpus": 1, "steps": k8, "pipeline": not args.no_pipeline,
                            "what": "config C4 on ONE GPU: the eight views of the 8-GPU batch one after the other, gradients accumulating, no collective "
                                    "(= `bench.py --config C4 --gpus 1`): the N = 1 point of the strong-scaling curve `--gpus 2/4/8` continues"}
         del hv

@@ -109,12 +109,20 @@ struct gs_ctx {
     // ---- longest-first launch orders (gs_config.schedule 3 / 4).  After every forward ONE order kernel turns the frame's per-tile
     // work into a launch order: this frame's backward uses it, and so does the NEXT forward rendered under the same view slot.
     int view_slot = -1;                      // gs_set_view_slot: the slot of the frame being rendered (-1: none)
-    DevBuf slot_order[GS_MAX_VIEW_SLOTS];    // per slot: the order built after the slot's last forward
-    int64_t slot_tiles[GS_MAX_VIEW_SLOTS] = {};   // ... valid for a grid of this many tiles (0: no history)
-    DevBuf order_frame;                      // the order of a frame without a slot (schedule 4: also the next such forward's order)
-    int64_t order_frame_tiles = 0;
-    const uint32_t *frame_order = nullptr;   // the order built after THIS frame's forward (null: none, e.g. grid too large)
-    bool bwd_counters_zeroed = false;        // the order kernel zeroed the backward's work counters on its way
+    // Orders are double buffered: [slot][sel] is the newest one; the order kernel of a frame writes the OTHER buffer on the side
+    // stream while this frame's backward still reads the one its forward used.  Index GS_MAX_VIEW_SLOTS = frames without a slot.
+    DevBuf slot_order[GS_MAX_VIEW_SLOTS + 1][2];
+    int slot_sel[GS_MAX_VIEW_SLOTS + 1] = {};
+    int64_t slot_tiles[GS_MAX_VIEW_SLOTS + 1] = {};   // the newest order is valid for a grid of this many tiles (0: no history)
+    const uint32_t *frame_order = nullptr;   // the launch order of THIS frame's composite kernels (null: tile order)
+    bool bwd_counters_zeroed = false;        // the forward kernel zeroed the backward's work counters on its way
+    // ---- side stream: what a frame needs but no kernel of the frame waits for runs beside the composite kernels -- the zero fill of
+    // the backward's gradient rows (beside the forward) and the order kernel (beside the backward, for the slot's next frame)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_g2d_zero = nullptr, ev_order = nullptr;
+    bool g2d_zero_pending = false;           // the side stream is zeroing g2d for this frame's backward (ev_g2d_zero)
+    bool prev_frame_had_backward = false;    // render-only loops do not pay for the zero fill
+    bool order_pending = false;              // an order kernel is in flight on the side stream (ev_order)
     int lpt_buckets = 0;                     // experiments: work classes of the order kernel (0: default)
     // ---- speculative binning: the lists are enqueued with the capacities of the buffers at hand while the frame's totals travel
     bool pending_totals = false;             // ev_count recorded, pinned totals not read yet
@@ -213,29 +221,48 @@ int bind_device(gs_ctx *c) {
 
 bool lpt_schedule(const gs_ctx *c) { return c->cfg.schedule == 3 || c->cfg.schedule == 4; }
 
-// Launch order of the forward about to be enqueued (gs_config.schedule 3 / 4): what the last forward under the same view slot
-// measured, else (schedule 4) what this ctx's previous forward measured; null = tile order.
+// Launch order of the frame's composite kernels (gs_config.schedule 3 / 4): what the last forward under the same view slot
+// measured, else (schedule 4) what this ctx's previous slot-less forward measured; null = no history: tile order for the forward.
+int order_index(const gs_ctx *c) { return c->view_slot >= 0 ? c->view_slot : GS_MAX_VIEW_SLOTS; }
 const uint32_t *forward_order(gs_ctx *c) {
     const int64_t ntiles = (int64_t)c->gx * c->gy;
     if (!lpt_schedule(c) || ntiles <= 0 || ntiles > GS_LPT_MAX_TILES) return nullptr;
-    if (c->view_slot >= 0 && c->slot_tiles[c->view_slot] == ntiles) return c->slot_order[c->view_slot].as<uint32_t>();
-    if (c->cfg.schedule == 4 && c->order_frame_tiles == ntiles) return c->order_frame.as<uint32_t>();
-    return nullptr;
+    const int k = order_index(c);
+    if (k == GS_MAX_VIEW_SLOTS && c->cfg.schedule != 4) return nullptr;
+    if (c->slot_tiles[k] != ntiles) return nullptr;
+    if (c->order_pending) {                                              // (long complete by now; an event wait on the stream costs nothing)
+        if (hipStreamWaitEvent(c->stream, c->ev_order, 0) != hipSuccess) return nullptr;
+        c->order_pending = false;
+    }
+    return c->slot_order[k][c->slot_sel[k]].as<uint32_t>();
 }
 
-// After the frame's (last) forward: ONE order kernel turns its per-tile work into the launch order of this frame's backward and
-// of the next forward under the same slot; on its way it zeroes the backward's work counters.
-int build_frame_order(gs_ctx *c) {
+// After the frame's (last) forward: ONE order kernel turns its per-tile work into a launch order.  When the forward already ran
+// on the slot's history, the backward uses the same order and the kernel runs on the SIDE stream, beside the backward, into the
+// slot's other buffer -- for the slot's next frame; nothing of this frame waits for it.  Without history (a slot's first frame)
+// the backward waits for it: it is its only source of a longest-first order.
+int build_frame_order(gs_ctx *c, const uint32_t *used) {
     const int64_t ntiles = (int64_t)c->gx * c->gy;
-    c->frame_order = nullptr; c->bwd_counters_zeroed = false;
+    c->frame_order = used;
     if (!lpt_schedule(c) || ntiles <= 0 || ntiles > GS_LPT_MAX_TILES) return GS_OK;
-    DevBuf &ob = c->view_slot >= 0 ? c->slot_order[c->view_slot] : c->order_frame;
+    const int k = order_index(c);
+    const int dst = used ? 1 - c->slot_sel[k] : c->slot_sel[k];
+    DevBuf &ob = c->slot_order[k][dst];
     HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
-    HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, (int)ntiles, ob.as<uint32_t>(), c->stream,
-                                       c->counters.as<unsigned long long>() + 2, c->lpt_buckets));
-    if (c->view_slot >= 0) c->slot_tiles[c->view_slot] = ntiles; else c->order_frame_tiles = ntiles;
-    c->frame_order = ob.as<uint32_t>();
-    c->bwd_counters_zeroed = true;
+    if (used) {
+        if (c->order_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0));      // (never two in flight)
+        HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, (int)ntiles, ob.as<uint32_t>(), c->side, nullptr, c->lpt_buckets));
+        HIPCHK(c, hipEventRecord(c->ev_order, c->side));
+        c->order_pending = true;
+        c->slot_sel[k] = dst;
+        // (tile_work is rewritten by the next forward of this ctx: it waits for ev_order first, see forward_order / gs_forward)
+    } else {
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, (int)ntiles, ob.as<uint32_t>(), c->stream, nullptr, c->lpt_buckets));
+        c->frame_order = ob.as<uint32_t>();
+    }
+    c->slot_tiles[k] = ntiles;
     return GS_OK;
 }
 
@@ -337,6 +364,9 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
         for (int k = 0; k < 2; ++k)
             if ((e = hipEventCreate(&c->ev[s][k])) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
     if ((e = hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
+    if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipStreamCreate"); }
+    for (hipEvent_t *ev : {&c->ev_main, &c->ev_g2d_zero, &c->ev_order})
+        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
     if (c->cfg.rank_mode == 0) {
         // The one-instruction stable rank (ds_add_rtn pre-values in ascending lane order) is a measured property of
         // gfx950's LDS, not an architectural guarantee: check it on THIS device before relying on it; ballots otherwise.
@@ -353,6 +383,7 @@ int gs_destroy(gs_ctx *c) {
     if (!c) return GS_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
@@ -361,15 +392,17 @@ int gs_destroy(gs_ctx *c) {
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
                       &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->tilecnt,
                       &c->ranges_r[0], &c->ranges_r[1], &c->ranges_r[2], &c->ranges_r[3],
-                      &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams, &c->order_frame, &c->tile_dead};
+                      &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams, &c->tile_dead};
     for (DevBuf *b : bufs) b->release();
-    for (auto &b : c->slot_order) b.release();
+    for (auto &b : c->slot_order) { b[0].release(); b[1].release(); }
     for (auto &b : c->model) b.release();
     for (auto &b : c->dbg) b.release();
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
         for (int k = 0; k < 2; ++k)
             if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
     if (c->ev_count) (void)hipEventDestroy(c->ev_count);
+    for (hipEvent_t ev : {c->ev_main, c->ev_g2d_zero, c->ev_order}) if (ev) (void)hipEventDestroy(ev);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -383,6 +416,7 @@ int gs_set_stream(gs_ctx *c, void *hip_stream) {
     if (hip_stream && !c->own_stream && c->stream == want && c->borrowed_stream) return GS_OK;      // unchanged: no sync
     if (bind_device(c)) return GS_ERR_HIP;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
     if (c->own_stream && c->stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
     if (hip_stream) { c->stream = want; c->borrowed_stream = true; }
     else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; c->borrowed_stream = false; }
@@ -393,6 +427,7 @@ int gs_synchronize(gs_ctx *c) {
     if (!c) return GS_ERR_INVALID;
     if (bind_device(c)) return GS_ERR_HIP;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
     return GS_OK;
 }
 
@@ -918,6 +953,7 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.resume = r > 0; a.final_round = r == R - 1;
     a.tile_work = c->tile_work.as<uint32_t>();
     a.tile_order = order;
+    a.zero_words = c->counters.as<unsigned long long>() + 2;               // the backward's work counters (walked, evaluated)
     if (R > 1) { a.tile_pos = c->tile_pos.as<uint32_t>(); a.tile_done = c->tile_done.as<uint8_t>(); a.tile_dead = c->tile_dead.as<unsigned long long>(); }
 #ifdef GS_EXPERIMENTS
     if (c->cfg.schedule == 10 || c->cfg.schedule == 12) {
@@ -953,6 +989,18 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
         HIPCHK(c, hipMemsetAsync(c->tile_pos.p, 0, sizeof(uint32_t) * ntiles, c->stream));
     }
     const uint32_t *order = forward_order(c);
+    if (c->order_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0)); c->order_pending = false; }     // the order kernel in flight reads tile_work
+    c->g2d_zero_pending = false;
+    if (c->prev_frame_had_backward) {   // the zero fill of the backward's gradient rows (64 B per gaussian) runs on the side stream BESIDE the forward composite
+        const bool det = c->cfg.deterministic != 0;
+        const size_t n1 = c->n ? (size_t)c->n : 1, bytes = (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1;
+        HIPCHK(c, c->g2d.ensure(bytes));
+        HIPCHK(c, hipEventRecord(c->ev_main, c->stream));                 // behind the previous frame's readers of g2d
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
+        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, bytes, c->side));
+        HIPCHK(c, hipEventRecord(c->ev_g2d_zero, c->side));
+        c->g2d_zero_pending = true;
+    }
     for (int r = 0; r < R; ++r) {
         if (r > 0) { if (int rc = bin_round(c, r)) return rc; }
         if (int rc = enqueue_forward_round(c, r, order)) return rc;
@@ -967,12 +1015,14 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
             }
         }
     }
-    if (int rc = build_frame_order(c)) return rc;
+    if (int rc = build_frame_order(c, order)) return rc;
+    c->bwd_counters_zeroed = true;                                         // by the forward kernel (GsCompositeArgs.zero_words)
     const hipMemcpyKind kind = mem == GS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     if (image && image != c->img()) HIPCHK(c, hipMemcpyAsync(image, c->img(), sizeof(float) * 3 * px, kind, c->stream));
     if (transmittance && transmittance != c->tr()) HIPCHK(c, hipMemcpyAsync(transmittance, c->tr(), sizeof(float) * px, kind, c->stream));
     if (mem == GS_MEM_HOST && (image || transmittance)) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->did_fwd = true; c->did_bwd = false; c->did_bwd_composite = false;
+    c->prev_frame_had_backward = false;
     c->prev_counters_valid = true; c->prev_n_inst = c->n_inst;
     return GS_OK;
 }
@@ -1033,11 +1083,15 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
     a.variant = c->variant_bwd; a.cull = c->cfg.alpha_cull != 0;
     if (!params_only) {
         c->last_dC = dC_dev;
-        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
-        // launch order: what the order kernel made of this frame's forward (it zeroed the counters on its way, once)
+        if (c->g2d_zero_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_g2d_zero, 0)); c->g2d_zero_pending = false; }   // zeroed beside the forward
+        else HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));     // a second backward of the frame
+        // launch order: the one the frame's forward used, or (no history) what the order kernel made of that forward
         if (lpt_schedule(c)) a.tile_order = c->frame_order;
-        if (!c->bwd_counters_zeroed) HIPCHK(c, hipMemsetAsync(a.walked, 0, 112, c->stream));    // the backward's work counters + the ticket counters
+        if (!c->bwd_counters_zeroed) HIPCHK(c, hipMemsetAsync(a.walked, 0, 16, c->stream));     // the backward's work counters
         c->bwd_counters_zeroed = false;
+#ifdef GS_EXPERIMENTS
+        HIPCHK(c, hipMemsetAsync(static_cast<char *>(c->counters.p) + 64, 0, 32, c->stream));   // the backward's ticket counters (schedules 10 / 12)
+#endif
 #ifdef GS_EXPERIMENTS
         if (c->cfg.schedule == 10 || c->cfg.schedule == 12) { if (int rc = composite_sched_queue(c, a, 1)) return rc; }
 #endif
@@ -1046,6 +1100,7 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
             HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
         }
         c->did_bwd_composite = true;
+        c->prev_frame_had_backward = true;
     }
     if (composite_only) {
         if (mem == GS_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -205,6 +205,7 @@ struct GsCompositeArgs {
     const uint32_t *tile_order_plain; // A/B: the same segments in tile order (no longest-first)
     const uint32_t *tile_order_band;  // A/B: longest-first permutation for a plain launch (schedule 3), tile % 8 preserved
     uint32_t *tile_work;       // forward: evaluated entries per tile (the backward's exact work measure); may be null
+    unsigned long long *zero_words; // forward: two 64-bit words zeroed by block 0 (the backward's work counters: saves a memset command); may be null
     unsigned long long *tile_clock; // debug: GS_TILE_CLOCK_WORDS per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated,
                                     // shader cycles (s_memtime) inside the per-entry loops, shader cycles outside them (staging, waiting for the gathers)}
     int grid_waves;            // waves to launch in queue mode

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
     __shared__ float syhi[CB];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
+    if (a.zero_words && blockIdx.x == 0 && threadIdx.x < 2) a.zero_words[threadIdx.x] = 0ull;
     for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
         forward_tile<EARLY, CULL, LEAN, CLK, SLAB>(a, tile, sp, syhi, nbig);
         __syncthreads();                                                // the next tile restages sp[]

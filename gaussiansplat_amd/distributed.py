@@ -40,7 +40,7 @@ def shard_views(num_views: int, world: int, rank: int) -> list[int]:
 
 
 def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=None, sync: str = "allreduce",
-                    overlap: bool = True) -> "torch.Tensor":
+                    overlap: bool = True, pipeline: bool = True) -> "torch.Tensor":
     """One data-parallel step over a view batch (8 views on 1 / 2 / 4 / 8 GPUs = 8 / 4 / 2 / 1 views per rank, rendered
     one after the other with the gradients ACCUMULATING, then the exchange).  Returns the flat gradient buffer summed over all
     views (identical on every rank; the caller applies its optimiser and the next step starts with reset()).
@@ -50,6 +50,10 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
     started there (async: RCCL's own stream, event-ordered behind the kernel) and runs beside the geometry chain; the
     all-reduce of the 11 N geometry floats follows.  Same sums, bit for bit, as ONE all-reduce of the whole buffer -- an
     all-reduce is element-wise.  overlap = False: literally one collective.
+    pipeline (a rank with two or more views, HIP renderer): consecutive views alternate between two renderers that share the model and
+    the gradient buffer but own their per-view scratch and HIP stream (HipViewRenderer.render_views_pipelined), so the short,
+    latency-bound kernels of view k+1 (preprocess, depth sort, tile lists) run beside the composite kernels of view k; the
+    per-gaussian chains stay in view order (event-chained), so the sums are the same bits as one view after the other.
     sync = "factored": see the module docstring (needs a renderer with render_view_factored / color_slots / sh_from_views, and
     the same number of views on every rank)."""
     import torch
@@ -59,6 +63,11 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
     mine = shard_views(len(cameras), world, rank)
     r.reset()
     if sync == "allreduce":
+        if pipeline and len(mine) > 1 and hasattr(r, "render_views_pipelined"):
+            r.render_views_pipelined([cameras[v] for v in mine], [dCs[v] for v in mine])
+            if world > 1:
+                dist.all_reduce(r.flat, op=dist.ReduceOp.SUM, group=group)  # the ONE collective of the step
+            return r.flat
         split = world > 1 and overlap and len(mine) > 0 and hasattr(r, "render_view_until_sh")
         for v in (mine[:-1] if split else mine):
             r.render_view(cameras[v], dCs[v])
@@ -111,6 +120,58 @@ class HipViewRenderer:
         R.compactIdxs(self.r)
         R.forward(self.r, tps)
         R.backward(self.r, dC)
+
+    # ---- several views of one rank on two streams (multi_view_step(pipeline=True))
+    def _twins(self):
+        """Two more renderers over the SAME parameter tensors and the SAME flat gradient buffer (borrowed device pointers: no
+        copy of the model), each with its own ctx -- i.e. its own per-view scratch (payload rows, depth order, tile lists,
+        image; 288 GB of HBM hold many) -- and its own HIP stream."""
+        if getattr(self, "_tw", None) is None:
+            import torch
+            from . import renderer as R
+            r = self.r
+            H, W = r.transmittance.shape
+            cfg = r.ctx.cfg
+            tw = []
+            for _ in range(2):
+                t = R.GaussianRenderer3D(r.splatData, (W, H), r.sh_degree, device=r.imageData.device.index or 0, order=int(cfg.order),
+                                         t_min=float(cfg.t_min), deterministic=bool(cfg.deterministic), alpha_cull=bool(cfg.alpha_cull),
+                                         rank_mode=int(cfg.rank_mode), slab_mode=int(cfg.slab_mode), schedule=int(cfg.schedule))
+                t._splatGrads = r._splatGrads                              # ONE gradient buffer
+                t._grads = r._grads
+                tw.append((t, torch.cuda.Stream(device=r.imageData.device)))
+            self._tw = tw
+        return self._tw
+
+    def render_views_pipelined(self, cameras, dCs) -> None:
+        """Views alternate between the two twins.  On a twin's stream: preprocess, lists, forward, composite adjoint of its view --
+        nothing there touches what the other twin uses -- then the per-gaussian chain, which accumulates into the shared
+        gradient buffer and therefore waits (event) for the chain of the view before it.  The first view overwrites (the lazy
+        reset), the others accumulate, in view order: the same sums, bit for bit, as render_view in a loop."""
+        import torch
+        from . import renderer as R
+        r = self.r
+        cur = torch.cuda.current_stream(r.imageData.device)
+        start = torch.cuda.Event(); start.record(cur)
+        overwrite = r._grads_lazy_zero
+        prev_chain = None
+        for i, (cam, dC) in enumerate(zip(cameras, dCs)):
+            t, st = self._twins()[i & 1]
+            with torch.cuda.stream(st):
+                if i < 2:
+                    st.wait_event(start)                                   # inputs and the previous step's readers of the gradient buffer
+                tps = R.preprocess(t, cam)
+                R.compactIdxs(t)
+                R.forward(t, tps)
+                t._dC_keepalive = dC
+                t.ctx.backward(dC.data_ptr(), t._grads, overwrite=False, phase="composite")
+                if prev_chain is not None:
+                    st.wait_event(prev_chain)
+                t.ctx.backward(dC.data_ptr(), t._grads, overwrite=overwrite, phase="params")
+                prev_chain = torch.cuda.Event(); prev_chain.record(st)
+            overwrite = False
+        r._grads_lazy_zero = False
+        cur.wait_event(prev_chain)                                         # the chains are chained: the last one is the end of the batch
 
     # ---- the last view of a rank in two steps (multi_view_step(overlap=True))
     def render_view_until_sh(self, camera, dC) -> None:

@@ -70,9 +70,16 @@ def test_two_ranks_equal_the_sequential_batch_bitwise(tmp_path, overlap):
         parts.append(hv.flat.clone())
     want = (parts[0] + parts[1]).cpu().numpy()                                       # the two-rank sum: ONE float addition per element
     assert np.array_equal(got, want)
-    D.multi_view_step(hv, cams, dCs)                                                 # all eight views in one process: another association
-    seq = hv.flat.cpu().numpy().astype(np.float64)
+    D.multi_view_step(hv, cams, dCs, pipeline=False)                                 # all eight views in one process: another association
+    torch.cuda.synchronize()
+    seq32 = hv.flat.cpu().numpy().copy()
+    seq = seq32.astype(np.float64)
     assert np.linalg.norm(got - seq) <= 1e-6 * np.linalg.norm(seq)
+    # two renderers / two streams over the same model (pipeline=True) keep the chains in view order: the same bits as one after the other
+    for _ in range(2):
+        D.multi_view_step(hv, cams, dCs, pipeline=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(hv.flat.cpu().numpy(), seq32)
     assert np.abs(got[11 * N:]).max() > 0 and np.abs(got[:11 * N]).max() > 0
 
 

@@ -174,3 +174,28 @@ def test_other_cameras_bit_exact_binning_and_pixels(oracle, view, fy_scale, W, H
     assert np.all(np.abs(img - ref["image"]) <= PIX_ATOL + PIX_RTOL * np.abs(ref["image"]))
     assert np.all(np.abs(tr - ref["trans"]) <= PIX_ATOL + PIX_RTOL * np.abs(ref["trans"]))
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 65, 1000, 4096, 4097, 10_000, 16_383, 16_384, 16_385, 40_000, 262_144, 262_145])
+def test_depth_sort_paths_bit_exact(oracle, n):
+    """forward.jl:103 sortperm(-tps[3,:]): the depth sort has three code paths by size -- one workgroup holding the whole array
+    (n <= 16384: one launch), chunked with the scan fused into the scatter (<= 64 chunks: two launches per pass), chunked with
+    a scan kernel -- and all must return the oracle's stable order, with heavy ties (depths quantised to a few hundred values,
+    ties resolved by gaussian index), NaN depths (last) and the sizes around each boundary."""
+    from gaussiansplat_amd import backend as B
+    W, H, deg = 160, 96, 0
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 900 + n % 97)
+    sc = dict(sc)
+    m = sc["means"].copy()
+    m[:, 2] = np.round(m[:, 2] * 40.0) / 40.0                           # ~320 distinct depths: long runs of equal keys
+    if n > 10:
+        m[n // 3, :] = np.nan                                            # NaN depth: isless puts it last
+        m[n // 2, 2] = m[n // 2 + 1, 2]
+    sc["means"] = m.astype(np.float32)
+    pre = oracle.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam)
+    for order in (1, 2):
+        ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0)
+        for frame in range(2):
+            ctx.preprocess(); ctx.bin()
+            assert np.array_equal(ctx.get_array(B.ARR_SORT_IDXS), oracle.depth_order(pre["tps"], order)), (order, frame)
+        ctx.close()
