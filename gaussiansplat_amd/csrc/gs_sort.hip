@@ -14,6 +14,7 @@
 // with ties in gaussian-index order.  All of this is HBM-bound integer work: coalesced 8-byte
 // streams, LDS histograms and an LDS-staged scatter; no MFMA.
 #include "gs_common.h"
+#include <stdlib.h>
 
 #define RS_THREADS 256
 #define RS_ITEMS 16
@@ -159,11 +160,20 @@ __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restri
     for (int i = tid; i < NW * RS_RADIX; i += NT) (&wcnt[0][0])[i] = 0;
     {   // table entry (+ in relative mode the totals of the smaller digits: exclusive scan of the 256 row totals)
         uint32_t g = 0, t = 0;
-        if (FUSED_SCAN) {
-            if (tid < RS_RADIX) {
-                const uint32_t *row = block_hist + (size_t)tid * nblocks;
-                for (int k = 0; k < nblocks; ++k) { const uint32_t c = row[k]; t += c; if (k < (int)blockIdx.x) g += c; }
+        if (FUSED_SCAN) {                                               // (NT == 1024) wave w sums the rows w, w + 16, ...: one coalesced load of <= 64 counts per row
+            uint32_t v[RS_RADIX / NW];
+#pragma unroll
+            for (int j = 0; j < RS_RADIX / NW; ++j) v[j] = lane < nblocks ? block_hist[(size_t)(w + NW * j) * nblocks + lane] : 0u;
+#pragma unroll
+            for (int j = 0; j < RS_RADIX / NW; ++j) {
+                uint32_t all = v[j], below = lane < (int)blockIdx.x ? v[j] : 0u;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) { all += (uint32_t)__shfl_xor((int)all, d); below += (uint32_t)__shfl_xor((int)below, d); }
+                if (lane == 0) { gbase[w + NW * j] = below; lpre[w + NW * j] = all; }
             }
+            __syncthreads();
+            if (tid < RS_RADIX) { g = gbase[tid]; t = lpre[tid]; }
+            __syncthreads();
         } else if (tid < RS_RADIX) { g = block_hist[(size_t)tid * nblocks + blockIdx.x]; if (row_total) t = row_total[tid]; }
         if (row_total || FUSED_SCAN) {
             const uint32_t incl = wave_incl_scan(t, lane);
@@ -390,7 +400,10 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
                              uint32_t *final_low32, const uint32_t *keys32) {
     *result_in_b = 0;
     if (n <= 0) return hipSuccess;
-    if (keys32 && final_low32 && bit_lo == 32 && bit_hi == 64 && n <= RSS_MAX) {         // the depth sort of a small model: one launch
+#ifdef GS_EXPERIMENTS
+    // (measured on MI355X at 10 k keys: 440 us -- sixteen waves on ONE CU walking 128 dependent ballot rounds -- against 56 us for the
+    //  twelve launches of the chunked sort; kept for experiments only, GS_SORT_ONE_WG=1)
+    if (keys32 && final_low32 && bit_lo == 32 && bit_hi == 64 && n <= RSS_MAX && getenv("GS_SORT_ONE_WG")) {
         const size_t lds = sizeof(uint64_t) * RSS_MAX;
         static bool attr_set = false;
         if (!attr_set) {
@@ -401,6 +414,7 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
         hipLaunchKernelGGL(rs_sort_small_kernel, dim3(1), dim3(RSS_THREADS), lds, stream, keys32, (int)n, final_low32);
         return hipGetLastError();
     }
+#endif
     const int nblocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
     uint64_t *src = a, *dst = b;
     // equal-width digits of at most 8 bits: fewer bins per pass = longer contiguous runs in the scatter

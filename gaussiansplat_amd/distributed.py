@@ -148,10 +148,14 @@ class HipViewRenderer:
         nothing there touches what the other twin uses -- then the per-gaussian chain, which accumulates into the shared
         gradient buffer and therefore waits (event) for the chain of the view before it.  The first view overwrites (the lazy
         reset), the others accumulate, in view order: the same sums, bit for bit, as render_view in a loop."""
+        import numpy as np
         import torch
         from . import renderer as R
         r = self.r
-        cur = torch.cuda.current_stream(r.imageData.device)
+        dev = r.imageData.device
+        dCs = [(d if isinstance(d, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(d, np.float32))).to(dev, torch.float32).contiguous()
+               for d in dCs]                                                # (uploads, if any, on the caller's stream: before `start`)
+        cur = torch.cuda.current_stream(dev)
         start = torch.cuda.Event(); start.record(cur)
         overwrite = r._grads_lazy_zero
         prev_chain = None

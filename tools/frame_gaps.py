@@ -37,6 +37,23 @@ def main():
     frames = frames[int(0.4 * len(frames)):]
     span = sum(f[-1][1] - f[0][0] for f in frames) / max(len(frames), 1)
     busy = sum(sum(e - s for s, e, _ in f) for f in frames) / max(len(frames), 1)
+    # whole trace: device time covered by at least one kernel vs the sum of the kernel durations (their difference = time two
+    # kernels of different streams ran at once), over the second half of the run
+    half = rows[len(rows) // 2:]
+    cover, cur_s, cur_e = 0, None, None
+    for s0, e0, _ in half:
+        if cur_e is None or s0 > cur_e:
+            if cur_e is not None:
+                cover += cur_e - cur_s
+            cur_s, cur_e = s0, e0
+        else:
+            cur_e = max(cur_e, e0)
+    if cur_e is not None:
+        cover += cur_e - cur_s
+    total = sum(e0 - s0 for s0, e0, _ in half)
+    wall = half[-1][1] - half[0][0] if half else 0
+    overlap = {"second_half_wall_us": wall / 1e3, "covered_us": cover / 1e3, "kernel_sum_us": total / 1e3, "overlapped_us": (total - cover) / 1e3,
+               "idle_us": (wall - cover) / 1e3, "preprocess_launches": sum("gs_preprocess_kernel" in k for _, _, k in half)}
     per = defaultdict(lambda: [0.0, 0.0, 0])
     for f in frames:
         prev_end = None
@@ -49,7 +66,7 @@ def main():
             p[2] += 1
             prev_end = max(prev_end or 0, e)
     nf = max(len(frames), 1)
-    res = {"frames": len(frames), "frame_span_us": span / 1e3, "kernel_sum_us": busy / 1e3, "idle_us": (span - busy) / 1e3,
+    res = {"overlap": overlap, "frames": len(frames), "frame_span_us": span / 1e3, "kernel_sum_us": busy / 1e3, "idle_us": (span - busy) / 1e3,
            "kernels": {k: {"per_frame_us": v[0] / nf / 1e3, "gap_before_us": v[1] / nf / 1e3, "launches_per_frame": v[2] / nf} for k, v in per.items()}}
     print(json.dumps({k: v for k, v in res.items() if k != "kernels"}))
     for k, v in sorted(res["kernels"].items(), key=lambda kv: -kv[1]["per_frame_us"]):
