@@ -264,11 +264,19 @@ def main():
         D.multi_view_step(hv, [cams[v] for v in batch], [dCs[v] for v in batch], sync=sync_mode[0], overlap=not args.no_overlap,
                           pipeline=not args.no_pipeline)
 
+    def stage_stats(r, reset=False):
+        """per-stage hipEvent sums of every ctx the renderer's views ran through (the pipelined view batches use two more)"""
+        tot = {}
+        for ctx in r._bench_hv.contexts() if "_bench_hv" in r.__dict__ else [r.ctx]:
+            for k, (sm, ct) in ctx.stage_stats(reset=reset).items():
+                a = tot.setdefault(k, [0.0, 0]); a[0] += sm; a[1] += ct
+        return {k: (v[0], v[1]) for k, v in tot.items()}
+
     def timed(r, steps, warmup, k0=0):
         for k in range(warmup):
             step(r, k0 + k)
         torch.cuda.synchronize()
-        r.ctx.stage_stats(reset=True)
+        stage_stats(r, reset=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -293,7 +301,7 @@ def main():
     ra = make(args.t_min, 1)
     ka = max(2 * len(batches), min(args.steps, 6))
     timed(ra, ka, max(len(batches), min(args.warmup, 4)))
-    survey = ra.ctx.stage_stats()
+    survey = stage_stats(ra)
     stage_ms = {k: (s / c if c else 0.0) for k, (s, c) in survey.items()}
     dom = max(stage_ms, key=stage_ms.get)
     if world > 1:                                                          # every rank must time the same stage
@@ -308,11 +316,12 @@ def main():
     # Pass B: THE timed region -- W warmup steps, then exactly K steps between barriers + synchronize.
     r = make(args.t_min, 2 + STAGES.index(dom))
     dt = timed(r, args.steps, args.warmup)
-    dom_sum, dom_cnt = r.ctx.stage_stats()[dom]
+    dom_sum, dom_cnt = stage_stats(r)[dom]
     dom_ms = dom_sum / dom_cnt if dom_cnt else 0.0
-    I = r.ctx.num_instances                                  # of the last view rendered
-    I1 = r.ctx.num_coarse_instances
-    wc = r.ctx.work_counters_ex()
+    lctx = r._bench_hv.last_ctx                              # the ctx of the last view rendered
+    I = lctx.num_instances
+    I1 = lctx.num_coarse_instances
+    wc = lctx.work_counters_ex()
     wf, wb = wc["walked_fwd"], wc["walked_bwd"]
     value = views_per_step * n * args.steps / dt / 1e6
     nranks = dist.get_world_size() if world > 1 else 1
@@ -377,7 +386,7 @@ def main():
                        "pipeline": (not args.no_pipeline) if views_per_step // world > 1 else None,
                        "grad_sync": args.grad_sync if world > 1 else None, "allreduce_overlap": (not args.no_overlap) if world > 1 else None,
                        "backend": args.backend if world > 1 else None,
-                       "rank_mode": int(r.ctx.cfg.rank_mode), "binning_rounds": r.ctx.num_rounds, "schedule": int(r.ctx.cfg.schedule) or 3,
+                       "rank_mode": int(r.ctx.cfg.rank_mode), "binning_rounds": lctx.num_rounds, "schedule": int(r.ctx.cfg.schedule) or 3,
                        "view_slots": not args.no_view_slots,
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
                        "instances": I, "coarse_instances": I1, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
@@ -426,7 +435,7 @@ def main():
         r0 = make(0.0, 1)
         k0 = max(2, min(args.steps, 4))
         dt0 = timed(r0, k0, 2)
-        st0 = r0.ctx.stage_stats()
+        st0 = stage_stats(r0)
         if rank == 0:
             out["literal_t_min_0"] = {"value": n * k0 / dt0 / 1e6, "unit": "Msplats/s", "ms_per_step": dt0 / k0 * 1e3, "steps": k0,
                                       "stage_ms": {k: round(s / c if c else 0.0, 4) for k, (s, c) in st0.items()}}

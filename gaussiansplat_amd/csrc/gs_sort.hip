@@ -14,7 +14,6 @@
 // with ties in gaussian-index order.  All of this is HBM-bound integer work: coalesced 8-byte
 // streams, LDS histograms and an LDS-staged scatter; no MFMA.
 #include "gs_common.h"
-#include <stdlib.h>
 
 #define RS_THREADS 256
 #define RS_ITEMS 16
@@ -137,11 +136,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
 // out32 != null (last pass of a (key | id) pair sort): only the low word -- the id -- is written, as 32 bits.
 // NT threads per 4096-key chunk: 256 (sixteen rounds per wave) for the big instance sorts, 1024 (four rounds, sixteen waves)
 // for the depth sort, whose 244 workgroups at 1 M gaussians would otherwise leave one wave per SIMD to hide every latency.
-// FUSED_SCAN (sorts of at most RS_FUSE_BLOCKS chunks, e.g. config C2's 100 k depth keys): block_hist holds the RAW per-chunk counts and
-// every workgroup forms its bases itself -- thread d sums row d below its own chunk and over all chunks (<= 64 words per thread from
-// L2) -- so a pass is two launches (histogram, scatter) instead of three.
-#define RS_FUSE_BLOCKS 64
-template <int NT, bool ATOMIC_RANK, bool FUSED_SCAN = false>
+template <int NT, bool ATOMIC_RANK>
 __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ in32,
                                                          uint64_t *__restrict__ out,
                                                          int64_t n, int shift, uint32_t mask,
@@ -160,22 +155,8 @@ __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restri
     for (int i = tid; i < NW * RS_RADIX; i += NT) (&wcnt[0][0])[i] = 0;
     {   // table entry (+ in relative mode the totals of the smaller digits: exclusive scan of the 256 row totals)
         uint32_t g = 0, t = 0;
-        if (FUSED_SCAN) {                                               // (NT == 1024) wave w sums the rows w, w + 16, ...: one coalesced load of <= 64 counts per row
-            uint32_t v[RS_RADIX / NW];
-#pragma unroll
-            for (int j = 0; j < RS_RADIX / NW; ++j) v[j] = lane < nblocks ? block_hist[(size_t)(w + NW * j) * nblocks + lane] : 0u;
-#pragma unroll
-            for (int j = 0; j < RS_RADIX / NW; ++j) {
-                uint32_t all = v[j], below = lane < (int)blockIdx.x ? v[j] : 0u;
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) { all += (uint32_t)__shfl_xor((int)all, d); below += (uint32_t)__shfl_xor((int)below, d); }
-                if (lane == 0) { gbase[w + NW * j] = below; lpre[w + NW * j] = all; }
-            }
-            __syncthreads();
-            if (tid < RS_RADIX) { g = gbase[tid]; t = lpre[tid]; }
-            __syncthreads();
-        } else if (tid < RS_RADIX) { g = block_hist[(size_t)tid * nblocks + blockIdx.x]; if (row_total) t = row_total[tid]; }
-        if (row_total || FUSED_SCAN) {
+        if (tid < RS_RADIX) { g = block_hist[(size_t)tid * nblocks + blockIdx.x]; if (row_total) t = row_total[tid]; }
+        if (row_total) {
             const uint32_t incl = wave_incl_scan(t, lane);
             if (tid < RS_RADIX && lane == 63) sm[w] = incl;
             __syncthreads();
@@ -254,98 +235,6 @@ __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restri
     }
 }
 
-// ---------------------------------------------------------------- whole sort in ONE workgroup (n <= 16384: config C1's 10 k gaussians)
-// The twelve launches of the chunked sort cost 4-5 us each whatever the size; below 16 K keys one workgroup holds the whole array:
-// sixteen (key | index) pairs per thread in registers, one 128 KiB LDS image to permute them through, the same stable ballot
-// ranks as rs_scatter_kernel (order = (wave, round, lane) = ascending index).  A digit on which all keys agree (the top bytes of
-// depth keys of one scene) is skipped.  Writes the permutation (the low words).
-#define RSS_THREADS 1024
-#define RSS_ITEMS 16
-#define RSS_MAX (RSS_THREADS * RSS_ITEMS)
-__global__ __launch_bounds__(RSS_THREADS) void rs_sort_small_kernel(const uint32_t *__restrict__ keys32, int n, uint32_t *__restrict__ out_ids) {
-    constexpr int NW = RSS_THREADS / GS_WAVE;
-    extern __shared__ uint64_t skeys[];                  // RSS_MAX
-    __shared__ uint32_t wcnt[NW][RS_RADIX];
-    __shared__ uint32_t lpre[RS_RADIX];
-    __shared__ uint32_t sm[RS_RADIX / GS_WAVE];
-    __shared__ uint32_t uniform_digit;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t khi[RSS_ITEMS], klo[RSS_ITEMS];                             // depth key, index
-#pragma unroll
-    for (int r = 0; r < RSS_ITEMS; ++r) {
-        const int li = w * (GS_WAVE * RSS_ITEMS) + r * GS_WAVE + lane;
-        khi[r] = li < n ? keys32[li] : 0xFFFFFFFFu;
-        klo[r] = (uint32_t)li;
-    }
-#define RSS_PEERS(dg, valid, peers) \
-    unsigned long long peers = __ballot(valid); \
-    _Pragma("unroll") for (int b_ = 0; b_ < 8; ++b_) { const unsigned long long bal_ = __ballot(((dg) >> b_) & 1u); peers &= (((dg) >> b_) & 1u) ? bal_ : ~bal_; }
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 8 * pass;
-        for (int i = tid; i < NW * RS_RADIX; i += RSS_THREADS) (&wcnt[0][0])[i] = 0;
-        if (tid == 0) uniform_digit = 0;
-        __syncthreads();
-        // count: keys per (wave, digit) -- the group leader adds the group's size
-#pragma unroll
-        for (int r = 0; r < RSS_ITEMS; ++r) {
-            const bool valid = (int)(w * (GS_WAVE * RSS_ITEMS) + r * GS_WAVE + lane) < n;
-            const uint32_t dg = valid ? ((khi[r] >> shift) & 255u) : 255u;
-            RSS_PEERS(dg, valid, peers)
-            if (valid && (peers & lt_mask) == 0ull) wcnt[w][dg] += (uint32_t)__popcll(peers);
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_sched_barrier(0);                           // one round at a time: sixteen rounds of nine ballots in flight spill
-        }
-        __syncthreads();
-        uint32_t tot = 0;
-        if (tid < RS_RADIX) {                                            // counts -> exclusive offsets over the waves; digit totals
-#pragma unroll
-            for (int k = 0; k < NW; ++k) { const uint32_t c = wcnt[k][tid]; wcnt[k][tid] = tot; tot += c; }
-            if (tot == (uint32_t)n) uniform_digit = 1;                   // every key has this digit: the pass would move nothing
-        }
-        const uint32_t incl = wave_incl_scan(tot, lane);
-        if (tid < RS_RADIX && lane == 63) sm[w] = incl;
-        __syncthreads();
-        if (tid < RS_RADIX) {
-            uint32_t woff = 0;
-            for (int k = 0; k < w; ++k) woff += sm[k];
-            lpre[tid] = woff + incl - tot;
-        }
-        __syncthreads();
-        const bool last = pass == 3;
-        if (!uniform_digit || last) {                                    // (uniform over the workgroup)
-            // place: the ranks again (same ballots), wcnt[w][digit] is now the wave's running cursor inside the digit
-#pragma unroll
-            for (int r = 0; r < RSS_ITEMS; ++r) {
-                const bool valid = (int)(w * (GS_WAVE * RSS_ITEMS) + r * GS_WAVE + lane) < n;
-                const uint32_t dg = valid ? ((khi[r] >> shift) & 255u) : 255u;
-                RSS_PEERS(dg, valid, peers)
-                const uint32_t before = wcnt[w][dg];
-                if (valid) skeys[lpre[dg] + before + (uint32_t)__popcll(peers & lt_mask)] = ((uint64_t)khi[r] << 32) | klo[r];
-                __builtin_amdgcn_wave_barrier();
-                if (valid && (peers & lt_mask) == 0ull) wcnt[w][dg] = before + (uint32_t)__popcll(peers);
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-            if (last) {
-#pragma unroll
-                for (int r = 0; r < RSS_ITEMS; ++r) { const int li = r * RSS_THREADS + tid; if (li < n) out_ids[li] = (uint32_t)skeys[li]; }
-            } else {
-#pragma unroll
-                for (int r = 0; r < RSS_ITEMS; ++r) {
-                    const int li = w * (GS_WAVE * RSS_ITEMS) + r * GS_WAVE + lane;
-                    const uint64_t k = li < n ? skeys[li] : ~0ull;
-                    khi[r] = (uint32_t)(k >> 32); klo[r] = (uint32_t)k;
-                }
-            }
-        }
-        __syncthreads();
-    }
-#undef RSS_PEERS
-}
-
 // ---------------------------------------------------------------- lane-order probe of the LDS atomic rank
 // 256 workgroups x 32 rounds: every wave draws digits from a hash (all-distinct, few-valued, constant and 32-valued
 // patterns, ~6 % inactive lanes), takes atomicAdd-return on an LDS counter row and compares the value with the ballot
@@ -400,21 +289,6 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
                              uint32_t *final_low32, const uint32_t *keys32) {
     *result_in_b = 0;
     if (n <= 0) return hipSuccess;
-#ifdef GS_EXPERIMENTS
-    // (measured on MI355X at 10 k keys: 440 us -- sixteen waves on ONE CU walking 128 dependent ballot rounds -- against 56 us for the
-    //  twelve launches of the chunked sort; kept for experiments only, GS_SORT_ONE_WG=1)
-    if (keys32 && final_low32 && bit_lo == 32 && bit_hi == 64 && n <= RSS_MAX && getenv("GS_SORT_ONE_WG")) {
-        const size_t lds = sizeof(uint64_t) * RSS_MAX;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rs_sort_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(rs_sort_small_kernel, dim3(1), dim3(RSS_THREADS), lds, stream, keys32, (int)n, final_low32);
-        return hipGetLastError();
-    }
-#endif
     const int nblocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
     uint64_t *src = a, *dst = b;
     // equal-width digits of at most 8 bits: fewer bins per pass = longer contiguous runs in the scatter
@@ -431,11 +305,7 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
         const uint32_t mask = (1u << bits) - 1u;
         const uint32_t *k32 = pass == 0 ? keys32 : nullptr;
         uint32_t *o32 = (final_low32 && shift + width >= bit_hi) ? final_low32 : nullptr;      // last pass: ids only
-        if (small && nblocks <= RS_FUSE_BLOCKS) {                        // two launches per pass: the scatter scans the raw counts itself
-            hipLaunchKernelGGL(rs_hist_kernel<1024>, dim3(nblocks), dim3(1024), 0, stream, src, k32, n, shift, mask, block_hist, nblocks, (uint32_t *)nullptr);
-            if (ballot_ranks) hipLaunchKernelGGL((rs_scatter_kernel<1024, false, true>), dim3(nblocks), dim3(1024), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32, (const uint32_t *)nullptr);
-            else hipLaunchKernelGGL((rs_scatter_kernel<1024, true, true>), dim3(nblocks), dim3(1024), 0, stream, src, k32, dst, n, shift, mask, block_hist, nblocks, o32, (const uint32_t *)nullptr);
-        } else if (small) {
+        if (small) {
             uint32_t *tot = digit_total + pass * RS_RADIX;
             hipLaunchKernelGGL(rs_hist_kernel<1024>, dim3(nblocks), dim3(1024), 0, stream, src, k32, n, shift, mask, block_hist, nblocks, (uint32_t *)nullptr);
             hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, (const uint32_t *)nullptr, tot);

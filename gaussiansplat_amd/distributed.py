@@ -105,6 +105,11 @@ class HipViewRenderer:
 
     def __init__(self, renderer):
         self.r = renderer
+        self.last_ctx = renderer.ctx            # the ctx that rendered the most recent view (introspection: counters, instance counts)
+
+    def contexts(self):
+        """every gs_ctx views are rendered through (the renderer's own, and the two twins of the pipelined mode once they exist)"""
+        return [self.r.ctx] + [t.ctx for t, _ in (getattr(self, "_tw", None) or [])]
 
     @property
     def flat(self):
@@ -120,6 +125,7 @@ class HipViewRenderer:
         R.compactIdxs(self.r)
         R.forward(self.r, tps)
         R.backward(self.r, dC)
+        self.last_ctx = self.r.ctx
 
     # ---- several views of one rank on two streams (multi_view_step(pipeline=True))
     def _twins(self):
@@ -136,7 +142,8 @@ class HipViewRenderer:
             for _ in range(2):
                 t = R.GaussianRenderer3D(r.splatData, (W, H), r.sh_degree, device=r.imageData.device.index or 0, order=int(cfg.order),
                                          t_min=float(cfg.t_min), deterministic=bool(cfg.deterministic), alpha_cull=bool(cfg.alpha_cull),
-                                         rank_mode=int(cfg.rank_mode), slab_mode=int(cfg.slab_mode), schedule=int(cfg.schedule))
+                                         rank_mode=int(cfg.rank_mode), slab_mode=int(cfg.slab_mode), schedule=int(cfg.schedule),
+                                         profile_stages=int(cfg.profile_stages))
                 t._splatGrads = r._splatGrads                              # ONE gradient buffer
                 t._grads = r._grads
                 tw.append((t, torch.cuda.Stream(device=r.imageData.device)))
@@ -174,6 +181,7 @@ class HipViewRenderer:
                 t.ctx.backward(dC.data_ptr(), t._grads, overwrite=overwrite, phase="params")
                 prev_chain = torch.cuda.Event(); prev_chain.record(st)
             overwrite = False
+            self.last_ctx = t.ctx
         r._grads_lazy_zero = False
         cur.wait_event(prev_chain)                                         # the chains are chained: the last one is the end of the batch
 
@@ -186,6 +194,7 @@ class HipViewRenderer:
         self._dC = dC
         R.backward(self.r, dC, phase="composite")
         R.backward(self.r, dC, phase="params_sh")
+        self.last_ctx = self.r.ctx
 
     def finish_geometry(self) -> None:
         from . import renderer as R
