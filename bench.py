@@ -413,8 +413,9 @@ def main():
         v8 = list(range(8))
         cams8 = [camera_of(v) for v in v8]
         dC8 = [torch.as_tensor(synthetic.make_dC(W, H, seed + v)).cuda() for v in v8]
-        hv = D.HipViewRenderer(r)
-        for _ in range(2):
+        r8 = make(args.t_min, 0)
+        hv = D.HipViewRenderer(r8)
+        for _ in range(3):
             D.multi_view_step(hv, cams8, dC8, pipeline=not args.no_pipeline)
         torch.cuda.synchronize()
         k8 = max(2, min(args.steps // 4, 10))
@@ -427,7 +428,7 @@ def main():
                            "views_per_step": 8, "n_gpus": 1, "steps": k8, "pipeline": not args.no_pipeline,
                            "what": "config C4 on ONE GPU: the eight views of the 8-GPU batch one after the other, gradients accumulating, no collective "
                                    "(= `bench.py --config C4 --gpus 1`): the N = 1 point of the strong-scaling curve `--gpus 2/4/8` continues"}
-        del hv
+        del hv, r8
     if not args.no_literal and args.t_min > 0 and extras:          # extra measurements only at N = 1
         del r
         gc.collect()

@@ -51,8 +51,9 @@ def _deps() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def build(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
-    out_dir = os.path.join(HERE, "lib_exp") if experiments else OUT_DIR
+def build(force: bool = False, verbose: bool = False, experiments: bool = False, tag: str = "", defines=()) -> str:
+    """tag / defines: a variant build for same-box A/B runs (e.g. tag="p48", defines=["-DGS_PAYLOAD_QUADS=3"] -> lib_p48/)."""
+    out_dir = os.path.join(HERE, "lib_" + tag) if tag else os.path.join(HERE, "lib_exp") if experiments else OUT_DIR
     lib = os.path.join(out_dir, "libgsplat_hip.so")
     os.makedirs(out_dir, exist_ok=True)
     hipcc = _hipcc()
@@ -61,6 +62,7 @@ def build(force: bool = False, verbose: bool = False, experiments: bool = False)
     for src, extra in SOURCES.items():
         if experiments:
             extra = [*extra, "-DGS_EXPERIMENTS"]
+        extra = [*extra, *defines]
         s = os.path.join(CSRC, src)
         o = os.path.join(out_dir, src.replace(".hip", ".o"))
         objs.append(o)
@@ -84,4 +86,6 @@ def build(force: bool = False, verbose: bool = False, experiments: bool = False)
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))
+    tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else ""
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv, tag=tag,
+                defines=[a for a in sys.argv[1:] if a.startswith("-D")]))

@@ -86,6 +86,7 @@ struct gs_ctx {
     bool have_cam = false, did_pre = false, did_bin = false, did_fwd = false, did_bwd = false, did_bwd_composite = false;
     int gx = 0, gy = 0;
 
+    DevBuf invcov;                           // 4 x n raw conic (introspection; the payload rows carry it scaled)
     DevBuf payload, depth_key, rect, pairs_a, pairs_b, perm, offsets, block_sums;
     DevBuf inst_a, inst_b, table, digit_total, ranges, image, trans, g2d, stage_in;
     DevBuf dbg[7];
@@ -392,7 +393,7 @@ int gs_destroy(gs_ctx *c) {
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
                       &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->tilecnt,
                       &c->ranges_r[0], &c->ranges_r[1], &c->ranges_r[2], &c->ranges_r[3],
-                      &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams, &c->tile_dead};
+                      &c->invcov, &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams, &c->tile_dead};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->slot_order) { b[0].release(); b[1].release(); }
     for (auto &b : c->model) b.release();
@@ -526,6 +527,7 @@ int gs_preprocess(gs_ctx *c) {
     c->frame_id += 1;
     const size_t n = (size_t)c->n, n1 = n ? n : 1;
     HIPCHK(c, c->payload.ensure(sizeof(GsPayload) * n1));
+    HIPCHK(c, c->invcov.ensure(sizeof(float) * 4 * n1));
     HIPCHK(c, c->depth_key.ensure(sizeof(uint32_t) * n1));
     HIPCHK(c, c->rect.ensure(sizeof(uint16_t) * 4 * n1));
     // the tile grid is fixed by the image: the reference passes blocks = size/threads (main.jl:9-11)
@@ -535,7 +537,7 @@ int gs_preprocess(gs_ctx *c) {
         GsPreprocess2DArgs a2{};
         a2.n = c->n; a2.W = c->cam.W; a2.H = c->cam.H; a2.gx = c->gx; a2.gy = c->gy;
         a2.means = c->means; a2.scales = c->scales; a2.rots = c->quats; a2.opac = c->opac; a2.colors = c->shs;
-        a2.payload = c->payload.as<GsPayload>(); a2.depth_key = c->depth_key.as<uint32_t>(); a2.rect = c->rect.as<uint16_t>();
+        a2.payload = c->payload.as<GsPayload>(); a2.invcov = c->invcov.as<float>(); a2.depth_key = c->depth_key.as<uint32_t>(); a2.rect = c->rect.as<uint16_t>();
         if (c->cfg.export_debug) {
             const size_t w[7] = {4, 4, 2, 9, 4, 4, 4};
             for (int i = 0; i < 7; ++i) HIPCHK(c, c->dbg[i].ensure(sizeof(float) * w[i] * n1));
@@ -554,6 +556,7 @@ int gs_preprocess(gs_ctx *c) {
     a.gx = c->gx; a.gy = c->gy;
     a.means = c->means; a.scales = c->scales; a.quats = c->quats; a.opac = c->opac; a.shs = c->shs;
     a.payload = c->payload.as<GsPayload>();
+    a.invcov = c->invcov.as<float>();
     a.depth_key = c->depth_key.as<uint32_t>();
     a.rect = c->rect.as<uint16_t>();
     if (c->cfg.export_debug) {
@@ -1333,8 +1336,9 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
         case GS_ARR_COV3D: if (int r = need_dbg(3, 9)) return r; break;
         case GS_ARR_COV2D: if (int r = need_dbg(4, 4)) return r; break;
         case GS_ARR_BBS: if (int r = need_dbg(6, 4)) return r; break;
-        case GS_ARR_MU: case GS_ARR_INVCOV: case GS_ARR_RGB: case GS_ARR_SIG: {
-            const size_t w = which == GS_ARR_MU ? 2 : which == GS_ARR_INVCOV ? 4 : which == GS_ARR_RGB ? 3 : 1;
+        case GS_ARR_INVCOV: src = c->invcov.p; need = sizeof(float) * 4 * n; break;
+        case GS_ARR_MU: case GS_ARR_RGB: case GS_ARR_SIG: {
+            const size_t w = which == GS_ARR_MU ? 2 : which == GS_ARR_RGB ? 3 : 1;
             if ((size_t)bytes != sizeof(float) * w * n) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
             std::vector<GsPayload> h(n ? n : 1);
             HIPCHK(c, hipMemcpyAsync(h.data(), c->payload.p, sizeof(GsPayload) * n, hipMemcpyDeviceToHost, c->stream));
@@ -1343,7 +1347,6 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
             for (size_t g = 0; g < n; ++g) {
                 const GsPayload &p = h[g];
                 if (which == GS_ARR_MU) { o[2 * g] = p.mx; o[2 * g + 1] = p.my; }
-                else if (which == GS_ARR_INVCOV) { o[4 * g] = p.i0; o[4 * g + 1] = p.i1; o[4 * g + 2] = p.i2; o[4 * g + 3] = p.i3; }     // the raw conic (fourth quad of the row)
                 else if (which == GS_ARR_RGB) { o[3 * g] = p.r; o[3 * g + 1] = p.g; o[3 * g + 2] = p.b; }
                 else o[g] = p.sig;
             }
@@ -1398,12 +1401,14 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
             }
             // the device rows hold raw moments: apply the per-gaussian factors with the view's payload (sig, conic)
             std::vector<GsPayload> pay(n ? n : 1);
+            std::vector<float> ic(4 * (n ? n : 1));
             if (n) HIPCHK(c, hipMemcpyAsync(pay.data(), c->payload.p, sizeof(GsPayload) * n, hipMemcpyDeviceToHost, c->stream));
+            if (n) HIPCHK(c, hipMemcpyAsync(ic.data(), c->invcov.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             for (size_t g = 0; g < n; ++g) {
                 float row[10];
                 for (int i = 0; i < 10; ++i) row[i] = o[10 * g + i];
-                gs_g2d_to_grads(row, pay[g].sig, pay[g].i0, 0.5f * (pay[g].i1 + pay[g].i2), pay[g].i3);
+                gs_g2d_to_grads(row, pay[g].sig, ic[4 * g], 0.5f * (ic[4 * g + 1] + ic[4 * g + 2]), ic[4 * g + 3]);
                 for (int i = 0; i < 10; ++i) o[10 * g + i] = row[i];
             }
             return GS_OK;

@@ -6,12 +6,18 @@
 #define GS_TILE 16
 #define GS_WAVE 64
 
-// Per-gaussian, per-view splat payload staged through LDS by the composite kernels: ONE 64-byte row per gaussian, 64-byte
-// aligned, so the random gather of a list entry touches a single 64-byte memory sector (the 48-byte rows of rounds 1-2
-// straddled two sectors for every second gaussian).  The composite kernels read the first three quads; everything in them
-// that is constant per (gaussian, view) is already in the form the inner loops use (log2 of the sigmoid, the conic scaled
-// by -1/2 log2 e), so the staging lane of a (tile, splat) entry has no v_log and no rescaling left to do.  Replaces the
-// 26 scattered floats the reference gathers per (pixel, slot) (src/splat.jl:224-252).
+// Per-gaussian, per-view splat payload staged through LDS by the composite kernels: GS_PAYLOAD_QUADS quads of 16 bytes per
+// gaussian.  Everything in it that is constant per (gaussian, view) is already in the form the inner loops use (log2 of the
+// sigmoid, the conic scaled by -1/2 log2 e), so the staging lane of a (tile, splat) entry has no v_log and no rescaling left
+// to do.  Replaces the 26 scattered floats the reference gathers per (pixel, slot) (src/splat.jl:224-252).
+// Row size.  The kernels read three quads (48 bytes).  Round 3 measured both row sizes on MI355X (tools/ab_payload.sh: same box,
+// interleaved runs): rows padded to 64 bytes (GS_PAYLOAD_QUADS = 4) put every gather inside one 64-byte line,
+// 48-byte rows straddle a line for every second gaussian but move fewer bytes (the memory side fetches 32-byte sectors:
+// FETCH_SIZE 457 MB vs 641 MB per C3 forward).  Frame time equal within 0.1 % (1.4679 vs 1.4693 ms over three runs each), the
+// preprocess 8 us faster with 48 bytes: 48 is the default.
+#ifndef GS_PAYLOAD_QUADS
+#define GS_PAYLOAD_QUADS 3
+#endif
 struct __attribute__((aligned(16))) GsPayload {
     float mx, my;        // renderer.positions (mu')                      projection.jl:88-93
     float l2s;           // min(log2(cusigmoid(opacity)), -2.6e-7): alpha = exp2(pw + l2s) < 1 strictly   splat.jl:175-178,247
@@ -20,9 +26,11 @@ struct __attribute__((aligned(16))) GsPayload {
     uint32_t bby;        // int16 ymin | int16 ymax << 16                 boundingbox.jl:26-27
     float r, g, b;       // sh2color                                      splat.jl:180-193
     float sig;           // cusigmoid(opacity)                            splat.jl:175-178
-    float i0, i1, i2, i3;// renderer.invCov2ds, column-major              cov2d.jl:30-45   (introspection only: gs_get_array)
+#if GS_PAYLOAD_QUADS == 4
+    float pad[4];        // one 64-byte line per gaussian
+#endif
 };
-static_assert(sizeof(GsPayload) == 64, "payload must be 64 bytes");
+static_assert(sizeof(GsPayload) == 16 * GS_PAYLOAD_QUADS, "payload row size");
 #define GS_NEG_HALF_LOG2E (-0.72134752044448170368f)
 #define GS_L2S_CAP (-2.6e-7f)
 
@@ -45,6 +53,7 @@ struct GsPreprocessArgs {
     int gx, gy;
     const float *means, *scales, *quats, *opac, *shs;
     GsPayload *payload;
+    float *invcov;        // 4 x n: renderer.invCov2ds (cov2d.jl:30-45), the raw conic; not read by the composite kernels (their rows carry it scaled)
     uint32_t *depth_key;
     uint16_t *rect;       // 4 x n : x0 x1 y0 y1 (1-based inclusive, x0 == 0 -> no tile)
     GsDebugArrays dbg;
@@ -58,6 +67,7 @@ struct GsPreprocess2DArgs {
     int W, H, gx, gy;
     const float *means, *scales, *rots, *opac, *colors;    // 2n, 2n, n, n, 3n
     GsPayload *payload;
+    float *invcov;                                         // 4 x n raw conic
     uint32_t *depth_key;
     uint16_t *rect;
     GsDebugArrays dbg;                                     // mu, cov2d, invcov, bbs used

@@ -5,7 +5,7 @@
 // C += rgb*alpha*T, T *= 1-alpha, for list entries whose pixel box contains the pixel
 // (splat.jl:240); no alpha clamp / 1/255 cut (reference has none).  The reference gathers
 // 26 floats per (pixel, slot) from global memory and evaluates SH per pixel; here the per-view
-// payload (one 64-byte row) is gathered once per (tile, splat) with coalesced id loads, staged in LDS
+// payload (three quads of a 48- or 64-byte row) is gathered once per (tile, splat) with coalesced id loads, staged in LDS
 // and broadcast to the lanes.
 //
 // Mapping (wave64-first, not a 16x16 CUDA block): ONE wave per tile, lane l owns the four
@@ -258,7 +258,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     uint32_t id2 = 0;
     if (!LEAN) {
         const uint32_t pos2 = pos + min((uint32_t)CB - (gp0 & (CB - 1)), s1 - s0);      // first position of the second batch + lane
-        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
+        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[GS_PAYLOAD_QUADS * g]; n1 = pay4[GS_PAYLOAD_QUADS * g + 1]; n2 = pay4[GS_PAYLOAD_QUADS * g + 2]; }
         if (pos2 < s1) id2 = a.ids[pos2];
     }
     uint32_t gp = gp0;                                                  // list position of `base` in the tile's whole list
@@ -282,7 +282,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         if (LEAN) {
             n0 = n1 = n2 = make_float4(0.f, 0.f, 0.f, 0.f);
             pos = base + lane;
-            if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
+            if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[GS_PAYLOAD_QUADS * g]; n1 = pay4[GS_PAYLOAD_QUADS * g + 1]; n2 = pay4[GS_PAYLOAD_QUADS * g + 2]; }
         }
         const float yhi_l = stage_record<false>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
         int slot = lane, nk = cnt;
@@ -301,7 +301,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
         if (!LEAN) {
-            if (pos < s1) { const size_t g = id2; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; }
+            if (pos < s1) { const size_t g = id2; n0 = pay4[GS_PAYLOAD_QUADS * g]; n1 = pay4[GS_PAYLOAD_QUADS * g + 1]; n2 = pay4[GS_PAYLOAD_QUADS * g + 2]; }
             const uint32_t pos2 = pos + min((uint32_t)CB, s1 - base);                   // (batches after the first start at multiples of CB)
             if (base < s1 && pos2 < s1) id2 = a.ids[pos2];
         }
@@ -580,7 +580,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     uint32_t id2 = 0;                                                     // ids run two batches ahead, payload rows one (see the forward)
     {
         const uint32_t pos2 = pos + min((uint32_t)CB - (gp & (CB - 1)), s1 - s0);
-        if (pos < s1) { nid = ids[pos]; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; }
+        if (pos < s1) { nid = ids[pos]; n0 = pay4[GS_PAYLOAD_QUADS * (size_t)nid]; n1 = pay4[GS_PAYLOAD_QUADS * (size_t)nid + 1]; n2 = pay4[GS_PAYLOAD_QUADS * (size_t)nid + 2]; }
         if (pos2 < s1) id2 = ids[pos2];
     }
     for (uint32_t base = s0; base < s1;) {
@@ -629,7 +629,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         };
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
-        if (pos < s1) { nid = id2; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; }
+        if (pos < s1) { nid = id2; n0 = pay4[GS_PAYLOAD_QUADS * (size_t)nid]; n1 = pay4[GS_PAYLOAD_QUADS * (size_t)nid + 1]; n2 = pay4[GS_PAYLOAD_QUADS * (size_t)nid + 2]; }
         {
             const uint32_t pos2 = pos + min((uint32_t)CB, s1 - base);
             if (base < s1 && pos2 < s1) id2 = ids[pos2];

@@ -231,11 +231,11 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, 
     // alpha = exp2(ka dX^2 + kb dX dY + kc dY^2 + l2s)   (same single fp32 operations the staging lanes performed in rounds 1-2)
     p.l2s = fminf(__builtin_amdgcn_logf(sg), GS_L2S_CAP);
     p.ka = GS_NEG_HALF_LOG2E * inv0; p.kb = GS_NEG_HALF_LOG2E * (inv1 + inv2); p.kc = GS_NEG_HALF_LOG2E * inv3;
-    p.i0 = inv0; p.i1 = inv1; p.i2 = inv2; p.i3 = inv3;
     p.r = rgb[0]; p.g = rgb[1]; p.b = rgb[2];
     if (finite_bb && depth_ok && pay_ok) { p.bbx = gs_pack_i16(bxmin, bxmax); p.bby = gs_pack_i16(bymin, bymax); }
     else { p.bbx = 1u; p.bby = 1u; }                                   // min 1, max 0: empty
     a.payload[g] = p;
+    reinterpret_cast<float4 *>(a.invcov)[g] = make_float4(inv0, inv1, inv2, inv3);
     a.depth_key[g] = key;
     reinterpret_cast<uint2 *>(a.rect)[g] = make_uint2((uint32_t)rc[0] | ((uint32_t)rc[1] << 16),
                                                        (uint32_t)rc[2] | ((uint32_t)rc[3] << 16));

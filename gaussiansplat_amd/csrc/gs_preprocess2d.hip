@@ -97,11 +97,11 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_kernel(GsPreprocess2DArgs
     p.mx = mux; p.my = muy; p.sig = sg;
     p.l2s = fminf(__builtin_amdgcn_logf(sg), GS_L2S_CAP);             // log2; sg == 0 gives -inf: alpha = exp2(-inf) = 0
     p.ka = GS_NEG_HALF_LOG2E * inv0; p.kb = GS_NEG_HALF_LOG2E * (inv1 + inv2); p.kc = GS_NEG_HALF_LOG2E * inv3;
-    p.i0 = inv0; p.i1 = inv1; p.i2 = inv2; p.i3 = inv3;
     p.r = cr; p.g = cg; p.b = cb;
     if (finite_bb && pay_ok) { p.bbx = gs2_pack_i16(bxmin, bxmax); p.bby = gs2_pack_i16(bymin, bymax); }
     else { p.bbx = 1u; p.bby = 1u; }                                   // min 1, max 0: empty
     a.payload[g] = p;
+    reinterpret_cast<float4 *>(a.invcov)[g] = make_float4(inv0, inv1, inv2, inv3);
     a.depth_key[g] = 0u;                                               // no depth: lists are in gaussian-index order
     reinterpret_cast<uint2 *>(a.rect)[g] = make_uint2((uint32_t)rc[0] | ((uint32_t)rc[1] << 16),
                                                        (uint32_t)rc[2] | ((uint32_t)rc[3] << 16));

@@ -24,6 +24,7 @@
 // `overwrite` stores instead of accumulating: used for the first backward after resetGrads, so
 // the reset needs no 4(11+3K)-byte/gaussian zero fill and this pass no read of the old gradients.
 #include "gs_common.h"
+#include <stdlib.h>
 
 #define SH_C0 0.28209479177387814f
 #define SH_C1 0.48860251190291990f
@@ -417,11 +418,26 @@ hipError_t gs_launch_sh_from_views(int64_t n, int sh_degree, const float *means,
     return hipGetLastError();
 }
 
+// gaussians per workgroup of the SH kernel: its LDS tile is (3K + 1) floats per gaussian (49 at SH degree 3), so 256 gaussians
+// allow three workgroups per CU, 128 six (GS_EXPERIMENTS builds: GS_SHBWD_T = 64 / 128 / 256)
+#ifndef GS_SHBWD_THREADS
+#define GS_SHBWD_THREADS 256
+#endif
+static int sh_bwd_threads() {
+#ifdef GS_EXPERIMENTS
+    static int v = 0;
+    if (!v) { const char *e = getenv("GS_SHBWD_T"); const int t = e ? atoi(e) : 0; v = (t == 64 || t == 128 || t == 256) ? t : GS_SHBWD_THREADS; }
+    return v;
+#else
+    return GS_SHBWD_THREADS;
+#endif
+}
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s, int phases) {
     if (a.n <= 0) return hipSuccess;
-    const dim3 block(256), grid((unsigned)((a.n + 255) / 256));
+    const int T = sh_bwd_threads();
+    dim3 block(T), grid((unsigned)((a.n + T - 1) / T));
     const int K = (a.sh_degree + 1) * (a.sh_degree + 1);
-    const size_t lds = sizeof(float) * 256 * (3 * K + 1);
+    const size_t lds = sizeof(float) * T * (3 * K + 1);
 #define GS_SH(D) do { if (a.overwrite) hipLaunchKernelGGL((gs_sh_bwd_kernel<D, true>), grid, block, lds, s, a, cam); \
                       else hipLaunchKernelGGL((gs_sh_bwd_kernel<D, false>), grid, block, lds, s, a, cam); } while (0)
     if (phases & 1)
@@ -432,6 +448,7 @@ hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera
         case 3: GS_SH(3); break;
         default: return hipErrorInvalidValue;
     }
+    block = dim3(256); grid = dim3((unsigned)((a.n + 255) / 256));
     if (phases & 2) {
         if (a.overwrite) hipLaunchKernelGGL(gs_geom_bwd_kernel<true>, grid, block, 0, s, a, cam);
         else hipLaunchKernelGGL(gs_geom_bwd_kernel<false>, grid, block, 0, s, a, cam);
