@@ -32,7 +32,6 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
 
 GS_ABI_VERSION = 2          # include/gsplat.h; load() refuses a library that reports another version
 GS_DEBUG_WIDE_CURSORS = 1
-GS_DEBUG_PX4 = 2             # composite kernels: one wave per tile also on small grids
 GS_MAX_VIEW_SLOTS = 64
 
 

@@ -220,17 +220,7 @@ int bind_device(gs_ctx *c) {
     return GS_OK;
 }
 
-// Pixels per lane of the composite kernels: 4 = one wave per tile (full-size frames).  A frame with fewer tiles than the chip
-// has wave slots (256 CUs x 4 SIMDs x 5 waves) is composited by two or four waves per tile, each with 2 or 1 pixels per lane.
-int composite_px(const gs_ctx *c) {
-    const int64_t ntiles = (int64_t)c->gx * c->gy;
-    if ((c->cfg.debug_flags & GS_DEBUG_PX4) || c->n_rounds > 1) return 4;
-#ifdef GS_EXPERIMENTS
-    if (c->cfg.schedule == 10 || c->cfg.schedule == 12) return 4;
-#endif
-    return ntiles * 4 <= 5120 ? 1 : ntiles * 2 <= 5120 ? 2 : 4;
-}
-bool lpt_schedule(const gs_ctx *c) { return (c->cfg.schedule == 3 || c->cfg.schedule == 4) && composite_px(c) == 4; }
+bool lpt_schedule(const gs_ctx *c) { return c->cfg.schedule == 3 || c->cfg.schedule == 4; }
 
 // Launch order of the frame's composite kernels (gs_config.schedule 3 / 4): what the last forward under the same view slot
 // measured, else (schedule 4) what this ctx's previous slot-less forward measured; null = no history: tile order for the forward.
@@ -349,7 +339,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (!(c0.slab_max_ratio >= 0.0f && c0.slab_max_ratio <= 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_max_ratio must be in [0, 1]");
     for (int i = 0; i < 3; ++i)
         if (!(c0.slab_fractions[i] >= 0.0f && c0.slab_fractions[i] < 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_fractions must be in [0, 1)");
-    if (c0.debug_flags & ~(GS_DEBUG_WIDE_CURSORS | GS_DEBUG_PX4)) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown debug_flags");
+    if (c0.debug_flags & ~GS_DEBUG_WIDE_CURSORS) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown debug_flags");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -966,7 +956,6 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.resume = r > 0; a.final_round = r == R - 1;
     a.tile_work = c->tile_work.as<uint32_t>();
     a.tile_order = order;
-    a.px = composite_px(c);
     a.zero_words = c->counters.as<unsigned long long>() + 2;               // the backward's work counters (walked, evaluated)
     if (R > 1) { a.tile_pos = c->tile_pos.as<uint32_t>(); a.tile_done = c->tile_done.as<uint8_t>(); a.tile_dead = c->tile_dead.as<unsigned long long>(); }
 #ifdef GS_EXPERIMENTS
@@ -1095,7 +1084,6 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
     a.dC = dC_dev; a.g2d = det ? nullptr : c->g2d.as<float>(); a.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
     a.walked = c->counters.as<unsigned long long>() + 2;
     a.variant = c->variant_bwd; a.cull = c->cfg.alpha_cull != 0;
-    a.px = composite_px(c);
     if (!params_only) {
         c->last_dC = dC_dev;
         if (c->g2d_zero_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_g2d_zero, 0)); c->g2d_zero_pending = false; }   // zeroed beside the forward

@@ -207,7 +207,6 @@ struct GsCompositeArgs {
                                 // after the no-op cull (one atomic each per tile); may be null
     int cull;                  // 1: drop (tile, splat) entries that are provably no-ops while staging (gs_config.alpha_cull)
     int variant;               // kernel variant (A/B testing; 0 = default)
-    int px;                    // pixels per lane: 4 (0 = 4; one wave per tile), 2 or 1 (two / four waves per tile: small grids; tile order, no slabs)
     int map_mode;              // block -> tile map of the non-queued launch (0 plain; 1, 2: XCD bands, A/B only)
     // work queue (persistent waves pull tiles from an atomic ticket counter, longest first)
     uint32_t *queue;           // 8 ticket counters (one per XCD), zeroed before the launch; null: one wave per tile, blockIdx order

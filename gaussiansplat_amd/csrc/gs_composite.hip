@@ -151,9 +151,7 @@ __device__ __forceinline__ bool rect_can_contribute(float A, float B, float C, f
 // lanes hold in slot p) can reach alpha >= 2^-27 somewhere.  The backward skips the dead strips of an entry with wave-uniform
 // branches: at C3 24 % of the strips of the evaluated entries are dead.  `keep` is the same tile-level test in both kernels, so
 // forward and backward evaluate the same entries.
-// ty0: first pixel row of the rows THIS WAVE composites (the whole tile with 4 pixels per lane, 8 or 4 rows of it with 2 or 1);
-// NSTRIP = 16 x 4 strips in those rows = pixels per lane.
-template <bool STRIPS, int NSTRIP>
+template <bool STRIPS>
 __device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2,
                                               const int tx0, const int ty0, bool &keep, uint32_t &strips) {
     // payload quads (gs_common.h): n0 = {mu_x, mu_y, log2 sig (capped below 0), box x}, n1 = {k i0, k (i1+i2), k i3, box y}, n2 = {r, g, b, sig}
@@ -174,14 +172,14 @@ __device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2
         const float A = q1.x, B = q1.y, C = q1.z;
         const bool concave = A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f;
         const float rx0 = (float)max(tx0, xmin) - n0.x, rx1 = (float)min(tx0 + GS_TILE - 1, xmax) - n0.x;
-        const float ry0 = (float)max(ty0, ymin) - n0.y, ry1 = (float)min(ty0 + 4 * NSTRIP - 1, ymax) - n0.y;
+        const float ry0 = (float)max(ty0, ymin) - n0.y, ry1 = (float)min(ty0 + GS_TILE - 1, ymax) - n0.y;
         const float hBrA = 0.5f * B * fast_rcp(A), hBrC = 0.5f * B * fast_rcp(C);
         keep = !empty && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, ry0, ry1);
-        strips = (1u << NSTRIP) - 1u;
+        strips = 0xFu;
         if (STRIPS) {
             strips = 0;
 #pragma unroll
-            for (int p = 0; p < NSTRIP; ++p) {
+            for (int p = 0; p < 4; ++p) {
                 const float sy0 = (float)max(ty0 + 4 * p, ymin) - n0.y, sy1 = (float)min(ty0 + 4 * p + 3, ymax) - n0.y;
                 if (keep && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, sy0, sy1)) strips |= 1u << p;
             }
@@ -204,11 +202,7 @@ __device__ __forceinline__ Entry load_entry(const float4 *sp, const float *syhi,
 }
 
 // ---------------------------------------------------------------- forward
-template <bool EARLY, bool CULL, bool LEAN, bool CLK, bool SLAB, int PX>
-// PX: pixels per lane = 4 (one wave per tile: the production mapping of full-size frames), 2 or 1 (two / four waves per tile, each
-// compositing 8 / 4 rows of it from the tile's list on its own: small frames have fewer tiles than the chip has wave slots --
-// config C1's 256 tiles would occupy a quarter of the SIMDs with one wave each -- and a wave's time per list entry falls with
-// its pixels, 19 instructions for one pixel per lane against 55 for four).  `sub` = which rows of the tile.
+template <bool EARLY, bool CULL, bool LEAN, bool CLK, bool SLAB>
 // SLAB: the frame is binned in depth slabs (several rounds; resume / tile_pos / tile_done / tile_dead): its own instantiation, the
 // single-round kernel carries none of that state (with it the compiler spilled: 96 VGPRs + 28 bytes of scratch against 90).
 // CLK: per-tile debug clocks (gs_debug_tile_clock); a separate instantiation so that the production kernel carries none of it.
@@ -216,13 +210,13 @@ template <bool EARLY, bool CULL, bool LEAN, bool CLK, bool SLAB, int PX>
 // eight waves per SIMD, i.e. every tile of a 1080p frame resident at once.
 // (Skipping the dead 16 x 4 strips of an entry with wave-uniform branches, as the backward does, was measured on the forward
 // too: 0.352 vs 0.357 ms at C3 -- its per-strip work is a 12-instruction dependent chain, the branches cost what they save.)
-__device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, const int sub, float4 *sp, float *syhi, const float nbig) {
+__device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
-    const int py0 = (tile / a.gx) * GS_TILE + 4 * PX * sub + (lane >> 4) + 1;
+    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
     const float fx = (float)px;
     const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
-    const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);     // first pixel of the tile / of this wave's rows (1-based)
+    const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);     // first pixel of the tile (1-based)
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
 
@@ -235,11 +229,11 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     if (SLAB && a.resume && a.tile_done[tile]) return;
     const uint32_t gp0 = SLAB && a.tile_pos ? a.tile_pos[tile] : 0u;
     const size_t plane = (size_t)a.W * a.H;
-    float Cr[PX], Cg[PX], Cb[PX], T[PX], Tdead[PX], fy[PX];
-    bool dead[PX];
+    float Cr[4], Cg[4], Cb[4], T[4], Tdead[4], fy[4];
+    bool dead[4];
     uint32_t walked = 0, evaluated = 0;
 #pragma unroll
-    for (int p = 0; p < PX; ++p) {
+    for (int p = 0; p < 4; ++p) {
         Cr[p] = Cg[p] = Cb[p] = 0.0f;
         fy[p] = (float)(py0 + 4 * p);
         const bool in = (px <= a.W && py0 + 4 * p <= a.H);
@@ -276,7 +270,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         if (EARLY && phase == 0) {
             bool live = false;
 #pragma unroll
-            for (int p = 0; p < PX; ++p) {
+            for (int p = 0; p < 4; ++p) {
                 if (!dead[p] && T[p] < a.t_min) { dead[p] = true; Tdead[p] = T[p]; T[p] = 0.0f; }
                 live = live || !dead[p];
             }
@@ -290,7 +284,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             pos = base + lane;
             if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[GS_PAYLOAD_QUADS * g]; n1 = pay4[GS_PAYLOAD_QUADS * g + 1]; n2 = pay4[GS_PAYLOAD_QUADS * g + 2]; }
         }
-        const float yhi_l = stage_record<false, PX>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
+        const float yhi_l = stage_record<false>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
         int slot = lane, nk = cnt;
         if (!CULL) keep = true;
         if (CULL) {                                                     // compact the batch to the entries that can matter
@@ -320,7 +314,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             const float A0 = fmaf(nbig, fabsf(ex), fmaf(e.q1.x * dX, dX, e.q0.z));  // k i0 dX^2 + log2 sig - penalty
             const float B0 = e.q1.y * dX;
 #pragma unroll
-            for (int p = 0; p < PX; ++p) {
+            for (int p = 0; p < 4; ++p) {
                 const float dY = fy[p] - e.q0.y;
                 const float ey = dY - __builtin_amdgcn_fmed3f(dY, e.q2.w, e.yhi);
                 const float pw = fmaf(dY, fmaf(e.q1.z, dY, B0), A0);
@@ -336,24 +330,24 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     }
     bool anylive = false;
 #pragma unroll
-    for (int p = 0; p < PX; ++p) anylive = anylive || !dead[p];
+    for (int p = 0; p < 4; ++p) anylive = anylive || !dead[p];
     const bool all_dead = __ballot(anylive) == 0ull;                    // complete: no pixel takes anything further
     if (SLAB && a.tile_dead && !a.final_round) {                        // the frozen flags travel to the next round beside the pixels
 #pragma unroll
-        for (int p = 0; p < PX; ++p) {                                  // (slab frames run four pixels per lane)
+        for (int p = 0; p < 4; ++p) {
             const unsigned long long m = __ballot(dead[p]);
             if (lane == 0) a.tile_dead[4 * (size_t)tile + p] = m;
         }
     }
     if (lane == 0) {
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
-        if (a.tile_work && PX == 4) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + evaluated : evaluated;
+        if (a.tile_work) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + evaluated : evaluated;
         if (SLAB && a.tile_done) a.tile_done[tile] = all_dead ? 1 : 0;
         if (SLAB && a.tile_pos) a.tile_pos[tile] = gp0 + (s1 - s0);
     }
     if (px <= a.W) {
 #pragma unroll
-        for (int p = 0; p < PX; ++p) {
+        for (int p = 0; p < 4; ++p) {
             const int py = py0 + 4 * p;
             if (py <= a.H) {
                 const size_t o = (size_t)(px - 1) + (size_t)a.W * (py - 1);
@@ -370,20 +364,15 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     }
 }
 
-template <bool EARLY, int MINW, bool CULL, bool LEAN = false, bool CLK = false, bool SLAB = false, int PX = 4>
+template <bool EARLY, int MINW, bool CULL, bool LEAN = false, bool CLK = false, bool SLAB = false>
 __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     if (a.zero_words && blockIdx.x == 0 && threadIdx.x < 2) a.zero_words[threadIdx.x] = 0ull;
-    if (PX < 4) {                                                       // 4 / PX waves per tile, in tile order (small grids: no queue, no launch order)
-        const int tile = (int)blockIdx.x / (4 / PX);
-        if (tile < ntiles) forward_tile<EARLY, CULL, LEAN, CLK, SLAB, PX>(a, tile, (int)blockIdx.x % (4 / PX), sp, syhi, nbig);
-        return;
-    }
     for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
-        forward_tile<EARLY, CULL, LEAN, CLK, SLAB, PX>(a, tile, 0, sp, syhi, nbig);
+        forward_tile<EARLY, CULL, LEAN, CLK, SLAB>(a, tile, sp, syhi, nbig);
         __syncthreads();                                                // the next tile restages sp[]
     }
 }
@@ -464,10 +453,9 @@ __device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__bui
 
 // per-pixel arithmetic of one entry: updates T, S; returns the lane's nine partial sums
 // v = {dr, dg, db, S0, Sx, Sy, Sxx, Sxy, Syy}.  live: wave-uniform 4-bit mask of the strips (pixel slots) the entry can touch.
-template <int PX>
-__device__ __forceinline__ void backward_entry(const Entry &e, const float fx, const float (&fy)[PX], const float nbig,
-                                               const float (&dCr)[PX], const float (&dCg)[PX], const float (&dCb)[PX],
-                                               float (&T)[PX], float (&S)[PX], float (&v)[9], bool &any, const uint32_t live) {
+__device__ __forceinline__ void backward_entry(const Entry &e, const float fx, const float (&fy)[4], const float nbig,
+                                               const float (&dCr)[4], const float (&dCg)[4], const float (&dCb)[4],
+                                               float (&T)[4], float (&S)[4], float (&v)[9], bool &any, const uint32_t live) {
     const float dX = fx - e.q0.x;
 #if GS_ABL & 16
     const float A0 = fmaf(e.q1.x * dX, dX, e.q0.z);
@@ -478,7 +466,7 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
     const float B0 = e.q1.y * dX;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f, q0s = 0.0f, q1s = 0.0f, q2s = 0.0f, asum = 0.0f;
 #pragma unroll
-    for (int p = 0; p < PX; ++p) {
+    for (int p = 0; p < 4; ++p) {
         if (!((live >> p) & 1u)) continue;                        // wave-uniform branch: a dead strip costs nothing
         const float dY = fy[p] - e.q0.y;
 #if GS_ABL & 16
@@ -523,12 +511,12 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
 // pixel-box penalty (v_med3 + sub + fma per axis), 32 reuses one staged entry (no LDS reads of the payload).  Outputs are wrong
 // by construction.
 // RED: 2 transposed LDS reduction, software pipelined (default); 1 reduce-scatter tree on ds_swizzle / ds_bpermute
-template <bool EARLY, bool DET, int RED, bool CULL, bool CLK, int PX>
-__device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, const int sub, float4 *sp, float *syhi, uint32_t *sid, uint32_t *sstrip,
+template <bool EARLY, bool DET, int RED, bool CULL, bool CLK>
+__device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, uint32_t *sid, uint32_t *sstrip,
                                               float *red, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
-    const int py0 = (tile / a.gx) * GS_TILE + 4 * PX * sub + (lane >> 4) + 1;     // PX pixels per lane: rows 4 PX sub .. 4 PX (sub + 1) - 1 of the tile
+    const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
     const float fx = (float)px;
     const size_t plane = (size_t)a.W * a.H;
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);
@@ -544,11 +532,11 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     float *wrow = red + lane;
     const int ocomp_t = (lane < 36 && (lane & 3) == 0) ? ((lane >> 2) < 8 ? (lane >> 2) : 9) : -1;
 
-    float dCr[PX], dCg[PX], dCb[PX], T[PX], S[PX], fy[PX];
-    bool dead[PX];
+    float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
+    bool dead[4];
     uint32_t walked = 0, evaluated = 0;
 #pragma unroll
-    for (int p = 0; p < PX; ++p) {
+    for (int p = 0; p < 4; ++p) {
         const int py = py0 + 4 * p;
         const bool in = (px <= a.W && py <= a.H);
         const size_t o = in ? (size_t)(px - 1) + (size_t)a.W * (py - 1) : 0;
@@ -581,7 +569,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     // The tile's list is the concatenation of its segments, one per binning round of the frame (one segment unless the
     // frame was binned in depth slabs); batches end at multiples of CB of the WHOLE list, as in the forward.
     uint32_t gp = 0;
-    uint32_t alive = (1u << PX) - 1u;                                     // strips with a live pixel (refreshed at every batch boundary)
+    uint32_t alive = 0xFu;                                                // strips with a live pixel (refreshed at every batch boundary)
     bool stop = false;
     unsigned long long t_loop = 0, t_stage = 0, t_mark = 0;               // debug clocks (a.tile_clock)
     if (CLK) t_mark = __builtin_amdgcn_s_memtime();
@@ -602,7 +590,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             bool live = false;
             alive = 0;
 #pragma unroll
-            for (int p = 0; p < PX; ++p) {
+            for (int p = 0; p < 4; ++p) {
                 if (!dead[p] && T[p] < a.t_min) { dead[p] = true; T[p] = 0.0f; S[p] = 0.0f; }
                 live = live || !dead[p];
                 if (__ballot(!dead[p]) != 0ull) alive |= 1u << p;           // strip p still has a pixel that takes entries
@@ -612,13 +600,11 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         float4 q0, q1, q2;
         uint32_t strips;
         bool keep;
-        const float yhi_l = stage_record<CULL, PX>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
+        const float yhi_l = stage_record<CULL>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
         if (CULL && EARLY) strips &= alive;                                 // a strip of frozen pixels (T = S = 0) adds exact zeros
         int slot = lane, nk = cnt;
         if (!CULL) keep = true;
-        uint64_t mq[PX];                                                  // bit k: strip p of the k-th staged entry is live
-#pragma unroll
-        for (int p = 0; p < PX; ++p) mq[p] = ~0ull;
+        uint64_t mq[4] = {~0ull, ~0ull, ~0ull, ~0ull};                    // bit k: strip p of the k-th staged entry is live
         if (CULL) {
             keep = keep && lane < cnt;
             const uint64_t m = __ballot(keep);
@@ -635,13 +621,11 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         if (CULL) {
             const uint32_t mine = lane < nk ? sstrip[lane] : 0u;
 #pragma unroll
-            for (int p = 0; p < PX; ++p) mq[p] = __ballot((mine >> p) & 1u);
+            for (int p = 0; p < 4; ++p) mq[p] = __ballot((mine >> p) & 1u);
         }
         auto live_of = [&](int k) -> uint32_t {                          // wave-uniform strip mask of staged entry k
-            uint32_t m = 0;
-#pragma unroll
-            for (int p = 0; p < PX; ++p) m |= (uint32_t)((mq[p] >> k) & 1ull) << p;
-            return m;
+            return (uint32_t)((mq[0] >> k) & 1ull) | ((uint32_t)((mq[1] >> k) & 1ull) << 1) | ((uint32_t)((mq[2] >> k) & 1ull) << 2)
+                   | ((uint32_t)((mq[3] >> k) & 1ull) << 3);
         };
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
@@ -658,7 +642,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             auto step = [&](const Entry &cur, const uint32_t gcur, Entry &nxt, uint32_t &gnxt, const int k) {
                 float v[9];
                 bool any;
-                backward_entry<PX>(cur, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
+                backward_entry(cur, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
                 const uint32_t gid_k = (uint32_t)__builtin_amdgcn_readfirstlane((int)gcur);
                 __builtin_amdgcn_sched_barrier(0);
                 nxt = load_entry(sp, syhi, k + 1);                       // slot nk <= CB exists (one spare slot), value unused
@@ -691,7 +675,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
 #endif
                 float v[9];
                 bool any = true;
-                backward_entry<PX>(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
+                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
                 if (!CULL && __ballot(any) == 0ull) continue;
 #if GS_ABL & 1
 #pragma unroll
@@ -712,7 +696,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
                 const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
                 float v[9];
                 bool any;
-                backward_entry<PX>(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
+                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
                 if (!CULL && __ballot(any) == 0ull) continue;            // nobody in the tile touched it
                 const float d = reduce8_lds(v, lane, xaddr);
                 const float t9 = wave_sum_lds(v[8], xaddr);
@@ -733,7 +717,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     }
 }
 
-template <bool EARLY, int MINW, bool DET, int RED, bool CULL, bool CLK = false, int PX = 4>
+template <bool EARLY, int MINW, bool DET, int RED, bool CULL, bool CLK = false>
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[(CB + 1) * 3];                                  // one spare slot: the pipelined loop loads entry k+1
     __shared__ float syhi[CB + 1];
@@ -742,13 +726,8 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     __shared__ __attribute__((aligned(16))) float red[RED >= 2 ? RED_FLOATS : 4];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
-    if (PX < 4) {                                                        // 4 / PX waves per tile, in tile order (small grids)
-        const int tile = (int)blockIdx.x / (4 / PX);
-        if (tile < ntiles) backward_tile<EARLY, DET, RED, CULL, CLK, PX>(a, tile, (int)blockIdx.x % (4 / PX), sp, syhi, sid, sstrip, red, nbig);
-        return;
-    }
     for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
-        backward_tile<EARLY, DET, RED, CULL, CLK, PX>(a, tile, 0, sp, syhi, sid, sstrip, red, nbig);
+        backward_tile<EARLY, DET, RED, CULL, CLK>(a, tile, sp, syhi, sid, sstrip, red, nbig);
         __syncthreads();
     }
 }
@@ -967,15 +946,6 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
 #define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
                      else hipLaunchKernelGGL((composite_fwd_kernel<E, 5, false>), grid, block, debug_extra_lds(), s, a); } while (0)
 #endif
-    if (a.px == 1 || a.px == 2) {                                         // small grids: four / two waves per tile, tile order
-        if (a.tile_pos || a.tile_clock) return hipErrorInvalidValue;
-        const dim3 g2((unsigned)(ntiles * (4 / a.px)));
-#define GS_FP(E, C, P) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, C, false, false, false, P>), g2, block, debug_extra_lds(), s, a)
-        if (a.px == 1) { if (early) { if (a.cull) GS_FP(true, true, 1); else GS_FP(true, false, 1); } else { if (a.cull) GS_FP(false, true, 1); else GS_FP(false, false, 1); } }
-        else           { if (early) { if (a.cull) GS_FP(true, true, 2); else GS_FP(true, false, 2); } else { if (a.cull) GS_FP(false, true, 2); else GS_FP(false, false, 2); } }
-#undef GS_FP
-        return hipGetLastError();
-    }
     if (a.tile_pos) {                                                     // a round of a slab frame (t_min > 0 by construction: plan_rounds)
         if (!early || a.tile_clock) return hipErrorInvalidValue;
         if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<true, 5, true, false, false, true>), grid, block, debug_extra_lds(), s, a);
@@ -1008,18 +978,6 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
 #define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, debug_extra_lds(), s, a); \
                                else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, debug_extra_lds(), s, a); } while (0)
 #define GS_B(E, M, Z) do { if (a.g2d_fixed) GS_B2(E, M, true, Z); else GS_B2(E, M, false, Z); } while (0)
-    if (a.px == 1 || a.px == 2) {                                         // small grids: four / two waves per tile, tile order
-        if (a.tile_clock) return hipErrorInvalidValue;
-        const dim3 g2((unsigned)(ntiles * (4 / a.px)));
-#define GS_BP(E, D, C, P) hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD3_MINW, D, 3, C, false, P>), g2, block, debug_extra_lds(), s, a)
-#define GS_BP2(E, P) do { if (a.g2d_fixed) { if (a.cull) GS_BP(E, true, true, P); else GS_BP(E, true, false, P); } \
-                          else { if (a.cull) GS_BP(E, false, true, P); else GS_BP(E, false, false, P); } } while (0)
-        if (a.px == 1) { if (early) GS_BP2(true, 1); else GS_BP2(false, 1); }
-        else           { if (early) GS_BP2(true, 2); else GS_BP2(false, 2); }
-#undef GS_BP2
-#undef GS_BP
-        return hipGetLastError();
-    }
     if (a.tile_clock) {                                                   // debug clocks: instantiations of their own (alpha_cull on, float atomics only)
         if (!a.cull || a.g2d_fixed) return hipErrorInvalidValue;
         if (early) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_BWD3_MINW, false, 3, true, true>), grid, block, debug_extra_lds(), s, a);

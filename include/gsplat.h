@@ -125,8 +125,6 @@ typedef struct {
     int32_t reserved[6];      /* sizeof(gs_config) == 96                                                                       */
 } gs_config;
 #define GS_DEBUG_WIDE_CURSORS 1   /* two-level binning: 64-bit list cursors although the lists fit 32-bit byte offsets (tests)    */
-#define GS_DEBUG_PX4 2            /* composite kernels: one wave per tile (4 pixels per lane) also on grids small enough for the
-                                     two- / four-waves-per-tile kernels -- so that small test scenes exercise the full-size kernels */
 
 typedef struct gs_ctx gs_ctx;
 

@@ -17,12 +17,7 @@ def scene_and_cameras(n, W, H, deg, seed, view=0):
 
 
 def hip_context(sc, cam, T, P, W, H, deg, **kw):
-    """A gs_ctx on the scene.  Unless the caller passes debug_flags, the composite kernels run one wave per tile (GS_DEBUG_PX4)
-    whatever the grid size: the test scenes are small, and the kernels under test are the ones full-size frames use -- their work
-    counters (walked == instances at t_min = 0, ...) are per tile.  The two- / four-waves-per-tile kernels that small grids get
-    by default are tested in tests/test_gpu_px.py and through every renderer-level test (getRenderer does not set the flag)."""
     from gaussiansplat_amd import backend as B
-    kw.setdefault("debug_flags", B.GS_DEBUG_PX4)
     ctx = B.Context(**kw)
     n = sc["means"].shape[0]
     ctx.set_model_host(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"].reshape(n, 3 * (deg + 1) ** 2), deg)

@@ -87,11 +87,11 @@ def test_8k_grid_and_wide_cursors(oracle):
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, 0, 78)
     sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(2.0)).astype(np.float32)
     a = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
-    b = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, debug_flags=B.GS_DEBUG_WIDE_CURSORS | B.GS_DEBUG_PX4)
+    b = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, debug_flags=B.GS_DEBUG_WIDE_CURSORS)
     n2, W2, H2 = 5_000, 640, 480
     sc2, cam2, T2, P2, ocam2 = scene_and_cameras(n2, W2, H2, 0, 79)
     sc2 = dict(sc2); sc2["scales"] = (sc2["scales"] + np.float32(1.5)).astype(np.float32)
-    _check_lists(oracle, B, sc2, cam2, T2, P2, ocam2, W2, H2, 0, 1, debug_flags=B.GS_DEBUG_WIDE_CURSORS | B.GS_DEBUG_PX4)
+    _check_lists(oracle, B, sc2, cam2, T2, P2, ocam2, W2, H2, 0, 1, debug_flags=B.GS_DEBUG_WIDE_CURSORS)
     assert a == b
     # forward + backward run at this size (plain tile order in the backward)
     ctx = hip_context(sc, cam, T, P, W, H, 0, t_min=1e-5)
