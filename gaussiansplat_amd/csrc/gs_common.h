@@ -10,13 +10,15 @@
 // gaussian.  Everything in it that is constant per (gaussian, view) is already in the form the inner loops use (log2 of the
 // sigmoid, the conic scaled by -1/2 log2 e), so the staging lane of a (tile, splat) entry has no v_log and no rescaling left
 // to do.  Replaces the 26 scattered floats the reference gathers per (pixel, slot) (src/splat.jl:224-252).
-// Row size.  The kernels read three quads (48 bytes).  Round 3 measured both row sizes on MI355X (tools/ab_payload.sh: same box,
-// interleaved runs): rows padded to 64 bytes (GS_PAYLOAD_QUADS = 4) put every gather inside one 64-byte line,
-// 48-byte rows straddle a line for every second gaussian but move fewer bytes (the memory side fetches 32-byte sectors:
-// FETCH_SIZE 457 MB vs 641 MB per C3 forward).  Frame time equal within 0.1 % (1.4679 vs 1.4693 ms over three runs each), the
-// preprocess 8 us faster with 48 bytes: 48 is the default.
+// Row size.  The kernels read three quads (48 bytes); the row is padded to ONE 64-byte line (GS_PAYLOAD_QUADS = 4), so that the
+// random gather of a list entry touches a single line -- 48-byte rows straddle two lines for every second gaussian.  Measured on
+// one MI355X box, interleaved runs (tools/ab_traffic.sh, C3): FETCH_SIZE x 2 per forward launch 628 MB with 64-byte rows against
+// 791 MB with 48-byte rows (backward 760 vs 939 MB), kernel and frame times equal within the run-to-run noise (1.54-1.56 ms on
+// that box for all four variants).  (With an L2 hit rate of 0.45 on 570 MB of requested rows + ids the uncorrected FETCH_SIZE,
+// 314 MB, is the plausible figure: the x 2 of the microarchitecture guide is calibrated on wide streaming reads, not on 64-byte
+// gathers; the prescribed corrected number is the one reported.)
 #ifndef GS_PAYLOAD_QUADS
-#define GS_PAYLOAD_QUADS 3
+#define GS_PAYLOAD_QUADS 4
 #endif
 struct __attribute__((aligned(16))) GsPayload {
     float mx, my;        // renderer.positions (mu')                      projection.jl:88-93

@@ -789,7 +789,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 // so a few classes lose nothing.  Ranks come from an LDS bitmap [class row][tile of the residue class]: atomic OR (order
 // free), word prefix, popcount below the own bit -- the same construction as the level-1 binning (gs_bin3.hip).
 // One workgroup; work = src[t], or the list length (ranges_mode).
+#ifndef GS_LPT_BUCKETS
 #define GS_LPT_BUCKETS 32
+#endif
 __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int nb,
                                                                uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14) {
     extern __shared__ uint32_t lds[];
