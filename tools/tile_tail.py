@@ -62,6 +62,19 @@ def analyse(clk):
         occ_hist[0] += e2[0, 0]                                          # before its first wave
         np.add.at(occ_hist, np.clip(c2, 0, 8), d2)
     occ_hist = occ_hist / max(occ_hist.sum(), 1)
+    # SIMD throughput by occupancy: every tile is taken to progress uniformly over its lifetime (evaluated / duration entries per
+    # tick); a SIMD's rate in an interval is the sum over its resident tiles; averaged (time-weighted) by the number resident.
+    rate_num, rate_den = np.zeros(9), np.zeros(9)
+    tile_rate = evaluated / np.maximum(end - start, 1)
+    for k in range(len(keys)):
+        m = np.nonzero(inv == k)[0]
+        ev2 = sorted([(int(start[i]), 1, tile_rate[i]) for i in m] + [(int(end[i]), -1, -tile_rate[i]) for i in m])
+        c, r, prev = 0, 0.0, None
+        for t, dc, dr in ev2:
+            if prev is not None and t > prev and c > 0:
+                rate_num[min(c, 8)] += r * (t - prev); rate_den[min(c, 8)] += (t - prev)
+            c += dc; r += dr; prev = t
+    simd_rate = [float(rate_num[i] / rate_den[i]) if rate_den[i] > 0 else 0.0 for i in range(9)]
     order = np.argsort(evaluated)
     dec = np.array_split(order, 10)
     # in-kernel shader-cycle stamps: per-entry loops vs everything else (staging a batch, waiting for its gathers, prologue/epilogue)
@@ -82,6 +95,7 @@ def analyse(clk):
         "tile_duration_us_percentiles": [float(np.percentile(dur, q)) * TICK_US for q in (0, 10, 50, 90, 99, 100)],
         "ticks_per_evaluated_entry_by_decile": [float(dur[d].sum() / max(evaluated[d].sum(), 1)) for d in dec],
         "simd_time_share_by_resident_waves_0_to_8": [round(float(x), 4) for x in occ_hist],
+        "simd_entries_per_us_by_resident_waves_0_to_8": [round(x * 100.0, 4) for x in simd_rate],
         "loop_cycles_per_evaluated_entry_by_decile": [float(loop_cyc[d].sum() / max(evaluated[d].sum(), 1)) for d in dec],
         "stage_cycles_per_walked_entry_by_decile": [float(stage_cyc[d].sum() / max(walked[d].sum(), 1)) for d in dec],
         "stage_share_of_stamped_cycles_by_decile": [float(stage_cyc[d].sum() / max((stage_cyc[d] + loop_cyc[d]).sum(), 1)) for d in dec],
@@ -114,7 +128,7 @@ def main():
             print(name, v, json.dumps({k: a[k] for k in ("span_us", "mean_ms_of_8_launches", "peak_waves_in_flight", "mean_over_peak",
                                                          "share_of_span_below_50pct_of_peak", "t90_over_span",
                                                          "evaluated_per_simd_max_over_mean", "simd_finish_spread_us",
-                                                         "simd_time_share_by_resident_waves_0_to_8", "stage_share_of_stamped_cycles",
+                                                         "simd_time_share_by_resident_waves_0_to_8", "simd_entries_per_us_by_resident_waves_0_to_8", "stage_share_of_stamped_cycles",
                                                          "duration_fit_ticks")}), flush=True)
     os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
     with open(out_path, "w") as fh:
