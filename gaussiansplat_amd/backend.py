@@ -32,6 +32,7 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
 
 GS_ABI_VERSION = 2          # include/gsplat.h; load() refuses a library that reports another version
 GS_DEBUG_WIDE_CURSORS = 1
+GS_DEBUG_ALWAYS_ORDER = 2     # launch orders + side stream also on small frames (tests)
 GS_MAX_VIEW_SLOTS = 64
 
 

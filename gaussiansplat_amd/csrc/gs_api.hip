@@ -220,7 +220,14 @@ int bind_device(gs_ctx *c) {
     return GS_OK;
 }
 
-bool lpt_schedule(const gs_ctx *c) { return c->cfg.schedule == 3 || c->cfg.schedule == 4; }
+// A launch order only matters when there are more tiles than wave slots (256 CUs x 4 SIMDs x 5 waves): below that every tile
+// starts at once whatever the order, and the order kernel would be one more launch in a frame that is bound by launches.
+bool lpt_schedule(const gs_ctx *c) {
+    return (c->cfg.schedule == 3 || c->cfg.schedule == 4) && ((int64_t)c->gx * c->gy > 5120 || (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER));
+}
+// The side stream (zero fill beside the forward, order kernel beside the backward) costs seven more runtime calls per frame: it
+// pays when the composite kernels are long, and costs when the frame is bound by the host's launch rate (config C2: + 9 %).
+bool use_side_stream(const gs_ctx *c) { return c->n >= 262144 || (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER); }
 
 // Launch order of the frame's composite kernels (gs_config.schedule 3 / 4): what the last forward under the same view slot
 // measured, else (schedule 4) what this ctx's previous slot-less forward measured; null = no history: tile order for the forward.
@@ -250,7 +257,7 @@ int build_frame_order(gs_ctx *c, const uint32_t *used) {
     const int dst = used ? 1 - c->slot_sel[k] : c->slot_sel[k];
     DevBuf &ob = c->slot_order[k][dst];
     HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
-    if (used) {
+    if (used && use_side_stream(c)) {
         if (c->order_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0));      // (never two in flight)
         HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
@@ -339,7 +346,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (!(c0.slab_max_ratio >= 0.0f && c0.slab_max_ratio <= 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_max_ratio must be in [0, 1]");
     for (int i = 0; i < 3; ++i)
         if (!(c0.slab_fractions[i] >= 0.0f && c0.slab_fractions[i] < 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_fractions must be in [0, 1)");
-    if (c0.debug_flags & ~GS_DEBUG_WIDE_CURSORS) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown debug_flags");
+    if (c0.debug_flags & ~(GS_DEBUG_WIDE_CURSORS | GS_DEBUG_ALWAYS_ORDER)) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown debug_flags");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -994,7 +1001,7 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     const uint32_t *order = forward_order(c);
     if (c->order_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0)); c->order_pending = false; }     // the order kernel in flight reads tile_work
     c->g2d_zero_pending = false;
-    if (c->prev_frame_had_backward) {   // the zero fill of the backward's gradient rows (64 B per gaussian) runs on the side stream BESIDE the forward composite
+    if (c->prev_frame_had_backward && use_side_stream(c)) {   // the zero fill of the backward's gradient rows (64 B per gaussian) runs on the side stream BESIDE the forward composite
         const bool det = c->cfg.deterministic != 0;
         const size_t n1 = c->n ? (size_t)c->n : 1, bytes = (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1;
         HIPCHK(c, c->g2d.ensure(bytes));

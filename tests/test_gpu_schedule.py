@@ -23,7 +23,8 @@ def test_all_schedules_agree(n, W, H, deg, scale_shift, t_min):
     ref = {}
     for det in (True, False):
         for schedule, slot in ((1, -1), (3, -1), (3, 5), (4, -1), (0, 7)):
-            ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=t_min, deterministic=det, schedule=schedule, slab_mode=0)
+            ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=t_min, deterministic=det, schedule=schedule, slab_mode=0,
+                              debug_flags=2)                        # GS_DEBUG_ALWAYS_ORDER: these grids are smaller than the wave slots
             ctx.set_view_slot(slot)
             out = None
             for frame in range(1 if schedule == 1 else 3):               # later frames launch the forward by what the slot / the previous frame measured
