@@ -900,12 +900,16 @@ hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode,
 // variant (A/B, tools/abtest.py; 0 = default): units digit = kernel body (backward: 3 transposed LDS reduction (default); 2 the same,
 // software pipelined at 96 VGPRs; 1 reduce-scatter tree; forward: 1), tens digit = scheduling (0 as the caller set it up: queue + order when given; 1 one wave per tile in
 // blockIdx order; 2 queue in tile order, no longest-first).
-// Profiling aid: GS_DEBUG_EXTRA_LDS=<bytes> adds that much dynamic LDS to every composite launch, which lowers the
+// Profiling aid (GS_EXPERIMENTS builds): GS_DEBUG_EXTRA_LDS=<bytes> adds that much dynamic LDS to every composite launch, which lowers the
 // waves resident per CU (160 KiB / (static + extra)) without touching the code -- the occupancy sweep of tools/ablate.sh.
 static size_t debug_extra_lds() {
+#ifdef GS_EXPERIMENTS
     static long v = -1;
     if (v < 0) { const char *e = getenv("GS_DEBUG_EXTRA_LDS"); v = e ? atol(e) : 0; if (v < 0) v = 0; }
     return (size_t)v;
+#else
+    return 0;
+#endif
 }
 
 static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {

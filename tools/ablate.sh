@@ -1,6 +1,6 @@
 #!/bin/bash
 # Diagnostic builds of the composite backward with parts removed (GS_ABL bit mask in gs_composite.hip), timed on the GPU box:
-#   tools/ablate.sh build      (here: cross-compiles tools/abl/libgsplat_<tag>.so)
+#   tools/ablate.sh build      (here: cross-compiles tools/abl/libgsplat_<tag>.so; needs `python -m gaussiansplat_amd.build --experiments` first)
 #   tools/ablate.sh run        (GPU box: times body 3, plain scheduling, of each build at t_min = 0 with tools/abtest.py)
 set -e
 cd "$(dirname "$0")/.."
@@ -11,12 +11,12 @@ SPECS="${SPECS:-full:0: nored:1: noatomic:2: nored_notrans:9: nored_nobox:17: no
 if [ "$1" = build ]; then
   for spec in $SPECS; do
     IFS=: read tag abl flags <<< "$spec"
-    /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -DGS_ABL=$abl $flags -c gaussiansplat_amd/csrc/gs_composite.hip -o $D/gs_composite_$tag.o &
+    /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -DGS_EXPERIMENTS -DGS_ABL=$abl $flags -c gaussiansplat_amd/csrc/gs_composite.hip -o $D/gs_composite_$tag.o &
   done
   wait
   for spec in $SPECS; do
     IFS=: read tag abl flags <<< "$spec"
-    objs=$(ls gaussiansplat_amd/lib/*.o | grep -v gs_composite.o)
+    objs=$(ls gaussiansplat_amd/lib_exp/*.o | grep -v gs_composite.o)     # GS_EXPERIMENTS objects: GS_DEBUG_EXTRA_LDS, variants
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $D/libgsplat_$tag.so $objs $D/gs_composite_$tag.o -ldl
   done
 elif [ "$1" = occ ]; then
@@ -24,13 +24,13 @@ elif [ "$1" = occ ]; then
   for tag in full nored; do
     for extra in 0 1900 3900 7200 13900 33900; do
       echo "== $tag extra LDS $extra B  (waves/CU <= $(( 163840 / (6100 + extra) )))"
-      GS_DEBUG_EXTRA_LDS=$extra GSPLAT_HIP_LIB=$PWD/$D/libgsplat_$tag.so AB_TMIN=${AB_TMIN:-0} AB_ROUNDS=3 python3 tools/abtest.py C3 10 13 2>&1 | grep -v amdgpu.ids
+      GS_DEBUG_EXTRA_LDS=$extra GSPLAT_HIP_LIB=$PWD/$D/libgsplat_$tag.so AB_TMIN=${AB_TMIN:-0} AB_ROUNDS=3 python3 tools/abtest.py C3 ${AB_F:-10} ${AB_B:-13} 2>&1 | grep -v amdgpu.ids
     done
   done
 else
   for spec in $SPECS; do
     IFS=: read tag abl flags <<< "$spec"
     echo "== $tag (GS_ABL=$abl $flags)"
-    GSPLAT_HIP_LIB=$PWD/$D/libgsplat_$tag.so AB_TMIN=${AB_TMIN:-0} AB_ROUNDS=3 python3 tools/abtest.py C3 10 13 2>&1 | grep -v amdgpu.ids
+    GSPLAT_HIP_LIB=$PWD/$D/libgsplat_$tag.so AB_TMIN=${AB_TMIN:-0} AB_ROUNDS=3 python3 tools/abtest.py C3 ${AB_F:-10} ${AB_B:-13} 2>&1 | grep -v amdgpu.ids
   done
 fi
