@@ -6,33 +6,38 @@
 #define GS_TILE 16
 #define GS_WAVE 64
 
-// Per-gaussian, per-view splat payload staged through LDS by the composite kernels: GS_PAYLOAD_QUADS quads of 16 bytes per
-// gaussian.  Everything in it that is constant per (gaussian, view) is already in the form the inner loops use (log2 of the
-// sigmoid, the conic scaled by -1/2 log2 e), so the staging lane of a (tile, splat) entry has no v_log and no rescaling left
-// to do.  Replaces the 26 scattered floats the reference gathers per (pixel, slot) (src/splat.jl:224-252).
-// Row size.  The kernels read three quads (48 bytes); the row is padded to ONE 64-byte line (GS_PAYLOAD_QUADS = 4), so that the
-// random gather of a list entry touches a single line -- 48-byte rows straddle two lines for every second gaussian.  Measured on
-// one MI355X box, interleaved runs (tools/ab_traffic.sh, C3): FETCH_SIZE x 2 per forward launch 628 MB with 64-byte rows against
-// 791 MB with 48-byte rows (backward 760 vs 939 MB), kernel and frame times equal within the run-to-run noise (1.54-1.56 ms on
-// that box for all four variants).  (With an L2 hit rate of 0.45 on 570 MB of requested rows + ids the uncorrected FETCH_SIZE,
-// 314 MB, is the plausible figure: the x 2 of the microarchitecture guide is calibrated on wide streaming reads, not on 64-byte
-// gathers; the prescribed corrected number is the one reported.)
-#ifndef GS_PAYLOAD_QUADS
+// Per-gaussian, per-view splat payload staged through LDS by the composite kernels: ONE 64-byte row (four quads) per gaussian,
+// so that the random gather of a list entry is a single memory request (48-byte rows were measured: they straddle two 64-byte
+// segments for every second gaussian; tools/ab_traffic.sh at C3, same box, interleaved: 791 vs 628 MB fetched per forward launch at
+// equal time).  Everything that is constant per (gaussian, view) is already in the form the inner loops use: log2 of the sigmoid,
+// the conic scaled by -1/2 log2 e, and (round 3) the pixel-box edges relative to the mean, so the first three quads ARE the
+// record a staging lane puts into LDS -- it modifies none of the registers the row was gathered into, which lets the gather of
+// the next batch stay in flight across the whole per-entry loop (a modified component forced a copy, and with it a wait for the
+// gather, before the loop).  Replaces the 26 scattered floats the reference gathers per (pixel, slot) (src/splat.jl:224-252).
 #define GS_PAYLOAD_QUADS 4
-#endif
+#define GS_BIG 1.0e30f
 struct __attribute__((aligned(16))) GsPayload {
     float mx, my;        // renderer.positions (mu')                      projection.jl:88-93
     float l2s;           // min(log2(cusigmoid(opacity)), -2.6e-7): alpha = exp2(pw + l2s) < 1 strictly   splat.jl:175-178,247
-    uint32_t bbx;        // int16 xmin | int16 xmax << 16  (renderer.bbs)  boundingbox.jl:24-25
+    float xlo;           // (xmin - mx) - 0.25; +BIG for an empty box: pixel-box test of splat.jl:240 as an exponent penalty
     float ka, kb, kc;    // k i0, k (i1 + i2), k i3 with k = -1/2 log2 e: pw = ka dX^2 + kb dX dY + kc dY^2   splat.jl:246
-    uint32_t bby;        // int16 ymin | int16 ymax << 16                 boundingbox.jl:26-27
+    float xhi;           // (xmax - mx) + 0.25
     float r, g, b;       // sh2color                                      splat.jl:180-193
-    float sig;           // cusigmoid(opacity)                            splat.jl:175-178
-#if GS_PAYLOAD_QUADS == 4
-    float pad[4];        // one 64-byte line per gaussian
-#endif
+    float ylo;           // (ymin - my) - 0.25
+    float yhi;           // (ymax - my) + 0.25
+    float sig;           // cusigmoid(opacity)                            splat.jl:175-178   (host read-backs only)
+    uint32_t bbx;        // int16 xmin | int16 xmax << 16  (renderer.bbs)  boundingbox.jl:24-25
+    uint32_t bby;        // int16 ymin | int16 ymax << 16                 boundingbox.jl:26-27
 };
 static_assert(sizeof(GsPayload) == 16 * GS_PAYLOAD_QUADS, "payload row size");
+// box edges of a payload row from its packed pixel box: the SAME single fp32 operations the staging lanes performed in rounds 1-2
+__host__ __device__ inline void gs_payload_box_edges(GsPayload &p) {
+    const int xmin = (int)(short)(p.bbx & 0xFFFFu), xmax = (int)(short)(p.bbx >> 16);
+    const int ymin = (int)(short)(p.bby & 0xFFFFu), ymax = (int)(short)(p.bby >> 16);
+    const bool empty = xmax < xmin || ymax < ymin;      // near/far-culled or degenerate splat: lo = hi = +BIG, every pixel is "outside"
+    p.xlo = empty ? GS_BIG : ((float)xmin - p.mx) - 0.25f; p.xhi = empty ? GS_BIG : ((float)xmax - p.mx) + 0.25f;
+    p.ylo = empty ? GS_BIG : ((float)ymin - p.my) - 0.25f; p.yhi = empty ? GS_BIG : ((float)ymax - p.my) + 0.25f;
+}
 #define GS_NEG_HALF_LOG2E (-0.72134752044448170368f)
 #define GS_L2S_CAP (-2.6e-7f)
 

@@ -121,7 +121,6 @@ __device__ __forceinline__ unsigned long long wave_hw_id() {
 //     pw' = pw - BIG * |d - med3(d, lo, hi)|        (d = pixel - mu on that axis)
 // which is exactly 0 inside the box (med3 returns d itself) and drives exp2 to 0 outside.
 // lo/hi = box edge - mu -/+ 0.25 are lane independent and staged once per (tile, splat).
-#define GS_BIG 1.0e30f
 // A (tile, splat) entry whose largest alpha over the tile's pixels is below 2^-27 is a no-op in the
 // reference's own fp32 arithmetic: T*(1-alpha) == T exactly (alpha < 2^-25 already rounds 1-alpha to 1)
 // and rgb*alpha*T is below 7.5e-9*|rgb|, under half an ulp of any accumulated colour above 1e-7.  Such
@@ -152,40 +151,40 @@ __device__ __forceinline__ bool rect_can_contribute(float A, float B, float C, f
 // branches: at C3 24 % of the strips of the evaluated entries are dead.  `keep` is the same tile-level test in both kernels, so
 // forward and backward evaluate the same entries.
 template <bool STRIPS>
-__device__ __forceinline__ float stage_record(float4 &q0, float4 &q1, float4 &q2, const float4 &n0, const float4 &n1, const float4 &n2,
-                                              const int tx0, const int ty0, bool &keep, uint32_t &strips) {
-    // payload quads (gs_common.h): n0 = {mu_x, mu_y, log2 sig (capped below 0), box x}, n1 = {k i0, k (i1+i2), k i3, box y}, n2 = {r, g, b, sig}
-    const uint32_t bbx = __float_as_uint(n0.w), bby = __float_as_uint(n1.w);
+__device__ __forceinline__ void stage_record(const float4 &n0, const float4 &n1, const float4 &n3, const int tx0, const int ty0, bool &keep, uint32_t &strips) {
+    // payload quads (gs_common.h): n0 = {mu_x, mu_y, log2 sig (capped below 0), x_lo}, n1 = {k i0, k (i1+i2), k i3, x_hi}, n2 = {r, g, b, y_lo},
+    // n3 = {y_hi, sig, box x, box y}: n0..n2 and n3.x go to LDS as they are; this is only the no-op test.
+    // log2(sig) arrives capped three ulps below 0 (gs_preprocess.hip), so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic
+    // is PSD) even when v_exp_f32 returns a value one ulp high; only matters when sigmoid(o) > 1 - 1.8e-7 (o > 15.5): relative change 1.8e-7
+    const uint32_t bbx = __float_as_uint(n3.z), bby = __float_as_uint(n3.w);
     const int xmin = (int)(short)(bbx & 0xFFFFu), xmax = (int)(short)(bbx >> 16);
     const int ymin = (int)(short)(bby & 0xFFFFu), ymax = (int)(short)(bby >> 16);
     const bool empty = xmax < xmin || ymax < ymin;
-    // log2(sig) arrives capped three ulps below 0 (gs_preprocess.hip), so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic
-    // is PSD) even when v_exp_f32 returns a value one ulp high; only matters when sigmoid(o) > 1 - 1.8e-7 (o > 15.5): relative change 1.8e-7
     const float l2s = n0.z;
-    // an empty box (near/far-culled splat) gets lo = hi = +BIG: every pixel is "outside"
-    const float xlo = empty ? GS_BIG : ((float)xmin - n0.x) - 0.25f, xhi = empty ? GS_BIG : ((float)xmax - n0.x) + 0.25f;
-    const float ylo = empty ? GS_BIG : ((float)ymin - n0.y) - 0.25f, yhi = empty ? GS_BIG : ((float)ymax - n0.y) + 0.25f;
-    q0 = make_float4(n0.x, n0.y, l2s, xlo);
-    q1 = make_float4(n1.x, n1.y, n1.z, xhi);
-    q2 = make_float4(n2.x, n2.y, n2.z, ylo);
-    {
-        const float A = q1.x, B = q1.y, C = q1.z;
-        const bool concave = A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f;
-        const float rx0 = (float)max(tx0, xmin) - n0.x, rx1 = (float)min(tx0 + GS_TILE - 1, xmax) - n0.x;
-        const float ry0 = (float)max(ty0, ymin) - n0.y, ry1 = (float)min(ty0 + GS_TILE - 1, ymax) - n0.y;
-        const float hBrA = 0.5f * B * fast_rcp(A), hBrC = 0.5f * B * fast_rcp(C);
-        keep = !empty && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, ry0, ry1);
-        strips = 0xFu;
-        if (STRIPS) {
-            strips = 0;
+    const float A = n1.x, B = n1.y, C = n1.z;
+    const bool concave = A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f;
+    const float rx0 = (float)max(tx0, xmin) - n0.x, rx1 = (float)min(tx0 + GS_TILE - 1, xmax) - n0.x;
+    const float ry0 = (float)max(ty0, ymin) - n0.y, ry1 = (float)min(ty0 + GS_TILE - 1, ymax) - n0.y;
+    const float hBrA = 0.5f * B * fast_rcp(A), hBrC = 0.5f * B * fast_rcp(C);
+    keep = !empty && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, ry0, ry1);
+    strips = 0xFu;
+    if (STRIPS) {
+        strips = 0;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float sy0 = (float)max(ty0 + 4 * p, ymin) - n0.y, sy1 = (float)min(ty0 + 4 * p + 3, ymax) - n0.y;
-                if (keep && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, sy0, sy1)) strips |= 1u << p;
-            }
+        for (int p = 0; p < 4; ++p) {
+            const float sy0 = (float)max(ty0 + 4 * p, ymin) - n0.y, sy1 = (float)min(ty0 + 4 * p + 3, ymax) - n0.y;
+            if (keep && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, sy0, sy1)) strips |= 1u << p;
         }
     }
-    return yhi;
+}
+
+// The gathered row of the NEXT batch must stay untouched in the registers it was loaded into until the per-entry loop of the current
+// batch is over: any earlier "use" -- even a register copy the allocator inserts to split a live range -- makes the compiler wait for
+// the gather before the loop, i.e. exposes one memory round trip per batch.  Passing the sixteen components through an empty asm
+// AFTER the loop makes that the first use.
+__device__ __forceinline__ void first_use_here(float4 &a, float4 &b, float4 &c, float4 &d) {
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w),
+                      "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w), "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
 }
 
 // kept-entry slot of this lane inside the wave's keep mask
@@ -249,7 +248,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         }
     }
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
-    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     uint32_t pos = s0 + lane;
     // Gathers run ahead of their use: the payload rows one batch (held in n0..n2 while the previous batch is composited), the
     // ids they are addressed by TWO batches (id2), so that the row loads of the next batch are issued from a register instead of
@@ -258,7 +257,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     uint32_t id2 = 0;
     if (!LEAN) {
         const uint32_t pos2 = pos + min((uint32_t)CB - (gp0 & (CB - 1)), s1 - s0);      // first position of the second batch + lane
-        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[GS_PAYLOAD_QUADS * g]; n1 = pay4[GS_PAYLOAD_QUADS * g + 1]; n2 = pay4[GS_PAYLOAD_QUADS * g + 2]; }
+        if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; n3 = pay4[4 * g + 3]; }
         if (pos2 < s1) id2 = a.ids[pos2];
     }
     uint32_t gp = gp0;                                                  // list position of `base` in the tile's whole list
@@ -276,15 +275,14 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             }
             if (__ballot(live) == 0ull) break;
         }
-        float4 q0, q1, q2;
         uint32_t strips;
         bool keep;
         if (LEAN) {
-            n0 = n1 = n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            n0 = n1 = n2 = n3 = make_float4(0.f, 0.f, 0.f, 0.f);
             pos = base + lane;
-            if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[GS_PAYLOAD_QUADS * g]; n1 = pay4[GS_PAYLOAD_QUADS * g + 1]; n2 = pay4[GS_PAYLOAD_QUADS * g + 2]; }
+            if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; n3 = pay4[4 * g + 3]; }
         }
-        const float yhi_l = stage_record<false>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
+        stage_record<false>(n0, n1, n3, tx0, ty0, keep, strips);
         int slot = lane, nk = cnt;
         if (!CULL) keep = true;
         if (CULL) {                                                     // compact the batch to the entries that can matter
@@ -294,14 +292,14 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         }
         __syncthreads();                                                // one wave: orders LDS reads/writes only
         if (keep) {
-            sp[3 * slot] = q0; sp[3 * slot + 1] = q1; sp[3 * slot + 2] = q2;
-            syhi[slot] = yhi_l;
+            sp[3 * slot] = n0; sp[3 * slot + 1] = n1; sp[3 * slot + 2] = n2;
+            syhi[slot] = n3.x;
         }
         __syncthreads();
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
         if (!LEAN) {
-            if (pos < s1) { const size_t g = id2; n0 = pay4[GS_PAYLOAD_QUADS * g]; n1 = pay4[GS_PAYLOAD_QUADS * g + 1]; n2 = pay4[GS_PAYLOAD_QUADS * g + 2]; }
+            if (pos < s1) { const size_t g = id2; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; n3 = pay4[4 * g + 3]; }
             const uint32_t pos2 = pos + min((uint32_t)CB, s1 - base);                   // (batches after the first start at multiples of CB)
             if (base < s1 && pos2 < s1) id2 = a.ids[pos2];
         }
@@ -326,6 +324,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             }
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
+        if (!LEAN) first_use_here(n0, n1, n2, n3);
         if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t; }
     }
     bool anylive = false;
@@ -549,7 +548,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         dead[p] = !in;
     }
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
-    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     uint32_t nid = 0;
     // pipeline state of the transposed reduction: the sixteen partials read back for the previous entry
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
@@ -580,7 +579,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     uint32_t id2 = 0;                                                     // ids run two batches ahead, payload rows one (see the forward)
     {
         const uint32_t pos2 = pos + min((uint32_t)CB - (gp & (CB - 1)), s1 - s0);
-        if (pos < s1) { nid = ids[pos]; n0 = pay4[GS_PAYLOAD_QUADS * (size_t)nid]; n1 = pay4[GS_PAYLOAD_QUADS * (size_t)nid + 1]; n2 = pay4[GS_PAYLOAD_QUADS * (size_t)nid + 2]; }
+        if (pos < s1) { nid = ids[pos]; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; n3 = pay4[4 * (size_t)nid + 3]; }
         if (pos2 < s1) id2 = ids[pos2];
     }
     for (uint32_t base = s0; base < s1;) {
@@ -597,10 +596,9 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             }
             if (alive == 0u) { stop = true; break; }
         }
-        float4 q0, q1, q2;
         uint32_t strips;
         bool keep;
-        const float yhi_l = stage_record<CULL>(q0, q1, q2, n0, n1, n2, tx0, ty0, keep, strips);
+        stage_record<CULL>(n0, n1, n3, tx0, ty0, keep, strips);
         if (CULL && EARLY) strips &= alive;                                 // a strip of frozen pixels (T = S = 0) adds exact zeros
         int slot = lane, nk = cnt;
         if (!CULL) keep = true;
@@ -612,8 +610,8 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         }
         __syncthreads();
         if (keep) {
-            sp[3 * slot] = q0; sp[3 * slot + 1] = q1; sp[3 * slot + 2] = q2;
-            syhi[slot] = yhi_l;
+            sp[3 * slot] = n0; sp[3 * slot + 1] = n1; sp[3 * slot + 2] = n2;
+            syhi[slot] = n3.x;
             sid[slot] = nid;                                             // gaussian id of the staged entry
             if (CULL) sstrip[slot] = strips;
         }
@@ -629,7 +627,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         };
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
-        if (pos < s1) { nid = id2; n0 = pay4[GS_PAYLOAD_QUADS * (size_t)nid]; n1 = pay4[GS_PAYLOAD_QUADS * (size_t)nid + 1]; n2 = pay4[GS_PAYLOAD_QUADS * (size_t)nid + 2]; }
+        if (pos < s1) { nid = id2; n0 = pay4[4 * (size_t)nid]; n1 = pay4[4 * (size_t)nid + 1]; n2 = pay4[4 * (size_t)nid + 2]; n3 = pay4[4 * (size_t)nid + 3]; }
         {
             const uint32_t pos2 = pos + min((uint32_t)CB, s1 - base);
             if (base < s1 && pos2 < s1) id2 = ids[pos2];
@@ -704,6 +702,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             }
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
+        first_use_here(n0, n1, n2, n3);
         if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t; }
     }
     }

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, 
     p.r = rgb[0]; p.g = rgb[1]; p.b = rgb[2];
     if (finite_bb && depth_ok && pay_ok) { p.bbx = gs_pack_i16(bxmin, bxmax); p.bby = gs_pack_i16(bymin, bymax); }
     else { p.bbx = 1u; p.bby = 1u; }                                   // min 1, max 0: empty
+    gs_payload_box_edges(p);
     a.payload[g] = p;
     reinterpret_cast<float4 *>(a.invcov)[g] = make_float4(inv0, inv1, inv2, inv3);
     a.depth_key[g] = key;

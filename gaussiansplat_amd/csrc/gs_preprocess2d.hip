@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void gs_preprocess2d_kernel(GsPreprocess2DArgs
     p.r = cr; p.g = cg; p.b = cb;
     if (finite_bb && pay_ok) { p.bbx = gs2_pack_i16(bxmin, bxmax); p.bby = gs2_pack_i16(bymin, bymax); }
     else { p.bbx = 1u; p.bby = 1u; }                                   // min 1, max 0: empty
+    gs_payload_box_edges(p);
     a.payload[g] = p;
     reinterpret_cast<float4 *>(a.invcov)[g] = make_float4(inv0, inv1, inv2, inv3);
     a.depth_key[g] = 0u;                                               // no depth: lists are in gaussian-index order
