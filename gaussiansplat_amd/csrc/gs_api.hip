@@ -117,12 +117,9 @@ struct gs_ctx {
     int64_t slot_tiles[GS_MAX_VIEW_SLOTS + 1] = {};   // the newest order is valid for a grid of this many tiles (0: no history)
     const uint32_t *frame_order = nullptr;   // the launch order of THIS frame's composite kernels (null: tile order)
     bool bwd_counters_zeroed = false;        // the forward kernel zeroed the backward's work counters on its way
-    // ---- side stream: what a frame needs but no kernel of the frame waits for runs beside the composite kernels -- the zero fill of
-    // the backward's gradient rows (beside the forward) and the order kernel (beside the backward, for the slot's next frame)
+    // ---- side stream: the order kernel (needed by the slot's NEXT frame, not by this one) runs beside the backward composite
     hipStream_t side = nullptr;
-    hipEvent_t ev_main = nullptr, ev_g2d_zero = nullptr, ev_order = nullptr;
-    bool g2d_zero_pending = false;           // the side stream is zeroing g2d for this frame's backward (ev_g2d_zero)
-    bool prev_frame_had_backward = false;    // render-only loops do not pay for the zero fill
+    hipEvent_t ev_main = nullptr, ev_order = nullptr;
     bool order_pending = false;              // an order kernel is in flight on the side stream (ev_order)
     int lpt_buckets = 0;                     // experiments: work classes of the order kernel (0: default)
     // ---- speculative binning: the lists are enqueued with the capacities of the buffers at hand while the frame's totals travel
@@ -225,8 +222,8 @@ int bind_device(gs_ctx *c) {
 bool lpt_schedule(const gs_ctx *c) {
     return (c->cfg.schedule == 3 || c->cfg.schedule == 4) && ((int64_t)c->gx * c->gy > 5120 || (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER));
 }
-// The side stream (zero fill beside the forward, order kernel beside the backward) costs seven more runtime calls per frame: it
-// pays when the composite kernels are long, and costs when the frame is bound by the host's launch rate (config C2: + 9 %).
+// The side stream (order kernel beside the backward) costs four more runtime calls per frame: it pays when the composite kernels
+// are long, and costs when the frame is bound by the host's launch rate (config C2, together with the zero fill it once carried: + 9 %).
 bool use_side_stream(const gs_ctx *c) { return c->n >= 262144 || (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER); }
 
 // Launch order of the frame's composite kernels (gs_config.schedule 3 / 4): what the last forward under the same view slot
@@ -373,7 +370,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
             if ((e = hipEventCreate(&c->ev[s][k])) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
     if ((e = hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
     if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipStreamCreate"); }
-    for (hipEvent_t *ev : {&c->ev_main, &c->ev_g2d_zero, &c->ev_order})
+    for (hipEvent_t *ev : {&c->ev_main, &c->ev_order})
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
     if (c->cfg.rank_mode == 0) {
         // The one-instruction stable rank (ds_add_rtn pre-values in ascending lane order) is a measured property of
@@ -409,7 +406,7 @@ int gs_destroy(gs_ctx *c) {
         for (int k = 0; k < 2; ++k)
             if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
     if (c->ev_count) (void)hipEventDestroy(c->ev_count);
-    for (hipEvent_t ev : {c->ev_main, c->ev_g2d_zero, c->ev_order}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {c->ev_main, c->ev_order}) if (ev) (void)hipEventDestroy(ev);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1000,17 +997,6 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     }
     const uint32_t *order = forward_order(c);
     if (c->order_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0)); c->order_pending = false; }     // the order kernel in flight reads tile_work
-    c->g2d_zero_pending = false;
-    if (c->prev_frame_had_backward && use_side_stream(c)) {   // the zero fill of the backward's gradient rows (64 B per gaussian) runs on the side stream BESIDE the forward composite
-        const bool det = c->cfg.deterministic != 0;
-        const size_t n1 = c->n ? (size_t)c->n : 1, bytes = (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1;
-        HIPCHK(c, c->g2d.ensure(bytes));
-        HIPCHK(c, hipEventRecord(c->ev_main, c->stream));                 // behind the previous frame's readers of g2d
-        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
-        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, bytes, c->side));
-        HIPCHK(c, hipEventRecord(c->ev_g2d_zero, c->side));
-        c->g2d_zero_pending = true;
-    }
     for (int r = 0; r < R; ++r) {
         if (r > 0) { if (int rc = bin_round(c, r)) return rc; }
         if (int rc = enqueue_forward_round(c, r, order)) return rc;
@@ -1032,7 +1018,6 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     if (transmittance && transmittance != c->tr()) HIPCHK(c, hipMemcpyAsync(transmittance, c->tr(), sizeof(float) * px, kind, c->stream));
     if (mem == GS_MEM_HOST && (image || transmittance)) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->did_fwd = true; c->did_bwd = false; c->did_bwd_composite = false;
-    c->prev_frame_had_backward = false;
     c->prev_counters_valid = true; c->prev_n_inst = c->n_inst;
     return GS_OK;
 }
@@ -1093,8 +1078,10 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
     a.variant = c->variant_bwd; a.cull = c->cfg.alpha_cull != 0;
     if (!params_only) {
         c->last_dC = dC_dev;
-        if (c->g2d_zero_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_g2d_zero, 0)); c->g2d_zero_pending = false; }   // zeroed beside the forward
-        else HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));     // a second backward of the frame
+        // zero fill of the gradient rows (64 B per gaussian), in line: on a side stream beside the forward composite it cost more than
+        // it hid (C3, same box, interleaved: 1.433 ms with the fill beside the forward, 1.412 ms in line -- its workgroups take wave slots
+        // from the forward's tiles, and the two event hand-shakes per frame delay the depth sort's launches)
+        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
         // launch order: the one the frame's forward used, or (no history) what the order kernel made of that forward
         if (lpt_schedule(c)) a.tile_order = c->frame_order;
         if (!c->bwd_counters_zeroed) HIPCHK(c, hipMemsetAsync(a.walked, 0, 16, c->stream));     // the backward's work counters
@@ -1110,7 +1097,6 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
             HIPCHK(c, gs_launch_composite_bwd(a, c->stream));
         }
         c->did_bwd_composite = true;
-        c->prev_frame_had_backward = true;
     }
     if (composite_only) {
         if (mem == GS_MEM_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
