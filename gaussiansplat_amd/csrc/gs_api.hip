@@ -364,11 +364,11 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipSetDevice"); }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipStreamCreate"); }
     c->own_stream = true;
-    if ((e = hipHostMalloc((void **)&c->pinned, 512, hipHostMallocDefault)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return hipfail(nullptr, e, "hipHostMalloc"); }
+    if ((e = hipHostMalloc((void **)&c->pinned, 512, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return hipfail(nullptr, e, "hipHostMalloc"); }
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
         for (int k = 0; k < 2; ++k)
             if ((e = hipEventCreate(&c->ev[s][k])) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
-    if ((e = hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
+    if ((e = hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming | hipEventReleaseToSystem)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
     if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipStreamCreate"); }
     for (hipEvent_t *ev : {&c->ev_main, &c->ev_order})
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
@@ -638,7 +638,7 @@ static GsBin3L1 two_level_args(gs_ctx *c, const uint32_t *perm_slab, int64_t n_a
     b.cap_coarse = (uint32_t)std::min<size_t>(cap_coarse, 0xFFFFFFFEu); b.cap_fine = (uint32_t)std::min<size_t>(cap_fine, 0xFFFFFFFEu);
     return b;
 }
-static int two_level_count(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, const uint8_t *sdone) {
+static int two_level_count(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, const uint8_t *sdone, bool to_host = false) {
     const int ns = c->sgx * c->sgy;
     HIPCHK(c, c->rect_sorted.ensure(sizeof(uint32_t) * 2 * (size_t)(nr ? nr : 1)));
     HIPCHK(c, c->l1_table.ensure(sizeof(uint32_t) * gs_bin3_table_words(nr, ns)));
@@ -647,7 +647,11 @@ static int two_level_count(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, 
     HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
     HIPCHK(c, c->cranges.ensure(sizeof(uint32_t) * 2 * (size_t)ns));
     HIPCHK(c, c->tilecnt.ensure(sizeof(uint32_t) * (size_t)c->gx * c->gy));
-    HIPCHK(c, gs_bin3_l1_count(two_level_args(c, perm_slab, n_all, nr, sdone, 0, 0), c->stream));
+    GsBin3L1 b = two_level_args(c, perm_slab, n_all, nr, sdone, 0, 0);
+    if (to_host) {                                                          // the layout settle_totals reads: counter block at pinned + 8
+        b.host_totals = c->pinned + 8 + 32; b.host_walked = c->pinned + 8; b.walked_src = c->counters.as<uint32_t>();
+    }
+    HIPCHK(c, gs_bin3_l1_count(b, c->stream));
     return GS_OK;
 }
 static int two_level_lists(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, size_t coarse, size_t fine, uint32_t *ranges, uint32_t *ids_out,
@@ -834,10 +838,11 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     if (c->two_level) {
         {
             StageTimer t(c, GS_STAGE_COUNT_SCAN);
-            if (int rc = two_level_count(c, perm, c->n, n0, nullptr)) return rc;
+            if (int rc = two_level_count(c, perm, c->n, n0, nullptr, c->n > 0)) return rc;
         }
-        // ONE copy carries the previous frame's walked count (bytes 0..7 of the counter block) and this frame's totals (bytes 128..139)
-        HIPCHK(c, hipMemcpyAsync(c->pinned + 8, c->counters.p, GS_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
+        // the previous frame's walked count (bytes 0..7 of the counter block) and this frame's totals (bytes 128..139) travel to the host:
+        // stored into coherent pinned memory by the scan kernel itself (no copy command in the stream); an empty model launches nothing
+        if (c->n <= 0) HIPCHK(c, hipMemcpyAsync(c->pinned + 8, c->counters.p, GS_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
         c->pending_totals = true;
         // speculative launch: one round, and buffers from an earlier frame to launch against

@@ -90,6 +90,8 @@ struct L1Args {
     uint32_t *zero_words;        // 32 words zeroed by l1_scatter (the forward's work counters: saves a memset command); may be null
     uint32_t cap_coarse, cap_fine; // entries the coarse lists (cids, clr) / the tile lists (ids) can hold: a frame whose totals exceed
                                  // them writes no list at all (every range empty) and the host redoes it with larger buffers
+    uint32_t *host_totals, *host_walked;   // coherent pinned host memory (may be null): the totals and the two words at walked_src, stored
+    const uint32_t *walked_src;            // by l1_rowscan itself -- a copy command in the stream is a blit kernel of 4 us plus its gaps
 };
 // The lists are enqueued BEFORE the host has seen the frame's totals (speculative launch, gs_api.hip): every kernel that
 // writes them checks the totals against the capacities of the buffers it was given.
@@ -202,7 +204,15 @@ __global__ __launch_bounds__(256) void l1_rowscan_kernel(L1Args a) {
         for (int d = GS_WAVE / 2; d > 0; d >>= 1) t += __shfl_down(t, d);
         if (lane == 0) wide[wv] = t;
         __syncthreads();
-        if (tid == 0) { const unsigned long long tot = wide[0] + wide[1] + wide[2] + wide[3]; a.totals[which] = tot >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot; }
+        if (tid == 0) {
+            const unsigned long long tot = wide[0] + wide[1] + wide[2] + wide[3];
+            const uint32_t t32 = tot >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot;
+            a.totals[which] = t32;
+            if (a.host_totals) {
+                a.host_totals[which] = t32;
+                if (which == 0 && a.host_walked) { a.host_walked[0] = a.walked_src[0]; a.host_walked[1] = a.walked_src[1]; }
+            }
+        }
         return;
     }
     uint32_t *row = a.table + (size_t)blockIdx.x * a.nwg;
@@ -547,6 +557,7 @@ static L1Args l1_args(const GsBin3L1 &b) {
     a.partials = b.partials; a.totals = b.totals; a.cranges = b.cranges; a.cids = b.cids; a.clr = b.clr;
     a.tilecnt = b.tilecnt; a.ntiles = b.ntiles; a.zero_words = b.zero_words;
     a.cap_coarse = b.cap_coarse; a.cap_fine = b.cap_fine;
+    a.host_totals = b.host_totals; a.host_walked = b.host_walked; a.walked_src = b.walked_src;
     return a;
 }
 size_t gs_bin3_table_words(int64_t n_slab, int ns) { const int G = gs_bin3_group(ns); return (size_t)ns * (size_t)((n_slab + G - 1) / G + 1); }

@@ -168,6 +168,10 @@ struct GsBin3L1 {
     int ntiles;
     uint32_t *zero_words;      // gs_bin3_l1_scatter zeroes these 32 words (may be null)
     uint32_t cap_coarse, cap_fine; // entries cids / clr and ids_out can hold (lists are dropped, not overrun, when the totals exceed them)
+    // read-back without a copy command: when host_totals is set (coherent pinned host memory) the scan kernel stores the three totals
+    // there as well, and the two words at walked_src (device: the previous frame's walked count) to host_walked
+    uint32_t *host_totals, *host_walked;
+    const uint32_t *walked_src;
 };
 struct GsBin3Args {
     const uint32_t *cranges;   // 2 x ns: [start, end) of every super-tile's list inside cids
