@@ -190,6 +190,7 @@ def main():
                     "segment starts as soon as the last view's SH kernel has run, beside the geometry chain)")
     ap.add_argument("--no-pipeline", action="store_true", help="view batches: one renderer, one stream (default: the views of a rank alternate between "
                     "two renderers / streams over the same model, so the lists of view k+1 are built beside the composite kernels of view k)")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="view batches: views of a rank in flight at once (renderers / streams over the same model)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
     if args.config is None:
@@ -260,7 +261,7 @@ def main():
     def step(r, k):
         """one step = one view batch: this rank's views one after the other (gradients accumulate), then the exchange"""
         batch = batches[k % len(batches)]
-        hv = r.__dict__.setdefault("_bench_hv", D.HipViewRenderer(r))            # (cycle r <-> hv: collected by gc below)
+        hv = r.__dict__.setdefault("_bench_hv", D.HipViewRenderer(r, args.pipeline_depth))            # (cycle r <-> hv: collected by gc below)
         D.multi_view_step(hv, [cams[v] for v in batch], [dCs[v] for v in batch], sync=sync_mode[0], overlap=not args.no_overlap,
                           pipeline=not args.no_pipeline)
 
@@ -414,7 +415,7 @@ def main():
         cams8 = [camera_of(v) for v in v8]
         dC8 = [torch.as_tensor(synthetic.make_dC(W, H, seed + v)).cuda() for v in v8]
         r8 = make(args.t_min, 0)
-        hv = D.HipViewRenderer(r8)
+        hv = D.HipViewRenderer(r8, args.pipeline_depth)
         for _ in range(3):
             D.multi_view_step(hv, cams8, dC8, pipeline=not args.no_pipeline)
         torch.cuda.synchronize()

@@ -103,9 +103,10 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
 class HipViewRenderer:
     """Adapter of a GaussianRenderer3D (HIP path) to the ViewRenderer protocol."""
 
-    def __init__(self, renderer):
+    def __init__(self, renderer, pipeline_depth: int = 2):
         self.r = renderer
         self.last_ctx = renderer.ctx            # the ctx that rendered the most recent view (introspection: counters, instance counts)
+        self.pipeline_depth = max(2, int(pipeline_depth))      # views in flight in render_views_pipelined
 
     def contexts(self):
         """every gs_ctx views are rendered through (the renderer's own, and the two twins of the pipelined mode once they exist)"""
@@ -139,7 +140,7 @@ class HipViewRenderer:
             H, W = r.transmittance.shape
             cfg = r.ctx.cfg
             tw = []
-            for _ in range(2):
+            for _ in range(self.pipeline_depth):
                 t = R.GaussianRenderer3D(r.splatData, (W, H), r.sh_degree, device=r.imageData.device.index or 0, order=int(cfg.order),
                                          t_min=float(cfg.t_min), deterministic=bool(cfg.deterministic), alpha_cull=bool(cfg.alpha_cull),
                                          rank_mode=int(cfg.rank_mode), slab_mode=int(cfg.slab_mode), schedule=int(cfg.schedule),
@@ -167,9 +168,9 @@ class HipViewRenderer:
         overwrite = r._grads_lazy_zero
         prev_chain = None
         for i, (cam, dC) in enumerate(zip(cameras, dCs)):
-            t, st = self._twins()[i & 1]
+            t, st = self._twins()[i % self.pipeline_depth]
             with torch.cuda.stream(st):
-                if i < 2:
+                if i < self.pipeline_depth:
                     st.wait_event(start)                                   # inputs and the previous step's readers of the gradient buffer
                 tps = R.preprocess(t, cam)
                 R.compactIdxs(t)
