@@ -88,7 +88,7 @@ struct gs_ctx {
 
     DevBuf invcov;                           // 4 x n raw conic (introspection; the payload rows carry it scaled)
     DevBuf payload, depth_key, rect, pairs_a, pairs_b, perm, offsets, block_sums;
-    DevBuf inst_a, inst_b, table, digit_total, ranges, image, trans, g2d, stage_in;
+    DevBuf inst_a, inst_b, table, digit_total, ranges, image, trans, g2d, stage_in, dbg_order;
     DevBuf dbg[7];
     DevBuf ids, words, cs, diff;             // sorted gaussian ids; pass-1 words; chunk owners; 2-D difference array
     uint32_t *perm_ptr = nullptr;
@@ -114,7 +114,7 @@ struct gs_ctx {
     // stream while this frame's backward still reads the one its forward used.  Index GS_MAX_VIEW_SLOTS = frames without a slot.
     DevBuf slot_order[GS_MAX_VIEW_SLOTS + 1][2];
     int slot_sel[GS_MAX_VIEW_SLOTS + 1] = {};
-    int64_t slot_tiles[GS_MAX_VIEW_SLOTS + 1] = {};   // the newest order is valid for a grid of this many tiles (0: no history)
+    int64_t slot_tiles[GS_MAX_VIEW_SLOTS + 1] = {};   // the newest order is valid for this grid (gx << 32 | gy; 0: no history)
     const uint32_t *frame_order = nullptr;   // the launch order of THIS frame's composite kernels (null: tile order)
     bool bwd_counters_zeroed = false;        // the forward kernel zeroed the backward's work counters on its way
     // ---- side stream: the order kernel (needed by the slot's NEXT frame, not by this one) runs beside the backward composite
@@ -234,7 +234,7 @@ const uint32_t *forward_order(gs_ctx *c) {
     if (!lpt_schedule(c) || ntiles <= 0 || ntiles > GS_LPT_MAX_TILES) return nullptr;
     const int k = order_index(c);
     if (k == GS_MAX_VIEW_SLOTS && c->cfg.schedule != 4) return nullptr;
-    if (c->slot_tiles[k] != ntiles) return nullptr;
+    if (c->slot_tiles[k] != (((int64_t)c->gx << 32) | (int64_t)c->gy)) return nullptr;          // (the order's length and groups belong to one grid)
     if (c->order_pending) {                                              // (long complete by now; an event wait on the stream costs nothing)
         if (hipStreamWaitEvent(c->stream, c->ev_order, 0) != hipSuccess) return nullptr;
         c->order_pending = false;
@@ -253,21 +253,21 @@ int build_frame_order(gs_ctx *c, const uint32_t *used) {
     const int k = order_index(c);
     const int dst = used ? 1 - c->slot_sel[k] : c->slot_sel[k];
     DevBuf &ob = c->slot_order[k][dst];
-    HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
+    HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)gs_lpt_order_len(c->gx, c->gy) + 16)));
     if (used && use_side_stream(c)) {
         if (c->order_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0));      // (never two in flight)
         HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
-        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, (int)ntiles, ob.as<uint32_t>(), c->side, nullptr, c->lpt_buckets));
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->side, nullptr, c->lpt_buckets));
         HIPCHK(c, hipEventRecord(c->ev_order, c->side));
         c->order_pending = true;
         c->slot_sel[k] = dst;
         // (tile_work is rewritten by the next forward of this ctx: it waits for ev_order first, see forward_order / gs_forward)
     } else {
-        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, (int)ntiles, ob.as<uint32_t>(), c->stream, nullptr, c->lpt_buckets));
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->stream, nullptr, c->lpt_buckets));
         c->frame_order = ob.as<uint32_t>();
     }
-    c->slot_tiles[k] = ntiles;
+    c->slot_tiles[k] = ((int64_t)c->gx << 32) | (int64_t)c->gy;
     return GS_OK;
 }
 
@@ -288,7 +288,7 @@ int composite_sched_queue(gs_ctx *c, GsCompositeArgs &a, int which) {
     HIPCHK(c, ord.ensure(sizeof(uint32_t) * ((size_t)ntiles + 16)));
     const uint32_t *src = c->cfg.schedule == 12 ? nullptr : which == 0 ? c->ranges.as<uint32_t>() : c->tile_work.as<uint32_t>();
     HIPCHK(c, gs_launch_tile_order(src, which == 0 ? 1 : 0, ntiles, ord.as<uint32_t>(), ord.as<uint32_t>() + ntiles, c->stream));
-    a.tile_order = ord.as<uint32_t>();
+    a.tile_order = ord.as<uint32_t>(); a.order_len = ntiles;
     a.queue_seg = ord.as<uint32_t>() + ntiles;
     return GS_OK;
 }
@@ -391,7 +391,7 @@ int gs_destroy(gs_ctx *c) {
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
-                      &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
+                      &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in, &c->dbg_order,
                       &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
                       &c->tile_order_f, &c->tile_order_b, &c->tile_order_p, &c->tile_work, &c->tile_clock,
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
@@ -964,7 +964,7 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
     a.resume = r > 0; a.final_round = r == R - 1;
     a.tile_work = c->tile_work.as<uint32_t>();
-    a.tile_order = order;
+    a.tile_order = order; a.order_len = order ? gs_lpt_order_len(c->gx, c->gy) : 0;
     a.zero_words = c->counters.as<unsigned long long>() + 2;               // the backward's work counters (walked, evaluated)
     if (R > 1) { a.tile_pos = c->tile_pos.as<uint32_t>(); a.tile_done = c->tile_done.as<uint8_t>(); a.tile_dead = c->tile_dead.as<unsigned long long>(); }
 #ifdef GS_EXPERIMENTS
@@ -1088,7 +1088,7 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         // from the forward's tiles, and the two event hand-shakes per frame delay the depth sort's launches)
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
         // launch order: the one the frame's forward used, or (no history) what the order kernel made of that forward
-        if (lpt_schedule(c)) a.tile_order = c->frame_order;
+        if (lpt_schedule(c)) { a.tile_order = c->frame_order; a.order_len = c->frame_order ? gs_lpt_order_len(c->gx, c->gy) : 0; }
         if (!c->bwd_counters_zeroed) HIPCHK(c, hipMemsetAsync(a.walked, 0, 16, c->stream));     // the backward's work counters
         c->bwd_counters_zeroed = false;
 #ifdef GS_EXPERIMENTS
@@ -1463,8 +1463,26 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     // variant tens digit (gs_composite.hip: apply_sched_variant): 0 the frame's own launch order (what production uses for the
     // backward and for the next forward of the slot), 1 tile order, 3 = 0 explicitly
     a.tile_order = lpt_schedule(c) ? c->frame_order : nullptr;
+    a.order_len = a.tile_order ? gs_lpt_order_len(c->gx, c->gy) : 0;
     a.tile_order_band = a.tile_order;
 #ifdef GS_EXPERIMENTS
+    if (const char *f = std::getenv("GS_DEBUG_ORDER_FILE")) {                // experiments: a launch order made by a script (uint32 x ntiles)
+        const size_t ntiles = (size_t)c->gx * c->gy;
+        std::vector<uint32_t> h(ntiles);
+        FILE *fp = std::fopen(f, "rb");
+        if (fp && std::fread(h.data(), sizeof(uint32_t), ntiles, fp) == ntiles) {
+            std::vector<uint8_t> seen(ntiles, 0);
+            bool ok = true;
+            for (uint32_t t : h) { if (t >= ntiles || seen[t]) { ok = false; break; } seen[t] = 1; }
+            if (ok) {
+                HIPCHK(c, c->dbg_order.ensure(sizeof(uint32_t) * (ntiles + 16)));
+                HIPCHK(c, hipMemcpyAsync(c->dbg_order.p, h.data(), sizeof(uint32_t) * ntiles, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                a.tile_order = c->dbg_order.as<uint32_t>(); a.tile_order_band = a.tile_order; a.order_len = (int)ntiles;
+            }
+        }
+        if (fp) std::fclose(fp);
+    }
     a.map_mode = (variant / 100) % 10;
     {   // tens digit 0 / 2 in experiment builds: the persistent queue, longest first / in tile order
         const int keep = c->cfg.schedule;

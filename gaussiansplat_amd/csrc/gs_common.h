@@ -222,7 +222,8 @@ struct GsCompositeArgs {
     // work queue (persistent waves pull tiles from an atomic ticket counter, longest first)
     uint32_t *queue;           // 8 ticket counters (one per XCD), zeroed before the launch; null: one wave per tile, blockIdx order
     const uint32_t *queue_seg; // 9 bounds of the per-XCD segments of tile_order
-    const uint32_t *tile_order; // segment x: the tiles with tile % 8 == x, heaviest first
+    const uint32_t *tile_order; // plain launch: block b composites tile_order[b] (0xFFFFFFFF: none); experiments' queues: segment x = XCD x's tiles
+    int order_len;              // entries of tile_order = blocks of the plain launch (0: gx * gy)
     const uint32_t *tile_order_plain; // A/B: the same segments in tile order (no longest-first)
     const uint32_t *tile_order_band;  // A/B: longest-first permutation for a plain launch (schedule 3), tile % 8 preserved
     uint32_t *tile_work;       // forward: evaluated entries per tile (the backward's exact work measure); may be null
@@ -240,10 +241,12 @@ struct GsCompositeArgs {
     int resume;                // forward: continue from the pixel state the previous round left in image / trans
     int final_round;           // forward: last round of the frame: transmittance is written plain (no sign flag)
 };
-// longest-first launch order of the tiles (keeps tile % 8; GS_LPT_BUCKETS work classes, tile order inside a class; one workgroup)
+// longest-first launch order of the tiles for a plain launch (gs_composite.hip: groups of 8 x 8 tiles dealt to the XCDs by work,
+// GS_LPT_BUCKETS work classes inside an XCD's list; one workgroup).  order: gs_lpt_order_len(gx, gy) entries, holes = 0xFFFFFFFF.
 // zero14 (may be null): fourteen 64-bit words zeroed on the way (the backward's work and ticket counters: saves a memset command)
 #define GS_LPT_MAX_TILES 35000
-hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s,
+int gs_lpt_order_len(int gx, int gy);
+hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
                                     unsigned long long *zero14 = nullptr, int buckets = 0);
 hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s);
 int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body = 0);   // occupancy x CUs (body: A/B variant)

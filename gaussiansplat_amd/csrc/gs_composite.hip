@@ -99,7 +99,11 @@ __device__ __forceinline__ int next_tile(const GsCompositeArgs &a, int ntiles, b
     }
 #endif
     if (!first) return -1;
-    if (a.tile_order) return (int)blockIdx.x < ntiles ? (int)a.tile_order[blockIdx.x] : -1;     // schedule 3 / 4: plain launch, permuted tiles
+    if (a.tile_order) {                                                  // schedule 3 / 4: plain launch over a launch order (holes: GS_LPT_NONE)
+        if ((int)blockIdx.x >= (a.order_len > 0 ? a.order_len : ntiles)) return -1;
+        const uint32_t t = a.tile_order[blockIdx.x];
+        return t < (uint32_t)ntiles ? (int)t : -1;
+    }
 #ifdef GS_EXPERIMENTS
     const int tile = tile_of_block(blockIdx.x, ntiles, a.gx, a.map_mode);
 #else
@@ -776,39 +780,55 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 #endif  // GS_EXPERIMENTS
 
 // Longest-first order for a PLAIN launch (gs_config.schedule 3 / 4).  The dispatcher hands workgroups out in blockIdx order,
-// round-robin over the XCDs, so order[b] keeps what the plain tile order has -- tile % 8 == b % 8: the same tiles on the same
-// XCD as in launch order -- and inside each residue class the heavier tiles come first, so the workgroups that start last are
-// the lightest ones and the kernel ends without a tail (C3 backward: 0.84 -> 0.74 ms).
-// Round 3: the order is a STABLE counting sort on NB work classes (work / max in NB steps), tiles of one class stay in tile
-// order.  Round 2 sorted on 256 classes with LDS atomics, i.e. in no particular order inside a class: vertically adjacent
-// tiles (tile + gx: same residue class for the 8-aligned grids of 1080p and 4K), which share most of their splats, no longer
-// ran together and the composite's payload gathers missed the XCD's L2 twice as often (r02c PMC: 961 MB fetched by the
-// permuted backward against 457 MB by the forward in tile order, same lists).  Only the START order of the light tail
-// matters for the balance -- with 5 waves per SIMD the first 5120 of C3's 8160 tiles start at once whatever their order --
-// so a few classes lose nothing.  Ranks come from an LDS bitmap [class row][tile of the residue class]: atomic OR (order
-// free), word prefix, popcount below the own bit -- the same construction as the level-1 binning (gs_bin3.hip).
-// One workgroup; work = src[t], or the list length (ranges_mode).
+// round-robin over the XCDs: block b runs on XCD b % 8.  order[8 j + x] is therefore the j-th tile of XCD x, and the kernel
+// decides two things.
+// (1) WHICH tiles an XCD gets.  Round 2 / early round 3 kept what the plain tile order has (XCD = tile % 8): neighbours in x on
+//     eight different XCDs, so a gaussian's payload row was fetched by nearly every XCD whose L2 it then filled.  Now the tiles are
+//     dealt in GROUPS of 8 x 8 (GS_LPT_GROUP): the groups are ranked by their work and dealt to the XCDs in snake order (rank k ->
+//     XCD k % 8, every second round reversed), which balances the XCDs' work to better than 1 % on the synthetic scenes
+//     (tools/xcd_order.py) and gives every XCD spatially compact sets of tiles.  Measured at C3 (rocprofv3 FETCH_SIZE, per launch):
+//     forward 338 -> 202 MB, backward 378 -> 225 MB requested from the fabric -- backward traffic 1.02 x its algorithmic bytes.
+// (2) IN WHICH ORDER an XCD starts its tiles: heavier first, so the workgroups that start last are the lightest ones and the
+//     kernel ends without a tail (C3 backward round 2: 0.84 -> 0.74 ms).  A STABLE counting sort on NB work classes (work / max in
+//     NB steps); inside a class the tiles stay in (group, row, column) order, so neighbours still start together.  Only the START
+//     order of the light tail matters for the balance -- with 5 waves per SIMD the first 5120 of C3's 8160 tiles start at once
+//     whatever their order -- so a few classes lose nothing.
+// Ranks come from an LDS bitmap [XCD][class][slot]: slot = 64 * (ordinal of the tile's group on its XCD) + position in the group;
+// atomic OR (order free), word prefix, popcount below the own bit -- the construction of the level-1 binning (gs_bin3.hip).
+// An XCD's list may be shorter than the longest one: the holes of `order` hold GS_LPT_NONE and their workgroups exit at once;
+// order has gs_lpt_order_len(gx, gy) entries and that is the launch's grid.  One workgroup; work = src[t], or the list length
+// (ranges_mode).
 #ifndef GS_LPT_BUCKETS
 #define GS_LPT_BUCKETS 32
 #endif
-__global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int nb,
+#define GS_LPT_GROUP 8
+#define GS_LPT_NONE 0xFFFFFFFFu
+static inline int lpt_groups(int gx, int gy) { return ((gx + GS_LPT_GROUP - 1) / GS_LPT_GROUP) * ((gy + GS_LPT_GROUP - 1) / GS_LPT_GROUP); }
+int gs_lpt_order_len(int gx, int gy) { return 8 * GS_LPT_GROUP * GS_LPT_GROUP * ((lpt_groups(gx, gy) + 7) / 8); }
+
+__global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int gx, int ng, int nb,
                                                                uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14) {
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wmax;
-    __shared__ uint32_t rowtot[8 * 32], rowstart[8 * 32];
+    __shared__ uint32_t rowtot[8 * 32], rowstart[8 * 32], xcount[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int per = (ntiles + 7) >> 3;                                   // tiles per residue class (upper bound)
-    const int W = (per + 31) >> 5;                                       // bitmap words per row
-    const int rows = 8 * nb;                                             // row = residue * nb + class
+    constexpr int GT = GS_LPT_GROUP * GS_LPT_GROUP;                      // tiles of a full group
+    const int ordmax = (ng + 7) >> 3;                                    // groups per XCD (upper bound)
+    const int per = ordmax * GT;                                         // slots per XCD
+    const int W = per >> 5;                                              // bitmap words per row
+    const int rows = 8 * nb;                                             // row = XCD * nb + class
+    const int ngx = (gx + GS_LPT_GROUP - 1) / GS_LPT_GROUP;
     uint32_t *bm = lds;                                                  // [rows][W]
-    uint16_t *pre = reinterpret_cast<uint16_t *>(bm + rows * W);         // [rows][W] set bits of the row below word w
-    uint8_t *cls = reinterpret_cast<uint8_t *>(pre + rows * W + ((rows * W) & 1));   // [ntiles]
-    for (int i = tid; i < rows * W; i += 1024) bm[i] = 0;
+    uint32_t *gsum = bm + rows * W;                                      // [ng] work of the group
+    uint16_t *pre = reinterpret_cast<uint16_t *>(gsum + ng);             // [rows][W] set bits of the row below word w
+    uint16_t *ginfo = pre + rows * W;                                    // [ng] XCD | ordinal << 3
+    uint8_t *cls = reinterpret_cast<uint8_t *>(ginfo + ng + (ng & 1) + ((rows * W) & 1));   // [ntiles]
+    for (int i = tid; i < rows * W + ng; i += 1024) bm[i] = 0;          // bitmap and group sums
     if (tid == 0) wmax = 1;
     if (zero14 && tid < 14) zero14[tid] = 0ull;
     __syncthreads();
-    // the tiles' work is read twice (maximum, then classes), eight independent loads in flight per thread each time: the
-    // second read comes from L2, and a copy in LDS would not fit beside the bitmap for 4K-class grids
+    // the tiles' work is read twice (maximum + group sums, then classes), eight independent loads in flight per thread each time:
+    // the second read comes from L2, and a copy in LDS would not fit beside the bitmap for 4K-class grids
     auto load8 = [&](int t0, uint32_t (&v)[8]) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -817,16 +837,34 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
             if (t < ntiles) v[k] = ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t];
         }
     };
+    auto group_of = [&](int t, int &local) {
+        const int ty = t / gx, tx = t - ty * gx;
+        local = (ty & (GS_LPT_GROUP - 1)) * GS_LPT_GROUP + (tx & (GS_LPT_GROUP - 1));
+        return (ty / GS_LPT_GROUP) * ngx + tx / GS_LPT_GROUP;
+    };
     uint32_t m = 0;
     for (int t0 = 0; t0 < ntiles; t0 += 8 * 1024) {
         uint32_t v[8];
         load8(t0, v);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) m = max(m, v[k]);
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * 1024 + tid;
+            m = max(m, v[k]);
+            if (t < ntiles && v[k]) { int local; atomicAdd(&gsum[group_of(t, local)], v[k]); }
+        }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
     if (lane == 0) atomicMax(&wmax, m);
+    __syncthreads();
+    // rank of every group by work (ties by index), dealt in snake order: round r = rank / 8 gives each XCD one group
+    for (int g = tid; g < ng; g += 1024) {
+        const uint32_t mine = gsum[g];
+        int rank = 0;
+        for (int h = 0; h < ng; ++h) { const uint32_t o = gsum[h]; rank += (o > mine || (o == mine && h < g)) ? 1 : 0; }
+        const int r = rank >> 3, x = (r & 1) ? 7 - (rank & 7) : (rank & 7);
+        ginfo[g] = (uint16_t)(x | (r << 3));
+    }
     __syncthreads();
     const float scale = (float)nb / (float)wmax;
     for (int t0 = 0; t0 < ntiles; t0 += 8 * 1024) {
@@ -838,8 +876,10 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
             if (t < ntiles) {
                 const int c = min(nb - 1, max(0, nb - 1 - (int)((float)v[k] * scale)));        // class 0 = heaviest
                 cls[t] = (uint8_t)c;
-                const int i = t >> 3;
-                atomicOr(&bm[((t & 7) * nb + c) * W + (i >> 5)], 1u << (i & 31));
+                int local;
+                const uint32_t gi = ginfo[group_of(t, local)];
+                const int i = (int)(gi >> 3) * GT + local;
+                atomicOr(&bm[((int)(gi & 7u) * nb + c) * W + (i >> 5)], 1u << (i & 31));
             }
         }
     }
@@ -858,24 +898,31 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
         if (lane == 0) rowtot[r] = carry;
     }
     __syncthreads();
-    if (tid < 8) {                                                       // class starts inside each residue class
+    if (tid < 8) {                                                       // class starts inside each XCD's list, and its length
         uint32_t run = 0;
         for (int c = 0; c < nb; ++c) { rowstart[tid * nb + c] = run; run += rowtot[tid * nb + c]; }
+        xcount[tid] = run;
     }
     __syncthreads();
+    for (int i = tid; i < 8 * per; i += 1024)                            // holes behind the shorter lists
+        if ((uint32_t)(i >> 3) >= xcount[i & 7]) order[i] = GS_LPT_NONE;
     for (int t = tid; t < ntiles; t += 1024) {
-        const int r = (t & 7) * nb + cls[t], i = t >> 3;
+        int local;
+        const uint32_t gi = ginfo[group_of(t, local)];
+        const int x = (int)(gi & 7u), r = x * nb + cls[t], i = (int)(gi >> 3) * GT + local;
         const uint32_t pos = rowstart[r] + pre[r * W + (i >> 5)] + (uint32_t)__popc(bm[r * W + (i >> 5)] & ((1u << (i & 31)) - 1u));
-        order[8u * pos + (uint32_t)(t & 7)] = (uint32_t)t;
+        order[8u * pos + (uint32_t)x] = (uint32_t)t;
     }
 }
-hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, hipStream_t s,
+
+hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
                                     unsigned long long *zero14, int buckets) {
+    const int ntiles = gx * gy;
     if (ntiles <= 0) return hipSuccess;
     if (ntiles > GS_LPT_MAX_TILES) return hipErrorInvalidValue;          // beyond 8K-class images: the callers keep launch order
     int nb = buckets > 0 && buckets <= 32 ? buckets : GS_LPT_BUCKETS;
-    const int per = (ntiles + 7) >> 3, W = (per + 31) >> 5;
-    auto lds_of = [&](int b) { return (size_t)8 * b * W * 4 + ((size_t)8 * b * W + 1) * 2 + (size_t)ntiles + 16; };
+    const int ng = lpt_groups(gx, gy), W = gs_lpt_order_len(gx, gy) / 8 / 32;
+    auto lds_of = [&](int b) { return (size_t)8 * b * W * 4 + (size_t)ng * 4 + ((size_t)8 * b * W + ng + 2) * 2 + (size_t)ntiles + 16; };
     while (nb > 2 && lds_of(nb) > 150 * 1024) nb >>= 1;                  // very large grids: fewer work classes
     const size_t lds = lds_of(nb);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
@@ -883,7 +930,7 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_lpt_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, nb, order, zero14);
+    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, gx, ng, nb, order, zero14);
     return hipGetLastError();
 }
 
@@ -914,8 +961,10 @@ static size_t debug_extra_lds() {
 static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {
 #ifdef GS_EXPERIMENTS
     if (a.queue) return dim3((unsigned)max(1, min(a.grid_waves > 0 ? a.grid_waves : ntiles, ntiles)));
+    if (a.tile_order && a.order_len > 0) return dim3((unsigned)a.order_len);
     return dim3(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8);
 #else
+    if (a.tile_order && a.order_len > 0) return dim3((unsigned)a.order_len);
     return dim3(((ntiles + 7) / 8) * 8);
 #endif
 }
