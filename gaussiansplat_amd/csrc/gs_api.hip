@@ -217,8 +217,11 @@ int bind_device(gs_ctx *c) {
     return GS_OK;
 }
 
-// A launch order only matters when there are more tiles than wave slots (256 CUs x 4 SIMDs x 5 waves): below that every tile
-// starts at once whatever the order, and the order kernel would be one more launch in a frame that is bound by launches.
+// A launch order is built only when there are more tiles than wave slots (256 CUs x 4 SIMDs x 5 waves).  Below that the isolated
+// kernels do gain from it (C2, 2500 tiles: forward 68 -> 61 us, backward 145 -> 122 us, tools/xcd_order.py C2 -- in tile order the
+// heavy tiles of the image centre land on neighbouring SIMDs), but the frame does not: its forward is bound by cold gathers, not by
+// balance, and the order kernel is one more launch in a frame that is bound by launches (C2 0.382 -> 0.400 ms, C1 0.183 -> 0.205 ms
+// with it, same box; 0.393 / 0.197 with the kernel on the side stream).
 bool lpt_schedule(const gs_ctx *c) {
     return (c->cfg.schedule == 3 || c->cfg.schedule == 4) && ((int64_t)c->gx * c->gy > 5120 || (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER));
 }

@@ -784,7 +784,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 // decides two things.
 // (1) WHICH tiles an XCD gets.  Round 2 / early round 3 kept what the plain tile order has (XCD = tile % 8): neighbours in x on
 //     eight different XCDs, so a gaussian's payload row was fetched by nearly every XCD whose L2 it then filled.  Now the tiles are
-//     dealt in GROUPS of 8 x 8 (GS_LPT_GROUP): the groups are ranked by their work and dealt to the XCDs in snake order (rank k ->
+//     dealt in GROUPS of 8 x 8 (lpt_group_side): the groups are ranked by their work and dealt to the XCDs in snake order (rank k ->
 //     XCD k % 8, every second round reversed), which balances the XCDs' work to better than 1 % on the synthetic scenes
 //     (tools/xcd_order.py) and gives every XCD spatially compact sets of tiles.  Measured at C3 (rocprofv3 FETCH_SIZE, per launch):
 //     forward 338 -> 202 MB, backward 378 -> 225 MB requested from the fabric -- backward traffic 1.02 x its algorithmic bytes.
@@ -801,23 +801,28 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 #ifndef GS_LPT_BUCKETS
 #define GS_LPT_BUCKETS 32
 #endif
-#define GS_LPT_GROUP 8
 #define GS_LPT_NONE 0xFFFFFFFFu
-static inline int lpt_groups(int gx, int gy) { return ((gx + GS_LPT_GROUP - 1) / GS_LPT_GROUP) * ((gy + GS_LPT_GROUP - 1) / GS_LPT_GROUP); }
-int gs_lpt_order_len(int gx, int gy) { return 8 * GS_LPT_GROUP * GS_LPT_GROUP * ((lpt_groups(gx, gy) + 7) / 8); }
+// group side: 8 tiles (a gaussian of the C3 scene covers 5-6 tiles across), smaller on small grids so that every XCD still gets
+// sixteen or more groups to balance with (config C2, 50 x 50 tiles: 4; a 16 x 16 grid: single tiles, i.e. longest-first over the XCDs)
+static inline int lpt_groups(int gx, int gy, int gs) { return ((gx + gs - 1) / gs) * ((gy + gs - 1) / gs); }
+static inline int lpt_group_side(int gx, int gy) {
+    for (int gs = 8; gs > 1; gs >>= 1) if (lpt_groups(gx, gy, gs) >= 128) return gs;
+    return 1;
+}
+int gs_lpt_order_len(int gx, int gy) { const int gs = lpt_group_side(gx, gy); return 8 * gs * gs * ((lpt_groups(gx, gy, gs) + 7) / 8); }
 
-__global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int gx, int ng, int nb,
+__global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int gx, int ng, int gs, int nb,
                                                                uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14) {
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wmax;
     __shared__ uint32_t rowtot[8 * 32], rowstart[8 * 32], xcount[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int GT = GS_LPT_GROUP * GS_LPT_GROUP;                      // tiles of a full group
+    const int GT = gs * gs;                                              // tiles of a full group (gs = 8, 4, 2 or 1: a power of two)
     const int ordmax = (ng + 7) >> 3;                                    // groups per XCD (upper bound)
     const int per = ordmax * GT;                                         // slots per XCD
-    const int W = per >> 5;                                              // bitmap words per row
+    const int W = (per + 31) >> 5;                                       // bitmap words per row
     const int rows = 8 * nb;                                             // row = XCD * nb + class
-    const int ngx = (gx + GS_LPT_GROUP - 1) / GS_LPT_GROUP;
+    const int ngx = (gx + gs - 1) / gs;
     uint32_t *bm = lds;                                                  // [rows][W]
     uint32_t *gsum = bm + rows * W;                                      // [ng] work of the group
     uint16_t *pre = reinterpret_cast<uint16_t *>(gsum + ng);             // [rows][W] set bits of the row below word w
@@ -839,8 +844,8 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
     };
     auto group_of = [&](int t, int &local) {
         const int ty = t / gx, tx = t - ty * gx;
-        local = (ty & (GS_LPT_GROUP - 1)) * GS_LPT_GROUP + (tx & (GS_LPT_GROUP - 1));
-        return (ty / GS_LPT_GROUP) * ngx + tx / GS_LPT_GROUP;
+        local = (ty & (gs - 1)) * gs + (tx & (gs - 1));
+        return (ty / gs) * ngx + tx / gs;
     };
     uint32_t m = 0;
     for (int t0 = 0; t0 < ntiles; t0 += 8 * 1024) {
@@ -921,7 +926,7 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
     if (ntiles <= 0) return hipSuccess;
     if (ntiles > GS_LPT_MAX_TILES) return hipErrorInvalidValue;          // beyond 8K-class images: the callers keep launch order
     int nb = buckets > 0 && buckets <= 32 ? buckets : GS_LPT_BUCKETS;
-    const int ng = lpt_groups(gx, gy), W = gs_lpt_order_len(gx, gy) / 8 / 32;
+    const int gs = lpt_group_side(gx, gy), ng = lpt_groups(gx, gy, gs), W = (gs_lpt_order_len(gx, gy) / 8 + 31) / 32;
     auto lds_of = [&](int b) { return (size_t)8 * b * W * 4 + (size_t)ng * 4 + ((size_t)8 * b * W + ng + 2) * 2 + (size_t)ntiles + 16; };
     while (nb > 2 && lds_of(nb) > 150 * 1024) nb >>= 1;                  // very large grids: fewer work classes
     const size_t lds = lds_of(nb);
@@ -930,7 +935,7 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_lpt_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, gx, ng, nb, order, zero14);
+    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, gx, ng, gs, nb, order, zero14);
     return hipGetLastError();
 }
 

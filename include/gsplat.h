@@ -125,7 +125,7 @@ typedef struct {
     int32_t reserved[6];      /* sizeof(gs_config) == 96                                                                       */
 } gs_config;
 #define GS_DEBUG_WIDE_CURSORS 1   /* two-level binning: 64-bit list cursors although the lists fit 32-bit byte offsets (tests)    */
-#define GS_DEBUG_ALWAYS_ORDER 2    /* longest-first launch orders and the side stream also on frames too small to profit (tests)   */
+#define GS_DEBUG_ALWAYS_ORDER 2    /* longest-first launch orders (and their side stream) also on grids with fewer tiles than wave slots (tests) */
 
 typedef struct gs_ctx gs_ctx;
 
