@@ -1452,6 +1452,10 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.payload = c->payload.as<GsPayload>();
     a.image = c->img(); a.trans = c->tr();
     a.dC = c->last_dC; a.walked = nullptr;
+    if (variant >= 10000) {                                                  // + 10000: with the two work-counter atomics per tile of a real frame (scratch words; tools/atomics_tail.py)
+        variant -= 10000;
+        a.walked = reinterpret_cast<unsigned long long *>(static_cast<char *>(c->counters.p) + 160);
+    }
     a.final_round = 1;
     a.nseg = 0;
     for (int r = 0; r < c->n_rounds; ++r) {
@@ -1503,7 +1507,9 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
 }
 
 int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *mean_ms) {
-    if (!c || !mean_ms || reps <= 0) return GS_ERR_INVALID;
+    if (!c || !mean_ms || reps == 0) return GS_ERR_INVALID;
+    const bool cold = reps < 0;                                               // negative: -reps launches WITHOUT the warm-up launch (tools/cold_fwd.py)
+    if (cold) reps = -reps;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_debug_time_composite: gs_forward first");
     if (which == 1 && !c->did_bwd) return fail(c, GS_ERR_INVALID, "gs_debug_time_composite: gs_backward first");
     if (bind_device(c)) return GS_ERR_HIP;
@@ -1518,7 +1524,7 @@ int gs_debug_time_composite(gs_ctx *c, int which, int variant, int reps, float *
         if (e != hipSuccess) return e;
         return which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream);
     };
-    HIPCHK(c, launch());   // warm
+    if (!cold) HIPCHK(c, launch());   // warm
     HIPCHK(c, hipEventRecord(e0, c->stream));
     for (int i = 0; i < reps; ++i) HIPCHK(c, launch());
     HIPCHK(c, hipEventRecord(e1, c->stream));
