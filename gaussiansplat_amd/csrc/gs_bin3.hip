@@ -99,6 +99,18 @@ __device__ __forceinline__ bool lists_overflow(const uint32_t *totals, uint32_t 
     return totals[0] > cap_coarse || totals[1] > cap_fine;
 }
 
+// Chunk of G list positions a level-1 workgroup works on.  Every workgroup touches one table word and one short run of the
+// coarse lists PER SUPER-TILE, and the words / runs of consecutive chunks are neighbours in memory -- but workgroup b runs on
+// XCD b % 8, whose L2 is its own: with chunk = b a 128-byte line was filled a few bytes at a time from eight L2s (C5, 510
+// super-tiles x 9.8 k workgroups: l1_hist fetched 600 MB and wrote 224 MB for 140 MB algorithmic, l1_scatter wrote 422 MB for
+// 120 MB).  So XCD x gets the contiguous chunks [x per, (x + 1) per), in launch order: a line is filled, and re-read, inside ONE
+// L2.  The grid is 8 per blocks; -1 = no chunk (exit before any barrier).  Which workgroup handles a chunk changes no result.
+__device__ __forceinline__ int l1_chunk(const int b, const int nchunks) {
+    const int per = (nchunks + 7) >> 3, j = b >> 3, c = (b & 7) * per + j;
+    return (j < per && c < nchunks) ? c : -1;
+}
+static inline unsigned l1_grid(int nchunks) { return 8u * (unsigned)((nchunks + 7) >> 3); }
+
 // One list position per thread (blockDim = G): sets the position's bits in the LDS bitmap bm[ns][G / 32].
 template <bool FROM_SORTED>
 __device__ __forceinline__ void l1_bitmap(const L1Args &a, uint32_t *bm, int64_t base, uint2 &rr, uint32_t &coarse, uint32_t &fine_slab,
@@ -162,7 +174,9 @@ __global__ __launch_bounds__(1024) void l1_hist_kernel(L1Args a) {
     uint32_t *bm = lds;
     uint32_t *rowcnt = lds + a.ns * (a.G >> 5);
     const int tid = threadIdx.x, wpr = a.G >> 5, nt = blockDim.x;
-    const int64_t base = (int64_t)blockIdx.x * a.G;
+    const int chunk = l1_chunk((int)blockIdx.x, a.nwg_all);
+    if (chunk < 0) return;
+    const int64_t base = (int64_t)chunk * a.G;
     const bool listed = base < a.n_slab;                    // workgroups beyond the slab only add up the frame's instance count
     if (listed) {
         for (int i = tid; i < a.ns * wpr; i += nt) bm[i] = 0;
@@ -176,12 +190,12 @@ __global__ __launch_bounds__(1024) void l1_hist_kernel(L1Args a) {
         __syncthreads();
         l1_row_counts(bm, a.ns, wpr, nullptr, rowcnt);
         __syncthreads();
-        for (int S = tid; S < a.ns; S += nt) a.table[(size_t)S * a.nwg + blockIdx.x] = rowcnt[S];
+        for (int S = tid; S < a.ns; S += nt) a.table[(size_t)S * a.nwg + chunk] = rowcnt[S];
     }
     coarse = block_sum_u32(coarse, sm, nt >> 6);
     fs = block_sum_u32(fs, sm, nt >> 6);
     fa = block_sum_u32(fa, sm, nt >> 6);
-    if (tid == 0) { a.partials[blockIdx.x] = coarse; a.partials[a.nwg_all + blockIdx.x] = fs; a.partials[2 * (size_t)a.nwg_all + blockIdx.x] = fa; }
+    if (tid == 0) { a.partials[chunk] = coarse; a.partials[a.nwg_all + chunk] = fs; a.partials[2 * (size_t)a.nwg_all + chunk] = fa; }
 }
 
 // blocks 0 .. ns-1: exclusive scan of table row S along the workgroups + the row total; blocks ns .. ns+2: the three totals;
@@ -246,12 +260,13 @@ __global__ __launch_bounds__(1024) void l1_scatter_kernel(L1Args a) {
     uint32_t *st_id = lstart + a.ns;                                    // [cap] staged gaussian ids, grouped by super-tile
     uint32_t *st_ls = st_id + cap;                                      // [cap] clipped rectangle | S << 12
     uint16_t *pre = reinterpret_cast<uint16_t *>(st_ls + cap);          // [ns][wpr] set bits of the row below word w
-    const int64_t base = (int64_t)blockIdx.x * a.G;
+    const int chunk = l1_chunk((int)blockIdx.x, a.nwg);
+    const int64_t base = (int64_t)chunk * a.G;
     if (a.zero_words && blockIdx.x == 0 && tid < 32) a.zero_words[tid] = 0;
-    if (lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;     // uniform over the grid
+    if (chunk < 0 || lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;     // uniform over the workgroup
     // issued first, used after the bitmap phase: the list-start operands of the first scan pass (all of them when ns <= G)
     const uint32_t v_first = tid < a.ns ? a.row_total[tid] : 0u;
-    const uint32_t tb_first = tid < a.ns ? a.table[(size_t)tid * a.nwg + blockIdx.x] : 0u;
+    const uint32_t tb_first = tid < a.ns ? a.table[(size_t)tid * a.nwg + chunk] : 0u;
     for (int i = tid; i < a.ns * wpr; i += nt) bm[i] = 0;
     __syncthreads();
     uint2 rr;
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(1024) void l1_scatter_kernel(L1Args a) {
         const int S = b0 + tid;
         const uint32_t lc = S < a.ns ? lstart[S] : 0u;
         uint32_t v = v_first, tb = tb_first;
-        if (b0 > 0) { v = S < a.ns ? a.row_total[S] : 0u; tb = S < a.ns ? a.table[(size_t)S * a.nwg + blockIdx.x] : 0u; }
+        if (b0 > 0) { v = S < a.ns ? a.row_total[S] : 0u; tb = S < a.ns ? a.table[(size_t)S * a.nwg + chunk] : 0u; }
         const uint32_t incl = wave_incl_scan_u32(v, lane), lincl = wave_incl_scan_u32(lc, lane);
         __syncthreads();
         if (lane == 63) { sm[wv] = incl; sm[16 + wv] = lincl; }
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(1024) void l1_scatter_kernel(L1Args a) {
             const uint32_t st = carry + woff + incl - v;
             gstart[S] = st + tb;
             lstart[S] = lcarry + lwoff + lincl - lc;
-            if (blockIdx.x == 0) { a.cranges[2 * S] = st; a.cranges[2 * S + 1] = st + v; }
+            if (chunk == 0) { a.cranges[2 * S] = st; a.cranges[2 * S + 1] = st + v; }
         }
         carry += all; lcarry += lall;
     }
@@ -572,7 +587,7 @@ hipError_t gs_bin3_l1_count(const GsBin3L1 &b, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(l1_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(l1_hist_kernel, dim3(a.nwg_all), dim3(a.G), lds, s, a);
+    hipLaunchKernelGGL(l1_hist_kernel, dim3(l1_grid(a.nwg_all)), dim3(a.G), lds, s, a);
     hipLaunchKernelGGL(l1_rowscan_kernel, dim3(a.ns + 3 + (a.ntiles + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -585,7 +600,7 @@ hipError_t gs_bin3_l1_scatter(const GsBin3L1 &b, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(l1_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(l1_scatter_kernel, dim3(a.nwg), dim3(a.G), lds, s, a);
+    hipLaunchKernelGGL(l1_scatter_kernel, dim3(l1_grid(a.nwg)), dim3(a.G), lds, s, a);
     return hipGetLastError();
 }
 

@@ -51,6 +51,13 @@
 #ifndef GS_BWD3_MINW
 #define GS_BWD3_MINW 5              // __launch_bounds__ waves/SIMD of backward body 3: 96 VGPRs (unconstrained: 104 -> 4 waves)
 #endif
+#ifndef GS_FWD_MINW
+#define GS_FWD_MINW 5               // __launch_bounds__ waves/SIMD of the forward (89 VGPRs)
+#endif
+#ifndef GS_FWD_UNROLL
+#define GS_FWD_UNROLL 2             // entries interleaved in the forward's per-entry loop
+#endif
+constexpr int kFwdUnroll = GS_FWD_UNROLL;
 #include <cstdlib>
 #define CB 64                       // splats staged per batch
 #define NEG_HALF_LOG2E (-0.72134752044448170368f)
@@ -308,7 +315,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             if (base < s1 && pos2 < s1) id2 = a.ids[pos2];
         }
         if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
-#pragma clang loop unroll_count(LEAN ? 1 : 2)
+#pragma clang loop unroll_count(LEAN ? 1 : kFwdUnroll)
         for (int k = 0; k < nk; ++k) {
             const Entry e = load_entry(sp, syhi, k);
             const float dX = fx - e.q0.x;
@@ -999,11 +1006,11 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
 #ifdef GS_EXPERIMENTS
 #define GS_F(E) do { if (a.variant % 10 == 2 && a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 8, true, true>), grid, block, debug_extra_lds(), s, a); \
                      else if (a.variant % 10 == 6 && a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 6, true>), grid, block, debug_extra_lds(), s, a); \
-                     else if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
-                     else hipLaunchKernelGGL((composite_fwd_kernel<E, 5, false>), grid, block, debug_extra_lds(), s, a); } while (0)
+                     else if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, GS_FWD_MINW, true>), grid, block, debug_extra_lds(), s, a); \
+                     else hipLaunchKernelGGL((composite_fwd_kernel<E, GS_FWD_MINW, false>), grid, block, debug_extra_lds(), s, a); } while (0)
 #else
-#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 5, true>), grid, block, debug_extra_lds(), s, a); \
-                     else hipLaunchKernelGGL((composite_fwd_kernel<E, 5, false>), grid, block, debug_extra_lds(), s, a); } while (0)
+#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, GS_FWD_MINW, true>), grid, block, debug_extra_lds(), s, a); \
+                     else hipLaunchKernelGGL((composite_fwd_kernel<E, GS_FWD_MINW, false>), grid, block, debug_extra_lds(), s, a); } while (0)
 #endif
     if (a.tile_pos) {                                                     // a round of a slab frame (t_min > 0 by construction: plan_rounds)
         if (!early || a.tile_clock) return hipErrorInvalidValue;
@@ -1073,8 +1080,8 @@ int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int 
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     CompositeKernel f = nullptr;
     if (which == 0) {
-        f = early ? (cull ? composite_fwd_kernel<true, 5, true> : composite_fwd_kernel<true, 5, false>)
-                  : (cull ? composite_fwd_kernel<false, 5, true> : composite_fwd_kernel<false, 5, false>);
+        f = early ? (cull ? composite_fwd_kernel<true, GS_FWD_MINW, true> : composite_fwd_kernel<true, GS_FWD_MINW, false>)
+                  : (cull ? composite_fwd_kernel<false, GS_FWD_MINW, true> : composite_fwd_kernel<false, GS_FWD_MINW, false>);
     } else {
         const int k = (early ? 4 : 0) | (det ? 2 : 0) | (cull ? 1 : 0);
         switch (k) {
