@@ -41,7 +41,7 @@ class GsConfig(C.Structure):
                 ("deterministic", C.c_int32), ("export_debug", C.c_int32), ("profile_stages", C.c_int32),
                 ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("alpha_cull", C.c_int32), ("schedule", C.c_int32),
                 ("slab_mode", C.c_int32), ("slab_max_ratio", C.c_float), ("slab_fractions", C.c_float * 3), ("debug_flags", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("depth_sort", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class GsGrads(C.Structure):
@@ -136,8 +136,9 @@ class Context:
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
                  profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 1,
                  alpha_cull: bool = True, schedule: int = 0, slab_mode: int = 1, slab_fractions=(), slab_max_ratio: float = 0.0,
-                 debug_flags: int = 0):
-        """schedule 0 = the library default (3); slab_fractions / slab_max_ratio / debug_flags: gs_config fields for tests."""
+                 debug_flags: int = 0, depth_sort: int = 0):
+        """schedule 0 = the library default (3); slab_fractions / slab_max_ratio / debug_flags: gs_config fields for tests;
+        depth_sort 0 automatic, 1 the four-pass radix sort, 2 always key-range buckets + LDS (same permutation)."""
         self.L = load()
         cfg = default_config()
         assert cfg.struct_size == C.sizeof(GsConfig) and cfg.abi_version == GS_ABI_VERSION
@@ -147,6 +148,7 @@ class Context:
         for i, f in enumerate(tuple(slab_fractions)[:3]):
             cfg.slab_fractions[i] = float(f)
         cfg.debug_flags = int(debug_flags)
+        cfg.depth_sort = int(depth_sort)
         cfg.order, cfg.t_min = int(order), float(t_min)
         cfg.export_debug, cfg.profile_stages, cfg.deterministic = int(export_debug), int(profile_stages), int(deterministic)
         cfg.bin_path, cfg.rank_mode, cfg.alpha_cull = int(bin_path), int(rank_mode), int(alpha_cull)

@@ -144,6 +144,13 @@ struct gs_ctx {
     int64_t coarse_listed = 0;               // coarse instances of the current round
     DevBuf rect_sorted, l1_table, l1_rows, l1_partials, cids, clr, cranges, segcnt, sdone, tilecnt;
     uint32_t *bin_totals() { return counters.as<uint32_t>() + 32; }
+    // ---- depth sort in two steps (gs_depth_sort_buckets; gs_config.depth_sort)
+    DevBuf key_range;                        // two frame parities of the key-range accumulators the preprocess kernel fills
+    int range_parity = 0;                    // parity of the frame being built
+    bool range_valid = false;                // the 3-D preprocess of this frame filled key_range[range_parity]
+    bool dsort_buckets_used = false;         // this frame's depth order came from the bucket path (its pinned stat word is live)
+    int64_t dsort_classic_until = 0;         // frame id up to which the classic sort is used (an oversize bucket was reported)
+    uint32_t *dsort_stat() { return pinned + 100 + (range_parity & 1); }
     float *bound_image = nullptr, *bound_trans = nullptr;   // gs_bind_outputs: caller-owned device buffers the forward writes directly
     float *img() { return bound_image ? bound_image : image.as<float>(); }
     float *tr() { return bound_trans ? bound_trans : trans.as<float>(); }
@@ -347,6 +354,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     for (int i = 0; i < 3; ++i)
         if (!(c0.slab_fractions[i] >= 0.0f && c0.slab_fractions[i] < 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_fractions must be in [0, 1)");
     if (c0.debug_flags & ~(GS_DEBUG_WIDE_CURSORS | GS_DEBUG_ALWAYS_ORDER)) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown debug_flags");
+    if (c0.depth_sort < 0 || c0.depth_sort > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: depth_sort must be 0, 1 or 2");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -541,6 +549,7 @@ int gs_preprocess(gs_ctx *c) {
     c->gx = (c->cam.W + GS_TILE - 1) / GS_TILE;
     c->gy = (c->cam.H + GS_TILE - 1) / GS_TILE;
     if (c->kind == 1) {                                  // preprocess(::GaussianRenderer2D), forward.jl:9-33
+        c->range_valid = false;
         GsPreprocess2DArgs a2{};
         a2.n = c->n; a2.W = c->cam.W; a2.H = c->cam.H; a2.gx = c->gx; a2.gy = c->gy;
         a2.means = c->means; a2.scales = c->scales; a2.rots = c->quats; a2.opac = c->opac; a2.colors = c->shs;
@@ -566,6 +575,16 @@ int gs_preprocess(gs_ctx *c) {
     a.invcov = c->invcov.as<float>();
     a.depth_key = c->depth_key.as<uint32_t>();
     a.rect = c->rect.as<uint16_t>();
+    c->range_valid = false;
+    if (c->cfg.depth_sort != 1 && c->order() != GS_ORDER_INDEX && c->n > 0) {
+        if (!c->key_range.p) {
+            HIPCHK(c, c->key_range.ensure(sizeof(uint32_t) * gs_depth_range_words()));
+            HIPCHK(c, gs_depth_range_reset(c->key_range.as<uint32_t>(), c->stream));
+        }
+        c->range_parity ^= 1;
+        a.key_range = c->key_range.as<uint32_t>() + (size_t)c->range_parity * gs_depth_range_parity_words();
+        c->range_valid = true;
+    }
     if (c->cfg.export_debug) {
         const size_t w[7] = {4, 4, 2, 9, 4, 4, 4};
         for (int i = 0; i < 7; ++i) HIPCHK(c, c->dbg[i].ensure(sizeof(float) * w[i] * n1));
@@ -760,12 +779,21 @@ static int bin_round(gs_ctx *c, int r) {
 // the rare frame whose lists outgrew a buffer -- grows the buffers and enqueues the lists again (returns 1: the caller
 // re-enqueues what it had enqueued on top of the empty lists).  The GPU never idles while the host wakes up, and there is no
 // stream synchronisation between gs_preprocess and the end of the frame.
+// The bucket path of the depth sort reported a bucket beyond a workgroup's capacity (it was sorted through global memory: correct,
+// slow): the next 64 frames use the classic sort, then the bucket path is tried again.  Read once the frame's ev_count has passed.
+static void dsort_feedback(gs_ctx *c) {
+    if (!c->dsort_buckets_used) return;
+    c->dsort_buckets_used = false;
+    if (*c->dsort_stat() != 0u && c->cfg.depth_sort != 2) c->dsort_classic_until = c->frame_id + 64;
+}
+
 static int settle_totals(gs_ctx *c, bool *redo, bool may_relist) {
     if (redo) *redo = false;
     if (!c->pending_totals) return GS_OK;
     HIPCHK(c, hipEventSynchronize(c->ev_count));
     c->pending_totals = false;
     harvest_events(c);
+    dsort_feedback(c);
     // pinned + 8: the counter block {walked_f, evaluated_f, walked_b, evaluated_b (u64) ... | byte 128: coarse listed, fine of the slab, fine of all}
     unsigned long long walked_prev = 0;
     std::memcpy(&walked_prev, c->pinned + 8, sizeof(walked_prev));
@@ -812,9 +840,23 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
         HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 4 * 256));
         int in_b = 0;
         perm = c->perm.as<uint32_t>();                  // the last pass writes the permutation itself (low word of the pairs)
-        // (depth | id) pairs are formed by the first pass from the 32-bit keys; the last pass writes only the ids
-        HIPCHK(c, gs_radix_sort_u64(c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, 32, 64, c->table.as<uint32_t>(),
-                                    c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0, perm, c->depth_key.as<uint32_t>()));
+        // Two steps (256 key-range buckets, then one workgroup per bucket in LDS: 4 launches) when this frame's preprocess left the
+        // key range, the mean bucket is well inside a workgroup's capacity, and no oversize bucket was reported lately; else the
+        // classic four LSD passes (12 launches).  Same permutation either way.
+        const bool buckets = c->range_valid && c->cfg.depth_sort != 1 &&
+                             (c->cfg.depth_sort == 2 || (c->n <= gs_depth_buckets_max_n() && c->frame_id > c->dsort_classic_until));
+        c->dsort_buckets_used = buckets;
+        if (buckets) {
+            uint32_t *range = c->key_range.as<uint32_t>() + (size_t)c->range_parity * gs_depth_range_parity_words();
+            uint32_t *other = c->key_range.as<uint32_t>() + (size_t)(c->range_parity ^ 1) * gs_depth_range_parity_words();
+            *c->dsort_stat() = 0u;                      // (no kernel of an earlier frame writes this parity's word any more: two frames back)
+            HIPCHK(c, gs_depth_sort_buckets(c->depth_key.as<uint32_t>(), c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, c->table.as<uint32_t>(),
+                                            c->digit_total.as<uint32_t>(), perm, range, other, c->dsort_stat(), c->stream, c->cfg.rank_mode != 0));
+        } else {
+            // (depth | id) pairs are formed by the first pass from the 32-bit keys; the last pass writes only the ids
+            HIPCHK(c, gs_radix_sort_u64(c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, 32, 64, c->table.as<uint32_t>(),
+                                        c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0, perm, c->depth_key.as<uint32_t>()));
+        }
     }
     c->perm_ptr = perm; c->perm_all = perm;
     int tile_bits = 1;
@@ -885,6 +927,7 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     }
     HIPCHK(c, hipEventSynchronize(c->ev_count));
     harvest_events(c, fast ? GS_STAGE_RANGES : -1);
+    dsort_feedback(c);
     if (c->pinned[0] == 0xFFFFFFFFu)
         return fail(c, GS_ERR_UNSUPPORTED, "gs_bin: more than 2^32 - 2 tile instances (32-bit list offsets); reduce the scene or the image");
     if (c->prev_counters_valid && c->prev_n_inst > 0) {

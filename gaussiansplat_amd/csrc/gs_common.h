@@ -64,7 +64,11 @@ struct GsPreprocessArgs {
     uint32_t *depth_key;
     uint16_t *rect;       // 4 x n : x0 x1 y0 y1 (1-based inclusive, x0 == 0 -> no tile)
     GsDebugArrays dbg;
+    uint32_t *key_range;  // may be null: 64 minima + 64 maxima of the depth keys, GS_KEY_RANGE_STRIDE words apart (every wave folds its
+                          // extremes into slot blockIdx % 64): the key range the two-step depth sort cuts into buckets (gs_sort.hip)
 };
+#define GS_KEY_RANGE_SLOTS 64
+#define GS_KEY_RANGE_STRIDE 64
 // launchers (each enqueues on `stream`, returns hipGetLastError())
 hipError_t gs_launch_preprocess(const GsPreprocessArgs &a, const GsCamera &cam, hipStream_t stream);
 
@@ -102,6 +106,17 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
                              uint32_t *block_hist, uint32_t *digit_total, int *result_in_b,
                              hipStream_t stream, bool ballot_ranks = false, uint32_t *final_low32 = nullptr,
                              const uint32_t *keys32 = nullptr);
+
+// Depth sort in two steps (256 key-range buckets, then one workgroup per bucket inside LDS): four launches instead of twelve.
+// range_acc: this frame's key-range accumulators (GsPreprocessArgs.key_range), reset_acc: the other parity's (re-armed for the
+// next frame); host_stat: coherent pinned word that receives the size of a bucket too large for the fast path (else untouched).
+size_t gs_depth_range_words();
+size_t gs_depth_range_parity_words();
+int64_t gs_depth_buckets_max_n();
+hipError_t gs_depth_range_reset(uint32_t *acc, hipStream_t s);
+hipError_t gs_depth_sort_buckets(const uint32_t *keys32, uint64_t *pairs_a, uint64_t *pairs_b, int64_t n, uint32_t *block_hist,
+                                 uint32_t *digit_total, uint32_t *perm, const uint32_t *range_acc, uint32_t *reset_acc,
+                                 uint32_t *host_stat, hipStream_t stream, bool ballot_ranks);
 
 // checks on the current device that one ds_add_rtn_u32 hands same-address lanes their pre-values in ascending lane order
 hipError_t gs_probe_lds_atomic_order(hipStream_t s, int *mismatches);

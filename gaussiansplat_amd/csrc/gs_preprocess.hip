@@ -238,6 +238,19 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, 
     a.payload[g] = p;
     reinterpret_cast<float4 *>(a.invcov)[g] = make_float4(inv0, inv1, inv2, inv3);
     a.depth_key[g] = key;
+    if (a.key_range) {                                                  // the frame's key range, for the two-step depth sort (gs_sort.hip)
+        uint32_t *lo = a.key_range + (size_t)(blockIdx.x % GS_KEY_RANGE_SLOTS) * GS_KEY_RANGE_STRIDE;
+        uint32_t *hi = lo + (size_t)GS_KEY_RANGE_SLOTS * GS_KEY_RANGE_STRIDE;
+        // keys of non-finite depths (NaN, +-Inf) stay out of the range: ds_bucket clamps them into the end buckets, and a single
+        // one would otherwise stretch the range until every finite key shares a bucket
+        const bool finite = key > 0x007FFFFFu && key < 0xFF800000u;
+        if (__ballot(1) == ~0ull) {                                     // a full wave (every wave but the grid's last) folds first
+            uint32_t mn = finite ? key : 0xFFFFFFFFu, mx = finite ? key : 0u;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, d)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, d)); }
+            if ((threadIdx.x & 63) == 0) { atomicMin(lo, mn); atomicMax(hi, mx); }
+        } else if (finite) { atomicMin(lo, key); atomicMax(hi, key); }
+    }
     reinterpret_cast<uint2 *>(a.rect)[g] = make_uint2((uint32_t)rc[0] | ((uint32_t)rc[1] << 16),
                                                        (uint32_t)rc[2] | ((uint32_t)rc[3] << 16));
     if (a.dbg.ts) {

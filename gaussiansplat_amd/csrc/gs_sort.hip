@@ -30,11 +30,55 @@ size_t gs_sort_table_entries(int64_t n_max) {
 // keys32 != null (first pass of the depth sort): the keys are the 32-bit depth keys themselves; the pair (key << 32 | index)
 // is never stored before the first scatter.  digit_total != null: the 256 digit totals are accumulated here with one atomic
 // per (workgroup, digit) -- for the small tables of the depth sort that saves the separate totals launch.
-template <int NT>
+// ---- depth-bucket digit (gs_depth_sort_buckets): the first pass of the two-step depth sort splits the keys into 256 buckets of
+// equal DEPTH width over the frame's depth range: b = floor((z(key) - zmin) * 256 / (zmax - zmin)), z(key) the float the key
+// encodes (the key is the order-preserving image of +-tps[3]).  fp32 subtraction, multiplication by a positive constant and the
+// float -> int conversion are all monotone, so b is monotone in the key and (bucket, key, id) order == (key, id) order.  (Equal
+// widths in KEY space -- the float's bit pattern -- were tried first: the C3 depths 26 .. 34 straddle an exponent boundary, the
+// far quarter of the depth range got an eighth of the buckets, and its buckets held 7 k of a workgroup's 8 k capacity.)
+// The range arrives in DS_SLOTS minima and DS_SLOTS maxima (the preprocess kernel folds every wave's extremes of the FINITE
+// depths into slot blockIdx % DS_SLOTS; slots DS_STRIDE words apart so that the atomics spread over the memory channels).
+// Keys outside the range (non-finite depths; a stale range) are clamped into the end buckets: correct whatever the range is.
+#define DS_BUCKETS 256
+#define DS_SLOTS GS_KEY_RANGE_SLOTS
+#define DS_STRIDE GS_KEY_RANGE_STRIDE
+struct DsMap { uint32_t kmin, kmax; float zmin, scale; };
+__device__ __forceinline__ float ds_key_value(uint32_t key) {              // inverse of the depth-key map of gs_preprocess.hip
+    return __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+}
+__device__ __forceinline__ DsMap ds_load_map(const uint32_t *__restrict__ acc, uint32_t *sh2) {
+    const int tid = threadIdx.x;                                            // blockDim >= 128
+    if (tid < 2 * DS_SLOTS) {
+        uint32_t v = acc[(size_t)tid * DS_STRIDE];
+#pragma unroll
+        for (int d = GS_WAVE / 2; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = tid < DS_SLOTS ? min(v, o) : max(v, o); }
+        if ((tid & 63) == 0) sh2[tid >> 6] = v;
+    }
+    __syncthreads();
+    DsMap m;
+    const uint32_t lo = sh2[0], hi = sh2[1];
+    m.kmin = lo <= hi ? lo : 0u;                                            // (no finite key at all: everything goes to bucket 0)
+    m.kmax = lo <= hi ? hi : 0u;
+    m.zmin = ds_key_value(m.kmin);
+    const float span = ds_key_value(m.kmax) - m.zmin;                       // may overflow to +Inf: scale 0, one bucket
+    m.scale = (span > 0.0f && span < 3.0e38f) ? 255.99f / span : 0.0f;
+    return m;
+}
+__device__ __forceinline__ uint32_t ds_bucket(const DsMap &m, uint32_t key) {
+    if (key <= m.kmin) return 0u;
+    if (key >= m.kmax) return DS_BUCKETS - 1;
+    const float t = (ds_key_value(key) - m.zmin) * m.scale;                 // >= 0: kmin < key < kmax
+    return min((uint32_t)t, (uint32_t)(DS_BUCKETS - 1));
+}
+
+template <int NT, bool BUCKETS = false>
 __global__ __launch_bounds__(NT) void rs_hist_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ keys32, int64_t n,
                                                       int shift, uint32_t mask, uint32_t *__restrict__ block_hist, int nblocks,
-                                                      uint32_t *__restrict__ digit_total) {
+                                                      uint32_t *__restrict__ digit_total, const uint32_t *__restrict__ range_acc = nullptr) {
     __shared__ uint32_t h[RS_RADIX];
+    __shared__ uint32_t sh2[2];
+    DsMap map{};
+    if (BUCKETS) map = ds_load_map(range_acc, sh2);
     if (threadIdx.x < RS_RADIX) h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
@@ -42,7 +86,8 @@ __global__ __launch_bounds__(NT) void rs_hist_kernel(const uint64_t *__restrict_
     for (int i = 0; i < RS_CHUNK / NT; ++i) {
         const int64_t idx = base + (int64_t)i * NT + threadIdx.x;
         if (idx < n) {
-            const uint32_t dg = keys32 ? ((keys32[idx] >> (shift - 32)) & mask) : ((uint32_t)(keys[idx] >> shift) & mask);
+            const uint32_t dg = BUCKETS ? ds_bucket(map, keys32[idx])
+                                        : keys32 ? ((keys32[idx] >> (shift - 32)) & mask) : ((uint32_t)(keys[idx] >> shift) & mask);
             atomicAdd(&h[dg], 1u);
         }
     }
@@ -136,18 +181,23 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
 // out32 != null (last pass of a (key | id) pair sort): only the low word -- the id -- is written, as 32 bits.
 // NT threads per 4096-key chunk: 256 (sixteen rounds per wave) for the big instance sorts, 1024 (four rounds, sixteen waves)
 // for the depth sort, whose 244 workgroups at 1 M gaussians would otherwise leave one wave per SIMD to hide every latency.
-template <int NT, bool ATOMIC_RANK>
+template <int NT, bool ATOMIC_RANK, bool BUCKETS = false>
 __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ in32,
                                                          uint64_t *__restrict__ out,
                                                          int64_t n, int shift, uint32_t mask,
                                                          const uint32_t *__restrict__ block_hist, int nblocks,
-                                                         uint32_t *__restrict__ out32, const uint32_t *__restrict__ row_total) {
+                                                         uint32_t *__restrict__ out32, const uint32_t *__restrict__ row_total,
+                                                         const uint32_t *__restrict__ range_acc = nullptr) {
     constexpr int NW = NT / GS_WAVE, ITEMS = RS_CHUNK / NT;
     __shared__ uint64_t skeys[RS_CHUNK];                 // 32 KiB
     __shared__ uint32_t wcnt[NW][RS_RADIX];              // running count per (wave, digit)
     __shared__ uint32_t lpre[RS_RADIX];                  // exclusive prefix over digits in this chunk
     __shared__ uint32_t gbase[RS_RADIX];
     __shared__ uint32_t sm[RS_RADIX / GS_WAVE];
+    __shared__ uint32_t sh2[2];
+    DsMap map{};
+    if (BUCKETS) map = ds_load_map(range_acc, sh2);
+    auto digit_of = [&](uint64_t k) -> uint32_t { return BUCKETS ? ds_bucket(map, (uint32_t)(k >> 32)) : ((uint32_t)(k >> shift) & mask); };
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
     const int64_t remain = n - base;
@@ -180,7 +230,7 @@ __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restri
     for (int r = 0; r < ITEMS; ++r) {
         const int li = w * (GS_WAVE * ITEMS) + r * GS_WAVE + lane;
         const bool valid = li < cnt;
-        const uint32_t dg = valid ? ((uint32_t)(key[r] >> shift) & mask) : (RS_RADIX - 1);
+        const uint32_t dg = valid ? digit_of(key[r]) : (RS_RADIX - 1);
         if (ATOMIC_RANK) {                                              // see gs_bin2.hip rank_round_atomic
             rank[r] = 0;
             if (valid) rank[r] = atomicAdd(&wcnt[w][dg], 1u);
@@ -218,7 +268,7 @@ __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restri
     for (int r = 0; r < ITEMS; ++r) {
         const int li = w * (GS_WAVE * ITEMS) + r * GS_WAVE + lane;
         if (li < cnt) {
-            const uint32_t dg = (uint32_t)(key[r] >> shift) & mask;
+            const uint32_t dg = digit_of(key[r]);
             skeys[lpre[dg] + wcnt[w][dg] + rank[r]] = key[r];
         }
     }
@@ -228,7 +278,7 @@ __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restri
         const int li = r * NT + tid;
         if (li < cnt) {
             const uint64_t k = skeys[li];
-            const uint32_t dg = (uint32_t)(k >> shift) & mask;
+            const uint32_t dg = digit_of(k);
             const size_t o = (size_t)gbase[dg] + (uint32_t)(li - (int)lpre[dg]);
             if (out32) out32[o] = (uint32_t)k; else out[o] = k;
         }
@@ -321,6 +371,245 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
         uint64_t *t = src; src = dst; dst = t;
         *result_in_b ^= 1;
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- depth sort in two steps: 256 key-range buckets, then LDS
+// Replaces the twelve dependent launches of the four-pass LSD sort of the (depth | id) pairs (CUDA.sortperm, src/forward.jl:103)
+// by four: histogram, scan and stable scatter of ONE pass whose digit is the key's bucket (ds_bucket: 256 buckets of equal key
+// width over the frame's key range), then ds_local_kernel: one workgroup per bucket finishes the order inside LDS.  A bucket's
+// elements arrive in index order (the scatter is stable), so a stable LSD sort on (key - the bucket's smallest key) -- as many
+// 8-bit digits as the bucket's key spread needs: two at C3 -- gives (key, id) order.  Same permutation as the classic path, bit
+// for bit (tests/test_gpu_dsort.py).  A bucket that does not fit the registers of its workgroup (8192 elements: a pathological
+// depth distribution, e.g. a wall of gaussians at one depth plus an outlier) is sorted by the same workgroup through global
+// memory, chunk by chunk (slow but correct), and reported to the host (host_stat), which returns to the classic path.
+#define DS_ITEMS 8
+#define DS_CAP_OF(NT) ((NT) * DS_ITEMS)
+
+// Element `li` of the (at most NT * 8) elements a workgroup holds in registers: wave w owns the `per` consecutive elements from
+// w * per on, round r of the wave the 64 from r * 64 on (per = a multiple of 64 sized to the element count, so that every wave
+// has work and a short bucket costs few rounds).  (wave, round, lane) ascending == li ascending: the stable order.
+#define DS_LI(w, r, lane, per) ((w) * (per) + (r) * GS_WAVE + (lane))
+
+// One stable counting-sort step on digit (sub >> shift) & 255 of the elements held in registers (valid if li < cnt; `rounds`
+// rounds per wave): afterwards skey / sid hold them digit-contiguously, lpre[d] is the first slot of digit d and ltot[d] their
+// number.  Ranks from wave ballots (as rs_scatter_kernel).
+template <int NT>
+__device__ __forceinline__ void ds_stage(const uint32_t (&sub)[DS_ITEMS], const uint32_t (&id)[DS_ITEMS], const int cnt, const int per, const int rounds,
+                                         const int shift, uint32_t *skey, uint32_t *sid, uint32_t (*wcnt)[RS_RADIX], uint32_t *lpre, uint32_t *ltot,
+                                         uint32_t *sm) {
+    constexpr int NW = NT / GS_WAVE;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < NW * RS_RADIX; i += NT) (&wcnt[0][0])[i] = 0;
+    __syncthreads();                                                    // (also: every reader of skey / sid of the previous step is done)
+    uint32_t rank[DS_ITEMS];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < DS_ITEMS; ++r) {
+        rank[r] = 0;
+        if (r < rounds && DS_LI(w, r, 0, per) < cnt) {                  // wave-uniform
+            const int li = DS_LI(w, r, lane, per);
+            const bool valid = li < cnt;
+            const uint32_t dg = valid ? ((sub[r] >> shift) & 255u) : 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long bal = __ballot((dg >> b) & 1u);
+                peers &= ((dg >> b) & 1u) ? bal : ~bal;
+            }
+            const uint32_t before = wcnt[w][dg];
+            rank[r] = before + (uint32_t)__popcll(peers & lt_mask);
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (peers & lt_mask) == 0ull) wcnt[w][dg] = before + (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    uint32_t tot = 0;
+    if (tid < RS_RADIX) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { const uint32_t c = wcnt[k][tid]; wcnt[k][tid] = tot; tot += c; }
+    }
+    const uint32_t incl = wave_incl_scan(tot, lane);
+    if (tid < RS_RADIX && lane == 63) sm[w] = incl;
+    __syncthreads();
+    if (tid < RS_RADIX) {
+        uint32_t woff = 0;
+        for (int k = 0; k < w; ++k) woff += sm[k];
+        lpre[tid] = woff + incl - tot;
+        ltot[tid] = tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < DS_ITEMS; ++r) {
+        const int li = DS_LI(w, r, lane, per);
+        if (r < rounds && li < cnt) {
+            const uint32_t dg = (sub[r] >> shift) & 255u;
+            const uint32_t o = lpre[dg] + wcnt[w][dg] + rank[r];
+            skey[o] = sub[r]; sid[o] = id[r];
+        }
+    }
+    __syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ void ds_block_minmax(uint32_t &mn, uint32_t &mx, uint32_t *sm) {     // sm: 2 * NW words
+    constexpr int NW = NT / GS_WAVE;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = GS_WAVE / 2; d > 0; d >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, d)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, d)); }
+    __syncthreads();
+    if (lane == 0) { sm[w] = mn; sm[NW + w] = mx; }
+    __syncthreads();
+    mn = sm[0]; mx = sm[NW];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) { mn = min(mn, sm[k]); mx = max(mx, sm[NW + k]); }
+    __syncthreads();
+}
+
+// pairs: the bucket-ordered (key << 32 | id) pairs; scratch: as many words again (only touched by oversize buckets);
+// bucket_total: the 256 bucket sizes (row totals of the scan); reset_acc: the range accumulators of the OTHER frame parity,
+// re-armed here for the next preprocess (nothing reads them during this frame); host_stat: coherent pinned word, receives the
+// size of an oversize bucket (the host zeroes it before the launch).  NT: 1024 threads (buckets of up to 8192), 256 for small
+// models (2048: the same four waves do everything, fewer to synchronise).
+template <int NT>
+__global__ __launch_bounds__(NT) void ds_local_kernel(uint64_t *__restrict__ pairs, uint64_t *__restrict__ scratch,
+                                                       const uint32_t *__restrict__ bucket_total, uint32_t *__restrict__ perm,
+                                                       uint32_t *__restrict__ reset_acc, uint32_t *__restrict__ host_stat) {
+    constexpr int NW = NT / GS_WAVE, CAP = DS_CAP_OF(NT);
+    __shared__ uint32_t skey[CAP];
+    __shared__ uint32_t sid[CAP];
+    __shared__ uint32_t wcnt[NW][RS_RADIX];
+    __shared__ uint32_t lpre[RS_RADIX], ltot[RS_RADIX], gbase[RS_RADIX];
+    __shared__ uint32_t sm[2 * NW + 16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
+    if (b == 0 && reset_acc) for (int i = tid; i < 2 * DS_SLOTS; i += NT) reset_acc[(size_t)i * DS_STRIDE] = i < DS_SLOTS ? 0xFFFFFFFFu : 0u;
+    // my bucket: [start, start + cnt) = exclusive prefix of the 256 totals (thread t < 256 holds total t)
+    uint32_t start = 0, cnt = 0;
+    {
+        const uint32_t t = tid < RS_RADIX ? bucket_total[tid] : 0u;
+        const uint32_t incl = wave_incl_scan(t, lane);
+        if (tid < RS_RADIX && lane == 63) sm[w] = incl;
+        __syncthreads();
+        if (tid == b) { uint32_t woff = 0; for (int k = 0; k < w; ++k) woff += sm[k]; sm[8] = woff + incl - t; sm[9] = t; }
+        __syncthreads();
+        start = sm[8]; cnt = sm[9];
+        __syncthreads();
+    }
+    if (cnt == 0) return;
+    uint32_t sub[DS_ITEMS], id[DS_ITEMS];
+    if (cnt <= (uint32_t)CAP) {
+        // ---- the bucket lives in registers / LDS from here to the final store
+        const int per = (int)((cnt + NT - 1) / NT) * GS_WAVE, rounds = per / GS_WAVE;
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+        for (int r = 0; r < DS_ITEMS; ++r) {
+            const int li = DS_LI(w, r, lane, per);
+            sub[r] = 0; id[r] = 0;
+            if (r < rounds && li < (int)cnt) { const uint64_t p = pairs[(size_t)start + li]; sub[r] = (uint32_t)(p >> 32); id[r] = (uint32_t)p; mn = min(mn, sub[r]); mx = max(mx, sub[r]); }
+        }
+        ds_block_minmax<NT>(mn, mx, sm);
+        const uint32_t spread = mx - mn;
+        const int bits = spread ? 32 - __builtin_clz(spread) : 0, passes = (bits + 7) >> 3;
+        if (passes == 0) {                                              // one key value: index order is the order
+#pragma unroll
+            for (int r = 0; r < DS_ITEMS; ++r) { const int li = DS_LI(w, r, lane, per); if (r < rounds && li < (int)cnt) perm[(size_t)start + li] = id[r]; }
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < DS_ITEMS; ++r) sub[r] -= mn;
+        for (int p = 0; p < passes; ++p) {
+            ds_stage<NT>(sub, id, (int)cnt, per, rounds, 8 * p, skey, sid, wcnt, lpre, ltot, sm);
+            if (p + 1 < passes) {
+#pragma unroll
+                for (int r = 0; r < DS_ITEMS; ++r) {
+                    const int li = DS_LI(w, r, lane, per);
+                    if (r < rounds && li < (int)cnt) { sub[r] = skey[li]; id[r] = sid[li]; }
+                }
+            }
+        }
+        for (int li = tid; li < (int)cnt; li += NT) perm[(size_t)start + li] = sid[li];
+        return;
+    }
+    // ---- oversize bucket: LSD passes through global memory, CAP elements at a time (pairs <-> scratch)
+    if (tid == 0 && host_stat) *host_stat = cnt;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    for (uint32_t i = tid; i < cnt; i += NT) { const uint32_t k = (uint32_t)(pairs[(size_t)start + i] >> 32); mn = min(mn, k); mx = max(mx, k); }
+    ds_block_minmax<NT>(mn, mx, sm);
+    const uint32_t spread = mx - mn;
+    const int bits = spread ? 32 - __builtin_clz(spread) : 0, passes = (bits + 7) >> 3;
+    if (passes == 0) {
+        for (uint32_t i = tid; i < cnt; i += NT) perm[(size_t)start + i] = (uint32_t)pairs[(size_t)start + i];
+        return;
+    }
+    uint64_t *src = pairs + start, *dst = scratch + start;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        if (tid < RS_RADIX) gbase[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += NT) atomicAdd(&gbase[(((uint32_t)(src[i] >> 32) - mn) >> shift) & 255u], 1u);
+        __syncthreads();
+        {                                                               // exclusive prefix over the digits
+            const uint32_t t = tid < RS_RADIX ? gbase[tid] : 0u;
+            const uint32_t incl = wave_incl_scan(t, lane);
+            if (tid < RS_RADIX && lane == 63) sm[w] = incl;
+            __syncthreads();
+            if (tid < RS_RADIX) { uint32_t woff = 0; for (int k = 0; k < w; ++k) woff += sm[k]; gbase[tid] = woff + incl - t; }
+            __syncthreads();
+        }
+        for (uint32_t c0 = 0; c0 < cnt; c0 += CAP) {
+            const int nc = (int)min((uint32_t)CAP, cnt - c0);
+            const int per = ((nc + NT - 1) / NT) * GS_WAVE, rounds = per / GS_WAVE;
+#pragma unroll
+            for (int r = 0; r < DS_ITEMS; ++r) {
+                const int li = DS_LI(w, r, lane, per);
+                sub[r] = 0; id[r] = 0;
+                if (r < rounds && li < nc) { const uint64_t pr = src[(size_t)c0 + li]; sub[r] = (uint32_t)(pr >> 32) - mn; id[r] = (uint32_t)pr; }
+            }
+            ds_stage<NT>(sub, id, nc, per, rounds, shift, skey, sid, wcnt, lpre, ltot, sm);
+            for (int li = tid; li < nc; li += NT) {
+                const uint32_t k = skey[li], dg = (k >> shift) & 255u;
+                const size_t o = (size_t)gbase[dg] + (uint32_t)(li - (int)lpre[dg]);
+                if (p + 1 < passes) dst[o] = ((uint64_t)(k + mn) << 32) | sid[li];
+                else perm[(size_t)start + o] = sid[li];
+            }
+            __syncthreads();
+            if (tid < RS_RADIX) gbase[tid] += ltot[tid];
+            __syncthreads();
+        }
+        uint64_t *t = src; src = dst; dst = t;
+    }
+}
+
+__global__ void ds_reset_range_kernel(uint32_t *__restrict__ acc, int nparity) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nparity * 2 * DS_SLOTS) acc[(size_t)i * DS_STRIDE] = (i % (2 * DS_SLOTS)) < DS_SLOTS ? 0xFFFFFFFFu : 0u;
+}
+size_t gs_depth_range_words() { return (size_t)2 * 2 * DS_SLOTS * DS_STRIDE; }           // two frame parities
+size_t gs_depth_range_parity_words() { return (size_t)2 * DS_SLOTS * DS_STRIDE; }
+int64_t gs_depth_buckets_max_n() { return (int64_t)DS_BUCKETS * DS_CAP_OF(1024) * 5 / 8; } // mean bucket at 5/8 of the capacity
+hipError_t gs_depth_range_reset(uint32_t *acc, hipStream_t s) {
+    hipLaunchKernelGGL(ds_reset_range_kernel, dim3(1), dim3(256), 0, s, acc, 2);
+    return hipGetLastError();
+}
+
+// perm = ids in (key, id) order of the n 32-bit keys.  pairs_a / pairs_b: n words each of 64 bits; table / digit_total as for
+// gs_radix_sort_u64; range_acc: this frame's key-range accumulators (filled by the preprocess kernel), reset_acc: the other parity's.
+hipError_t gs_depth_sort_buckets(const uint32_t *keys32, uint64_t *pairs_a, uint64_t *pairs_b, int64_t n, uint32_t *block_hist,
+                                 uint32_t *digit_total, uint32_t *perm, const uint32_t *range_acc, uint32_t *reset_acc,
+                                 uint32_t *host_stat, hipStream_t stream, bool ballot_ranks) {
+    if (n <= 0) return hipSuccess;
+    const int nblocks = (int)((n + RS_CHUNK - 1) / RS_CHUNK);
+    hipLaunchKernelGGL((rs_hist_kernel<1024, true>), dim3(nblocks), dim3(1024), 0, stream, (const uint64_t *)nullptr, keys32, n, 0, 0u, block_hist, nblocks,
+                       (uint32_t *)nullptr, range_acc);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, stream, block_hist, nblocks, (const uint32_t *)nullptr, digit_total);
+    if (ballot_ranks) hipLaunchKernelGGL((rs_scatter_kernel<1024, false, true>), dim3(nblocks), dim3(1024), 0, stream, (const uint64_t *)nullptr, keys32, pairs_b, n, 0, 0u,
+                                         block_hist, nblocks, (uint32_t *)nullptr, digit_total, range_acc);
+    else hipLaunchKernelGGL((rs_scatter_kernel<1024, true, true>), dim3(nblocks), dim3(1024), 0, stream, (const uint64_t *)nullptr, keys32, pairs_b, n, 0, 0u,
+                            block_hist, nblocks, (uint32_t *)nullptr, digit_total, range_acc);
+    // small models: four waves per bucket (capacity 2048: eight times the mean bucket at 64 K gaussians)
+    if (n <= 65536) hipLaunchKernelGGL(ds_local_kernel<256>, dim3(DS_BUCKETS), dim3(256), 0, stream, pairs_b, pairs_a, digit_total, perm, reset_acc, host_stat);
+    else hipLaunchKernelGGL(ds_local_kernel<1024>, dim3(DS_BUCKETS), dim3(1024), 0, stream, pairs_b, pairs_a, digit_total, perm, reset_acc, host_stat);
     return hipGetLastError();
 }
 

@@ -37,7 +37,8 @@ mutable struct GsConfig                      # must mirror gs_config (96 bytes)
     slab_max_ratio::Float32
     slab_fractions::NTuple{3, Float32}
     debug_flags::Int32
-    reserved::NTuple{6, Int32}
+    depth_sort::Int32
+    reserved::NTuple{5, Int32}
 end
 
 struct GsGrads                               # gs_grads: device pointers, may be C_NULL
@@ -63,7 +64,7 @@ function check(r::HipRenderer, rc::Cint)
 end
 
 function defaultConfig()
-    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, ntuple(_ -> Int32(0), 6))
+    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, 0, ntuple(_ -> Int32(0), 5))
     ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
     # a library built from another header would read this struct with shifted fields: refuse it here, loudly
     (hip_abiVersion() == GS_ABI_VERSION && cfg.abi_version == GS_ABI_VERSION && cfg.struct_size == sizeof(GsConfig)) ||
