@@ -144,6 +144,11 @@ struct gs_ctx {
     int64_t coarse_listed = 0;               // coarse instances of the current round
     DevBuf rect_sorted, l1_table, l1_rows, l1_partials, cids, clr, cranges, segcnt, sdone, tilecnt;
     uint32_t *bin_totals() { return counters.as<uint32_t>() + 32; }
+    // ---- per-tile work counters of the composite launches (walked / evaluated list entries): counters[0..3] hold their sums only
+    // after sum_work_counters() (gs_get_work_counters, the radix binning paths); the two-level path sums the walked counts of the
+    // previous forward inside l1_rowscan on their way to the host
+    DevBuf tile_walked, tile_walked_b, tile_work_b;
+    int64_t counters_grid = 0;               // the grid (gx << 32 | gy) the forward's per-tile counters were written for
     // ---- depth sort in two steps (gs_depth_sort_buckets; gs_config.depth_sort)
     DevBuf key_range;                        // two frame parities of the key-range accumulators the preprocess kernel fills
     int range_parity = 0;                    // parity of the frame being built
@@ -408,7 +413,7 @@ int gs_destroy(gs_ctx *c) {
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
                       &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->tilecnt,
                       &c->ranges_r[0], &c->ranges_r[1], &c->ranges_r[2], &c->ranges_r[3],
-                      &c->invcov, &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams, &c->tile_dead};
+                      &c->invcov, &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams, &c->tile_dead, &c->key_range, &c->tile_walked, &c->tile_walked_b, &c->tile_work_b};
     for (DevBuf *b : bufs) b->release();
     for (auto &b : c->slot_order) { b[0].release(); b[1].release(); }
     for (auto &b : c->model) b.release();
@@ -672,6 +677,10 @@ static int two_level_count(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, 
     GsBin3L1 b = two_level_args(c, perm_slab, n_all, nr, sdone, 0, 0);
     if (to_host) {                                                          // the layout settle_totals reads: counter block at pinned + 8
         b.host_totals = c->pinned + 8 + 32; b.host_walked = c->pinned + 8; b.walked_src = c->counters.as<uint32_t>();
+        // the previous forward's walked entries, per tile (valid only if that forward ran on this grid: prev_counters_valid)
+        const bool same_grid = c->counters_grid == (((int64_t)c->gx << 32) | (int64_t)c->gy) && c->tile_walked.p;
+        if (!same_grid) c->prev_counters_valid = false;
+        b.tile_walked = c->prev_counters_valid ? c->tile_walked.as<uint32_t>() : nullptr; b.n_tile_walked = c->gx * c->gy;
     }
     HIPCHK(c, gs_bin3_l1_count(b, c->stream));
     return GS_OK;
@@ -917,7 +926,11 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     // ranges) is enqueued BEFORE the host waits, so the GPU stays busy while the host wakes up and launches the instance passes.
     HIPCHK(c, hipMemcpyAsync(c->pinned, c->offsets.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->pinned + 1, c->offsets.as<uint32_t>() + n0, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    if (c->prev_counters_valid) HIPCHK(c, hipMemcpyAsync(c->pinned + 2, c->counters.p, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->prev_counters_valid && c->counters_grid != (((int64_t)c->gx << 32) | (int64_t)c->gy)) c->prev_counters_valid = false;
+    if (c->prev_counters_valid) {
+        HIPCHK(c, gs_launch_sum_tiles(c->tile_walked.as<uint32_t>(), c->tile_work.as<uint32_t>(), c->gx * c->gy, c->counters.as<unsigned long long>(), c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->pinned + 2, c->counters.p, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
     if (fast) {
         HIPCHK(c, c->diff.ensure(sizeof(int) * gs_tile_ranges_scratch_ints(c->gx, c->gy)));
@@ -1006,10 +1019,10 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.ranges = r == 0 ? c->ranges.as<uint32_t>() : c->ranges_r[r].as<uint32_t>();
     a.ids = c->ids.as<uint32_t>() + c->round_ids_off[r]; a.payload = c->payload.as<GsPayload>();
     a.image = c->img(); a.trans = c->tr();
-    a.walked = c->counters.as<unsigned long long>();
+    a.walked = nullptr;                                                     // per tile: tile_walked / tile_work (GsCompositeArgs.walked)
     a.variant = c->variant_fwd; a.cull = c->cfg.alpha_cull != 0;
     a.resume = r > 0; a.final_round = r == R - 1;
-    a.tile_work = c->tile_work.as<uint32_t>();
+    a.tile_work = c->tile_work.as<uint32_t>(); a.tile_walked = c->tile_walked.as<uint32_t>();
     a.tile_order = order; a.order_len = order ? gs_lpt_order_len(c->gx, c->gy) : 0;
     a.zero_words = c->counters.as<unsigned long long>() + 2;               // the backward's work counters (walked, evaluated)
     if (R > 1) { a.tile_pos = c->tile_pos.as<uint32_t>(); a.tile_done = c->tile_done.as<uint8_t>(); a.tile_dead = c->tile_dead.as<unsigned long long>(); }
@@ -1037,6 +1050,8 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     }
     HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
     HIPCHK(c, c->tile_work.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
+    HIPCHK(c, c->tile_walked.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
+    c->counters_grid = ((int64_t)c->gx << 32) | (int64_t)c->gy;
     if (!c->counters_zeroed) HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 128, c->stream));   // work counters + both sets of ticket counters
     c->counters_zeroed = false;
     const int R = c->n_rounds;
@@ -1125,7 +1140,13 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         ++a.nseg;
     }
     a.dC = dC_dev; a.g2d = det ? nullptr : c->g2d.as<float>(); a.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
-    a.walked = c->counters.as<unsigned long long>() + 2;
+    {
+        const size_t nt = (size_t)c->gx * c->gy;
+        HIPCHK(c, c->tile_walked_b.ensure(sizeof(uint32_t) * (nt ? nt : 1)));
+        HIPCHK(c, c->tile_work_b.ensure(sizeof(uint32_t) * (nt ? nt : 1)));
+    }
+    a.walked = nullptr; a.tile_walked = c->tile_walked_b.as<uint32_t>(); a.tile_work = c->tile_work_b.as<uint32_t>();
+    unsigned long long *bwd_words = c->counters.as<unsigned long long>() + 2;  // (reduced sums: sum_work_counters)
     a.variant = c->variant_bwd; a.cull = c->cfg.alpha_cull != 0;
     if (!params_only) {
         c->last_dC = dC_dev;
@@ -1135,7 +1156,7 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
         // launch order: the one the frame's forward used, or (no history) what the order kernel made of that forward
         if (lpt_schedule(c)) { a.tile_order = c->frame_order; a.order_len = c->frame_order ? gs_lpt_order_len(c->gx, c->gy) : 0; }
-        if (!c->bwd_counters_zeroed) HIPCHK(c, hipMemsetAsync(a.walked, 0, 16, c->stream));     // the backward's work counters
+        if (!c->bwd_counters_zeroed) HIPCHK(c, hipMemsetAsync(bwd_words, 0, 16, c->stream));    // the backward's work counters
         c->bwd_counters_zeroed = false;
 #ifdef GS_EXPERIMENTS
         HIPCHK(c, hipMemsetAsync(static_cast<char *>(c->counters.p) + 64, 0, 32, c->stream));   // the backward's ticket counters (schedules 10 / 12)
@@ -1601,11 +1622,23 @@ int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
 
 int gs_rank_probe_result(const gs_ctx *c) { return c ? c->rank_probe : -1; }
 
+// counters[0..3] = {walked, evaluated} of the last forward and of the last composite backward, summed from the per-tile arrays
+static int sum_work_counters(gs_ctx *c) {
+    unsigned long long *w = c->counters.as<unsigned long long>();
+    const int nt = c->gx * c->gy;
+    HIPCHK(c, gs_launch_sum_tiles(c->tile_walked.as<uint32_t>(), c->tile_work.as<uint32_t>(), nt, w, c->stream));
+    if (c->did_bwd_composite && c->tile_walked_b.p && c->tile_work_b.p)
+        HIPCHK(c, gs_launch_sum_tiles(c->tile_walked_b.as<uint32_t>(), c->tile_work_b.as<uint32_t>(), nt, w + 2, c->stream));
+    else HIPCHK(c, hipMemsetAsync(w + 2, 0, 16, c->stream));
+    return GS_OK;
+}
+
 int gs_get_work_counters(gs_ctx *c, int64_t *walked_fwd, int64_t *walked_bwd) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_work_counters: gs_forward first");
     if (bind_device(c)) return GS_ERR_HIP;
     unsigned long long h[4] = {0, 0, 0, 0};
+    if (int rc = sum_work_counters(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(h, c->counters.p, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (walked_fwd) *walked_fwd = (int64_t)h[0];
@@ -1618,6 +1651,7 @@ int gs_get_work_counters_ex(gs_ctx *c, int64_t out[4]) {
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_work_counters_ex: gs_forward first");
     if (bind_device(c)) return GS_ERR_HIP;
     unsigned long long h[4] = {0, 0, 0, 0};
+    if (int rc = sum_work_counters(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(h, c->counters.p, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     out[0] = (int64_t)h[0]; out[1] = (int64_t)h[2]; out[2] = (int64_t)h[1]; out[3] = (int64_t)h[3];

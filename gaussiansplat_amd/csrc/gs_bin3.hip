@@ -92,6 +92,8 @@ struct L1Args {
                                  // them writes no list at all (every range empty) and the host redoes it with larger buffers
     uint32_t *host_totals, *host_walked;   // coherent pinned host memory (may be null): the totals and the two words at walked_src, stored
     const uint32_t *walked_src;            // by l1_rowscan itself -- a copy command in the stream is a blit kernel of 4 us plus its gaps
+    const uint32_t *tile_walked;           // != null: host_walked receives the 64-bit SUM of these n_tile_walked per-tile counts (the previous
+    int n_tile_walked;                     // forward's walked list entries) instead of the two words at walked_src
 };
 // The lists are enqueued BEFORE the host has seen the frame's totals (speculative launch, gs_api.hip): every kernel that
 // writes them checks the totals against the capacities of the buffers it was given.
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(1024) void l1_hist_kernel(L1Args a) {
 // further blocks: zero the per-tile hit counters of the level-2 count pass
 __global__ __launch_bounds__(256) void l1_rowscan_kernel(L1Args a) {
     __shared__ uint32_t sm[4];
-    __shared__ unsigned long long wide[4];
+    __shared__ unsigned long long wide[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if ((int)blockIdx.x >= a.ns + 3) {
         const int i = ((int)blockIdx.x - a.ns - 3) * 256 + tid;
@@ -212,11 +214,18 @@ __global__ __launch_bounds__(256) void l1_rowscan_kernel(L1Args a) {
     if ((int)blockIdx.x >= a.ns) {
         const int which = (int)blockIdx.x - a.ns;
         const uint32_t *p = a.partials + (size_t)which * a.nwg_all;
-        unsigned long long t = 0;
+        unsigned long long t = 0, wk = 0;
         for (int i = tid; i < a.nwg_all; i += 256) t += p[i];
+        if (which == 0 && a.host_walked && a.tile_walked) {                 // 16-byte loads, four in flight per thread: this block must not
+            const uint4 *v4 = reinterpret_cast<const uint4 *>(a.tile_walked);  // become the kernel's critical path on 4K-class grids
+            const int n4 = a.n_tile_walked >> 2;
+#pragma unroll 4
+            for (int i = tid; i < n4; i += 256) { const uint4 v = v4[i]; wk += (unsigned long long)v.x + v.y + v.z + v.w; }
+            for (int i = 4 * n4 + tid; i < a.n_tile_walked; i += 256) wk += a.tile_walked[i];
+        }
 #pragma unroll
-        for (int d = GS_WAVE / 2; d > 0; d >>= 1) t += __shfl_down(t, d);
-        if (lane == 0) wide[wv] = t;
+        for (int d = GS_WAVE / 2; d > 0; d >>= 1) { t += __shfl_down(t, d); wk += __shfl_down(wk, d); }
+        if (lane == 0) { wide[wv] = t; wide[4 + wv] = wk; }
         __syncthreads();
         if (tid == 0) {
             const unsigned long long tot = wide[0] + wide[1] + wide[2] + wide[3];
@@ -224,7 +233,12 @@ __global__ __launch_bounds__(256) void l1_rowscan_kernel(L1Args a) {
             a.totals[which] = t32;
             if (a.host_totals) {
                 a.host_totals[which] = t32;
-                if (which == 0 && a.host_walked) { a.host_walked[0] = a.walked_src[0]; a.host_walked[1] = a.walked_src[1]; }
+                if (which == 0 && a.host_walked) {
+                    if (a.tile_walked) {
+                        const unsigned long long w = wide[4] + wide[5] + wide[6] + wide[7];
+                        a.host_walked[0] = (uint32_t)w; a.host_walked[1] = (uint32_t)(w >> 32);
+                    } else { a.host_walked[0] = a.walked_src[0]; a.host_walked[1] = a.walked_src[1]; }
+                }
             }
         }
         return;
@@ -573,6 +587,7 @@ static L1Args l1_args(const GsBin3L1 &b) {
     a.tilecnt = b.tilecnt; a.ntiles = b.ntiles; a.zero_words = b.zero_words;
     a.cap_coarse = b.cap_coarse; a.cap_fine = b.cap_fine;
     a.host_totals = b.host_totals; a.host_walked = b.host_walked; a.walked_src = b.walked_src;
+    a.tile_walked = b.tile_walked; a.n_tile_walked = b.n_tile_walked;
     return a;
 }
 size_t gs_bin3_table_words(int64_t n_slab, int ns) { const int G = gs_bin3_group(ns); return (size_t)ns * (size_t)((n_slab + G - 1) / G + 1); }

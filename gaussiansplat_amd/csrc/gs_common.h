@@ -187,6 +187,8 @@ struct GsBin3L1 {
     // there as well, and the two words at walked_src (device: the previous frame's walked count) to host_walked
     uint32_t *host_totals, *host_walked;
     const uint32_t *walked_src;
+    const uint32_t *tile_walked;           // != null: host_walked receives the 64-bit sum of these n_tile_walked per-tile counts instead
+    int n_tile_walked;
 };
 struct GsBin3Args {
     const uint32_t *cranges;   // 2 x ns: [start, end) of every super-tile's list inside cids
@@ -229,8 +231,12 @@ struct GsCompositeArgs {
     const float *dC;           // W*H*3
     float *g2d;                // GS_G2D_STRIDE x n (atomic accumulate): drgb3 | S0 Sx Sy Sxx Sxy - Syy (raw moments, see below)
     long long *g2d_fixed;      // deterministic mode: the same sums as fixed point (integer atomics commute)
-    unsigned long long *walked; // [0] list entries walked (staged) by this launch, [1] entries evaluated per pixel
-                                // after the no-op cull (one atomic each per tile); may be null
+    unsigned long long *walked; // debug launches only (gs_debug_time_composite + 10000): [0] list entries walked (staged), [1] entries
+                                // evaluated after the no-op cull, ONE ATOMIC EACH PER TILE on two shared words.  Production counts per
+                                // tile instead (tile_walked, tile_work; summed on demand): 2 x tiles same-address atomics drain at the
+                                // memory side one after the other at the END of the kernel -- + 28 us on the 69 us forward of C2
+                                // (2500 tiles), + 15 us at C3 (tools/abtest.py variants 10010 / 10030)
+    uint32_t *tile_walked;     // list entries walked (staged) per tile; may be null
     int cull;                  // 1: drop (tile, splat) entries that are provably no-ops while staging (gs_config.alpha_cull)
     int variant;               // kernel variant (A/B testing; 0 = default)
     int map_mode;              // block -> tile map of the non-queued launch (0 plain; 1, 2: XCD bands, A/B only)
@@ -241,7 +247,7 @@ struct GsCompositeArgs {
     int order_len;              // entries of tile_order = blocks of the plain launch (0: gx * gy)
     const uint32_t *tile_order_plain; // A/B: the same segments in tile order (no longest-first)
     const uint32_t *tile_order_band;  // A/B: longest-first permutation for a plain launch (schedule 3), tile % 8 preserved
-    uint32_t *tile_work;       // forward: evaluated entries per tile (the backward's exact work measure); may be null
+    uint32_t *tile_work;       // evaluated entries per tile (forward: the backward's exact work measure and the next launch order); may be null
     unsigned long long *zero_words; // forward: two 64-bit words zeroed by block 0 (the backward's work counters: saves a memset command); may be null
     unsigned long long *tile_clock; // debug: GS_TILE_CLOCK_WORDS per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated,
                                     // shader cycles (s_memtime) inside the per-entry loops, shader cycles outside them (staging, waiting for the gathers)}
@@ -261,6 +267,8 @@ struct GsCompositeArgs {
 // zero14 (may be null): fourteen 64-bit words zeroed on the way (the backward's work and ticket counters: saves a memset command)
 #define GS_LPT_MAX_TILES 35000
 int gs_lpt_order_len(int gx, int gy);
+// out[0] = sum of a[0 .. n), out[1] = sum of b[0 .. n) (64 bit): the per-tile work counters of a composite launch, on demand
+hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsigned long long *out, hipStream_t s);
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
                                     unsigned long long *zero14 = nullptr, int buckets = 0);
 hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s);

@@ -352,6 +352,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     if (lane == 0) {
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
         if (a.tile_work) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + evaluated : evaluated;
+        if (a.tile_walked) a.tile_walked[tile] = SLAB && a.resume ? a.tile_walked[tile] + walked : walked;
         if (SLAB && a.tile_done) a.tile_done[tile] = all_dead ? 1 : 0;
         if (SLAB && a.tile_pos) a.tile_pos[tile] = gp0 + (s1 - s0);
     }
@@ -719,6 +720,8 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     }
     if (RED == 2 && pend) finish();
     if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
+    if (lane == 0 && a.tile_walked) a.tile_walked[tile] = walked;
+    if (lane == 0 && a.tile_work) a.tile_work[tile] = evaluated;
     if (CLK && a.tile_clock && lane == 0) {
         unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)tile;
         c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
@@ -968,6 +971,23 @@ static size_t debug_extra_lds() {
 #else
     return 0;
 #endif
+}
+
+// the per-tile work counters of a composite launch, summed when somebody asks (gs_get_work_counters, the radix binning paths)
+__global__ __launch_bounds__(1024) void sum_tiles_kernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, int n,
+                                                          unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long sm[2][16];
+    unsigned long long sa = 0, sb = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) { if (a) sa += a[i]; if (b) sb += b[i]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { sa += __shfl_down(sa, d); sb += __shfl_down(sb, d); }
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = sa; sm[1][threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x < 2) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += sm[threadIdx.x][k]; out[threadIdx.x] = t; }
+}
+hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsigned long long *out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_tiles_kernel, dim3(1), dim3(1024), 0, s, a, b, n, out);
+    return hipGetLastError();
 }
 
 static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {
