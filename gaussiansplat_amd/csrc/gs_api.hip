@@ -1293,7 +1293,7 @@ int gs_loss_l1_dssim(gs_ctx *c, const float *img, const float *gt, int32_t W, in
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t n = (size_t)W * H * C;
     HIPCHK(c, c->loss_maps.ensure(sizeof(float) * 3 * n));
-    HIPCHK(c, c->loss_acc.ensure(2 * sizeof(double)));
+    HIPCHK(c, c->loss_acc.ensure(sizeof(double) * GS_LOSS_SLOTS * GS_LOSS_SLOT_STRIDE));
     const float *d_img = img, *d_gt = gt;
     float *d_dc = dC;
     if (mem == GS_MEM_HOST) {
@@ -1315,9 +1315,10 @@ int gs_loss_l1_dssim(gs_ctx *c, const float *img, const float *gt, int32_t W, in
     HIPCHK(c, gs_loss_run(W, H, C, d_img, d_gt, c->loss_maps.as<float>(), c->loss_acc.as<double>(), d_dc, lam, win, c->stream));
     if (mem == GS_MEM_HOST && dC) HIPCHK(c, hipMemcpyAsync(dC, d_dc, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     if (loss_out) {
-        double acc[2];
-        HIPCHK(c, hipMemcpyAsync(acc, c->loss_acc.p, sizeof(acc), hipMemcpyDeviceToHost, c->stream));
+        double slots[GS_LOSS_SLOTS * GS_LOSS_SLOT_STRIDE], acc[2] = {0.0, 0.0};
+        HIPCHK(c, hipMemcpyAsync(slots, c->loss_acc.p, sizeof(slots), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < GS_LOSS_SLOTS; ++k) { acc[0] += slots[k * GS_LOSS_SLOT_STRIDE]; acc[1] += slots[k * GS_LOSS_SLOT_STRIDE + 1]; }
         *loss_out = (1.0 - (double)lam) * acc[0] / (2.0 * (double)n) + (double)lam * (1.0 - acc[1] / (double)n) / 2.0;
     } else if (mem == GS_MEM_HOST) {
         HIPCHK(c, hipStreamSynchronize(c->stream));

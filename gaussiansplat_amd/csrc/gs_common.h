@@ -319,6 +319,9 @@ __host__ __device__ inline void gs_g2d_to_grads(R (&g2)[10], R sig, R i0, R mc, 
 __host__ __device__ inline double gs_fixed_inv(int comp) { return comp >= 6 ? GS_FIXED_INV2 : GS_FIXED_INV; }
 
 // loss + SGD (gs_loss.hip)
+// loss accumulators: GS_LOSS_SLOTS pairs {sum |x - y|, sum ssim}, GS_LOSS_SLOT_STRIDE doubles apart (summed by the host)
+#define GS_LOSS_SLOTS 64
+#define GS_LOSS_SLOT_STRIDE 8
 hipError_t gs_loss_run(int W, int H, int C, const float *img, const float *gt, float *maps, double *acc, float *dC, float lam,
                        const float *win121, hipStream_t s);
 hipError_t gs_launch_sgd(float *p, const float *g, float lr, size_t n, hipStream_t s);

@@ -146,7 +146,11 @@ __global__ __launch_bounds__(256, 3) void ssim_stats_kernel(GsLossArgs a) {
     }
     const float t1 = block_sum_256(l1, sm);
     const float t2 = block_sum_256(St, sm2);
-    if (threadIdx.x == 0) { atomicAdd(&a.acc[0], (double)t1); atomicAdd(&a.acc[1], (double)t2); }
+    // 64 slots, 64 bytes apart (summed by the host): 6120 workgroups x 2 atomics on ONE pair of words drain one after the other
+    if (threadIdx.x == 0) {
+        double *slot = a.acc + (size_t)((blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7u) % GS_LOSS_SLOTS) * GS_LOSS_SLOT_STRIDE;
+        atomicAdd(&slot[0], (double)t1); atomicAdd(&slot[1], (double)t2);
+    }
 }
 
 __global__ __launch_bounds__(256, 4) void ssim_grad_kernel(GsLossArgs a) {
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256, 4) void ssim_grad_kernel(GsLossArgs a) {
 }
 
 hipError_t gs_launch_loss(const GsLossArgs &a, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(a.acc, 0, 2 * sizeof(double), s);
+    hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(double) * GS_LOSS_SLOTS * GS_LOSS_SLOT_STRIDE, s);
     if (e != hipSuccess) return e;
     const dim3 grid((a.W + LTX - 1) / LTX, (a.H + LTY - 1) / LTY, a.C), block(256);
     hipLaunchKernelGGL(ssim_stats_kernel, grid, block, 0, s, a);
