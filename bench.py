@@ -177,6 +177,10 @@ def main():
     ap.add_argument("--schedule", type=int, default=0, help="gs_config.schedule (0 = library default = 3; 1 = tile order; 4 = forward by the previous frame when its slot has no history)")
     ap.add_argument("--no-view-slots", action="store_true", help="do not name view slots (the forward then launches in tile order)")
     ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
+    ap.add_argument("--settle-frames", type=int, default=24, help="untimed frames per rank the timed pass's renderer runs BEFORE its W warm-up "
+                    "steps (0: none; the same count on every rank).  A fresh renderer's first ~20 frames run up to 4 %% slower than its "
+                    "steady state whatever W is (tools/frames_probe.py: 1.54, 1.48, 1.42, 1.40, 1.39 ms over groups of four C3 frames); "
+                    "the driver's W = 5 would time that transient, not the rate a training run sees")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal (t_min=0) measurement")
     ap.add_argument("--no-train-iteration", action="store_true", help="skip the extra training-iteration measurement (loss + SGD, N = 1)")
@@ -273,7 +277,17 @@ def main():
                 a = tot.setdefault(k, [0.0, 0]); a[0] += sm; a[1] += ct
         return {k: (v[0], v[1]) for k, v in tot.items()}
 
-    def timed(r, steps, warmup, k0=0):
+    settled = {"steps": 0}
+
+    def timed(r, steps, warmup, k0=0, settle_frames=0):
+        if settle_frames > 0:                                                # untimed: the fresh renderer (and the chip) reach their steady state
+            per_rank = max(1, views_per_step // world)
+            ks = -(-settle_frames // per_rank)                               # steps: the same number on every rank (the steps hold collectives)
+            ks += (-ks) % len(batches)
+            for k in range(ks):
+                step(r, k0 + k)
+            settled["steps"] = ks
+            k0 += ks
         for k in range(warmup):
             step(r, k0 + k)
         torch.cuda.synchronize()
@@ -316,7 +330,7 @@ def main():
 
     # Pass B: THE timed region -- W warmup steps, then exactly K steps between barriers + synchronize.
     r = make(args.t_min, 2 + STAGES.index(dom))
-    dt = timed(r, args.steps, args.warmup)
+    dt = timed(r, args.steps, args.warmup, settle_frames=args.settle_frames)
     dom_sum, dom_cnt = stage_stats(r)[dom]
     dom_ms = dom_sum / dom_cnt if dom_cnt else 0.0
     lctx = r._bench_hv.last_ctx                              # the ctx of the last view rendered
@@ -384,6 +398,7 @@ def main():
                                           "tests/test_gpu_sizes.py)",
                        "views_per_step": views_per_step, "views_per_rank": views_per_step // world, "nranks": nranks,
                        "ms_per_view": dt / args.steps * 1e3 / (views_per_step // world),
+                       "settle_steps": settled["steps"],      # untimed steps before the W warm-up steps (--settle-frames)
                        "pipeline": (not args.no_pipeline) if views_per_step // world > 1 else None,
                        "grad_sync": args.grad_sync if world > 1 else None, "allreduce_overlap": (not args.no_overlap) if world > 1 else None,
                        "backend": args.backend if world > 1 else None,
