@@ -384,6 +384,7 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
 // depth distribution, e.g. a wall of gaussians at one depth plus an outlier) is sorted by the same workgroup through global
 // memory, chunk by chunk (slow but correct), and reported to the host (host_stat), which returns to the classic path.
 #define DS_ITEMS 8
+#define DS_PATHOLOGICAL 8
 #define DS_CAP_OF(NT) ((NT) * DS_ITEMS)
 
 // Element `li` of the (at most NT * 8) elements a workgroup holds in registers: wave w owns the `per` consecutive elements from
@@ -531,8 +532,10 @@ __global__ __launch_bounds__(NT) void ds_local_kernel(uint64_t *__restrict__ pai
         for (int li = tid; li < (int)cnt; li += NT) perm[(size_t)start + li] = sid[li];
         return;
     }
-    // ---- oversize bucket: LSD passes through global memory, CAP elements at a time (pairs <-> scratch)
-    if (tid == 0 && host_stat) *host_stat = cnt;
+    // ---- oversize bucket: LSD passes through global memory, CAP elements at a time (pairs <-> scratch).  A few chunks per bucket are
+    // the normal case for models beyond 1.3 M gaussians (C5: 19.5 k pairs per bucket, three chunks); only a bucket of more than
+    // DS_PATHOLOGICAL chunks is reported to the host (one workgroup would sort a large share of the model alone)
+    if (tid == 0 && host_stat && cnt > (uint32_t)(DS_PATHOLOGICAL * CAP)) *host_stat = cnt;
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
     for (uint32_t i = tid; i < cnt; i += NT) { const uint32_t k = (uint32_t)(pairs[(size_t)start + i] >> 32); mn = min(mn, k); mx = max(mx, k); }
     ds_block_minmax<NT>(mn, mx, sm);
@@ -587,7 +590,7 @@ __global__ void ds_reset_range_kernel(uint32_t *__restrict__ acc, int nparity) {
 }
 size_t gs_depth_range_words() { return (size_t)2 * 2 * DS_SLOTS * DS_STRIDE; }           // two frame parities
 size_t gs_depth_range_parity_words() { return (size_t)2 * DS_SLOTS * DS_STRIDE; }
-int64_t gs_depth_buckets_max_n() { return (int64_t)DS_BUCKETS * DS_CAP_OF(1024) * 5 / 8; } // mean bucket at 5/8 of the capacity
+int64_t gs_depth_buckets_max_n() { return (int64_t)DS_BUCKETS * DS_CAP_OF(1024) * 4; }     // mean bucket of four chunks (8.4 M gaussians)
 hipError_t gs_depth_range_reset(uint32_t *acc, hipStream_t s) {
     hipLaunchKernelGGL(ds_reset_range_kernel, dim3(1), dim3(256), 0, s, acc, 2);
     return hipGetLastError();

@@ -124,9 +124,9 @@ typedef struct {
     int32_t debug_flags;      /* GS_DEBUG_* bits; 0 in production                                                              */
     int32_t depth_sort;       /* the depth order (CUDA.sortperm of forward.jl:103; same permutation on every path, bit for bit):
                                  0 (default) automatic -- two steps (256 buckets over the frame's key range, then one workgroup
-                                 per bucket inside LDS: 4 launches) for 3-D frames of up to 1.3 M gaussians, the four-pass LSD
-                                 radix sort (12 launches) otherwise and for 64 frames after a frame whose depths piled up in one
-                                 bucket; 1 always the four-pass sort; 2 always the two-step sort (tests)                          */
+                                 per bucket: inside LDS up to 8192 pairs, else through global memory in chunks; 4 launches) for 3-D frames
+                                 of up to 8.4 M gaussians, the four-pass LSD radix sort (12 launches) otherwise and for 64 frames after
+                                 a frame whose depths piled up in one bucket (more than eight chunks); 1 always the four-pass sort; 2 always the two-step sort (tests)                          */
     int32_t reserved[5];      /* sizeof(gs_config) == 96                                                                       */
 } gs_config;
 #define GS_DEBUG_WIDE_CURSORS 1   /* two-level binning: 64-bit list cursors although the lists fit 32-bit byte offsets (tests)    */
