@@ -28,7 +28,7 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
-           "gs_debug_tile_clock", "gs_rank_probe_result", "gs_num_rounds", "gs_set_view_slot", "gs_num_coarse_instances")
+           "gs_debug_tile_clock", "gs_debug_clock_mhz", "gs_rank_probe_result", "gs_num_rounds", "gs_set_view_slot", "gs_num_coarse_instances")
 
 GS_ABI_VERSION = 2          # include/gsplat.h; load() refuses a library that reports another version
 GS_DEBUG_WIDE_CURSORS = 1
@@ -113,6 +113,7 @@ def load():
     L.gs_get_work_counters_ex.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gs_debug_time_composite.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.gs_debug_tile_clock.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.gs_debug_clock_mhz.argtypes = [vp, C.POINTER(C.c_float)]
     L.gs_rank_probe_result.argtypes = [vp]
     L.gs_num_rounds.argtypes = [vp]
     L.gs_set_view_slot.argtypes = [vp, C.c_int32]
@@ -386,6 +387,12 @@ class Context:
         out = np.zeros((ntiles, 6), np.uint64)
         self._chk(self.L.gs_debug_tile_clock(self.h, which, variant, C.c_void_p(out.ctypes.data)))
         return out
+
+    def clock_mhz(self) -> float:
+        """the shader clock the chip runs at right now (one wave counting cycles over 20 us; waits for the stream)"""
+        mhz = C.c_float()
+        self._chk(self.L.gs_debug_clock_mhz(self.h, C.byref(mhz)))
+        return float(mhz.value)
 
     @property
     def rank_probe_result(self) -> int:

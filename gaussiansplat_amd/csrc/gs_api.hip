@@ -1621,6 +1621,18 @@ int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
     return GS_OK;
 }
 
+int gs_debug_clock_mhz(gs_ctx *c, float *mhz) {
+    if (!c || !mhz) return GS_ERR_INVALID;
+    if (bind_device(c)) return GS_ERR_HIP;
+    HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(static_cast<char *>(c->counters.p) + 160), h[2] = {0, 1};
+    HIPCHK(c, gs_launch_clock_probe(d, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *mhz = h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : 0.0f;       // s_memrealtime ticks at 100 MHz
+    return GS_OK;
+}
+
 int gs_rank_probe_result(const gs_ctx *c) { return c ? c->rank_probe : -1; }
 
 // counters[0..3] = {walked, evaluated} of the last forward and of the last composite backward, summed from the per-tile arrays

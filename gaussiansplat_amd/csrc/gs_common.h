@@ -267,6 +267,8 @@ struct GsCompositeArgs {
 // zero14 (may be null): fourteen 64-bit words zeroed on the way (the backward's work and ticket counters: saves a memset command)
 #define GS_LPT_MAX_TILES 35000
 int gs_lpt_order_len(int gx, int gy);
+// out[0] = shader cycles (s_memtime), out[1] = 100 MHz ticks (s_memrealtime) of one wave over ~20 us: the chip's clock right now
+hipError_t gs_launch_clock_probe(unsigned long long *out, hipStream_t s);
 // out[0] = sum of a[0 .. n), out[1] = sum of b[0 .. n) (64 bit): the per-tile work counters of a composite launch, on demand
 hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsigned long long *out, hipStream_t s);
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,

@@ -990,6 +990,18 @@ hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsi
     return hipGetLastError();
 }
 
+__global__ void clock_probe_kernel(unsigned long long *__restrict__ out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    for (int i = 0; i < (1 << 20) && r1 - r0 < 2000ull; ++i) r1 = __builtin_amdgcn_s_memrealtime();      // 20 us, bounded
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+hipError_t gs_launch_clock_probe(unsigned long long *out, hipStream_t s) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, out);
+    return hipGetLastError();
+}
+
 static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {
 #ifdef GS_EXPERIMENTS
     if (a.queue) return dim3((unsigned)max(1, min(a.grid_waves > 0 ? a.grid_waves : ntiles, ntiles)));

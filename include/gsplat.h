@@ -351,6 +351,10 @@ int gs_debug_time_composite(gs_ctx *ctx, int which, int variant, int reps, float
  * for its gathers)}.  tools/tile_tail.py turns it into the occupancy-over-time and tail summary under profiles/. */
 int gs_debug_tile_clock(gs_ctx *ctx, int which, int variant, uint64_t *out);
 
+/* Profiling hook: the shader clock (MHz) the chip runs at right now, from one wave that counts s_memtime cycles over 20 us of
+ * s_memrealtime on the ctx stream (waits for the stream).  tools/frames_probe.py samples it between frames. */
+int gs_debug_clock_mhz(gs_ctx *ctx, float *mhz);
+
 /* -1: the lane-order probe of the LDS-atomic rank was not run (rank_mode = 1 was asked for); 0: it ran at gs_create and
  * passed; 1: it failed on this device and ballots were forced. */
 int gs_rank_probe_result(const gs_ctx *ctx);

@@ -266,6 +266,12 @@ function hip_debugTileClock(r::HipRenderer, which::Integer, variant::Integer, nt
     check(r, ccall((:gs_debug_tile_clock, libgs), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), r.ctx, which, variant, out))
     return out
 end
+function hip_clockMHz(r::HipRenderer)
+    mhz = Ref{Cfloat}(0f0)
+    check(r, ccall((:gs_debug_clock_mhz, libgs), Cint, (Ptr{Cvoid}, Ref{Cfloat}), r.ctx, mhz))
+    return mhz[]
+end
+
 hip_rankProbeResult(r::HipRenderer) = ccall((:gs_rank_probe_result, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 
 end # module
