@@ -77,16 +77,21 @@ __global__ __launch_bounds__(NT) void rs_hist_kernel(const uint64_t *__restrict_
                                                       uint32_t *__restrict__ digit_total, const uint32_t *__restrict__ range_acc = nullptr) {
     __shared__ uint32_t h[RS_RADIX];
     __shared__ uint32_t sh2[2];
+    const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
+    uint32_t k32[RS_CHUNK / NT];                         // bucket pass: the keys are requested before the range is folded (one exposed
+    if (BUCKETS) {                                       // round trip instead of two: these kernels are latency, not bandwidth)
+#pragma unroll
+        for (int i = 0; i < RS_CHUNK / NT; ++i) { const int64_t idx = base + (int64_t)i * NT + threadIdx.x; k32[i] = idx < n ? keys32[idx] : 0u; }
+    }
     DsMap map{};
     if (BUCKETS) map = ds_load_map(range_acc, sh2);
     if (threadIdx.x < RS_RADIX) h[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
 #pragma unroll
     for (int i = 0; i < RS_CHUNK / NT; ++i) {
         const int64_t idx = base + (int64_t)i * NT + threadIdx.x;
         if (idx < n) {
-            const uint32_t dg = BUCKETS ? ds_bucket(map, keys32[idx])
+            const uint32_t dg = BUCKETS ? ds_bucket(map, k32[i])
                                         : keys32 ? ((keys32[idx] >> (shift - 32)) & mask) : ((uint32_t)(keys[idx] >> shift) & mask);
             atomicAdd(&h[dg], 1u);
         }
@@ -195,13 +200,20 @@ __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restri
     __shared__ uint32_t gbase[RS_RADIX];
     __shared__ uint32_t sm[RS_RADIX / GS_WAVE];
     __shared__ uint32_t sh2[2];
-    DsMap map{};
-    if (BUCKETS) map = ds_load_map(range_acc, sh2);
-    auto digit_of = [&](uint64_t k) -> uint32_t { return BUCKETS ? ds_bucket(map, (uint32_t)(k >> 32)) : ((uint32_t)(k >> shift) & mask); };
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
     const int64_t remain = n - base;
     const int cnt = remain < RS_CHUNK ? (int)remain : RS_CHUNK;
+    uint64_t key[ITEMS];                                 // requested first: the prologue below (range, table entry, totals) hides their latency
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int li = w * (GS_WAVE * ITEMS) + r * GS_WAVE + lane;      // index inside the chunk
+        const bool valid = li < cnt;
+        key[r] = !valid ? ~0ull : in32 ? (((uint64_t)in32[base + li] << 32) | (uint32_t)(base + li)) : in[base + li];
+    }
+    DsMap map{};
+    if (BUCKETS) map = ds_load_map(range_acc, sh2);
+    auto digit_of = [&](uint64_t k) -> uint32_t { return BUCKETS ? ds_bucket(map, (uint32_t)(k >> 32)) : ((uint32_t)(k >> shift) & mask); };
     for (int i = tid; i < NW * RS_RADIX; i += NT) (&wcnt[0][0])[i] = 0;
     {   // table entry (+ in relative mode the totals of the smaller digits: exclusive scan of the 256 row totals)
         uint32_t g = 0, t = 0;
@@ -217,15 +229,8 @@ __global__ __launch_bounds__(NT) void rs_scatter_kernel(const uint64_t *__restri
     }
     __syncthreads();
 
-    uint64_t key[ITEMS];
     uint32_t rank[ITEMS];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-        const int li = w * (GS_WAVE * ITEMS) + r * GS_WAVE + lane;      // index inside the chunk
-        const bool valid = li < cnt;
-        key[r] = !valid ? ~0ull : in32 ? (((uint64_t)in32[base + li] << 32) | (uint32_t)(base + li)) : in[base + li];
-    }
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int li = w * (GS_WAVE * ITEMS) + r * GS_WAVE + lane;
