@@ -193,8 +193,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="allreduce: literally ONE collective after the last kernel (default: the Δshs "
                     "segment starts as soon as the last view's SH kernel has run, beside the geometry chain)")
     ap.add_argument("--no-pipeline", action="store_true", help="view batches: one renderer, one stream (default: the views of a rank alternate between "
-                    "two renderers / streams over the same model, so the lists of view k+1 are built beside the composite kernels of view k)")
-    ap.add_argument("--pipeline-depth", type=int, default=2, help="view batches: views of a rank in flight at once (renderers / streams over the same model)")
+                    "--pipeline-depth renderers / streams over the same model, so the lists of view k+1 are built beside the composite kernels of view k)")
+    ap.add_argument("--pipeline-depth", type=int, default=3, help="view batches: views of a rank in flight at once (renderers / streams over the same model; 3: + 2 % over 2 at C4 on one GPU, 4 and 5 no better)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
     if args.config is None:
@@ -382,7 +382,7 @@ def main():
         else:
             what = (f"{args.config}: {n} gaussians, {W}x{H}, SH{deg}, a batch of {views_per_step} camera views per step (view k: eye rotated about +y "
                     f"by 45k degrees), fwd+bwd per view with the gradients accumulating; {views_per_step // world} view(s) per GPU"
-                    + (" (consecutive views alternate between two renderers / HIP streams over the same model: the lists of view k+1 are built beside "
+                    + (f" (consecutive views alternate between {args.pipeline_depth} renderers / HIP streams over the same model: the lists of view k+1 are built beside "
                        "the composite kernels of view k)" if views_per_step // world > 1 and not args.no_pipeline else "")
                     + ((", then all-reduce of 11N f32 + all-gather of 3N f32 per view (colour-factored) over RCCL" if factored
                         else ", then the sum of the flat 59N-f32 gradient buffer over RCCL ("

@@ -50,7 +50,7 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
     started there (async: RCCL's own stream, event-ordered behind the kernel) and runs beside the geometry chain; the
     all-reduce of the 11 N geometry floats follows.  Same sums, bit for bit, as ONE all-reduce of the whole buffer -- an
     all-reduce is element-wise.  overlap = False: literally one collective.
-    pipeline (a rank with two or more views, HIP renderer): consecutive views alternate between two renderers that share the model and
+    pipeline (a rank with two or more views, HIP renderer): consecutive views alternate between `pipeline_depth` (3) renderers that share the model and
     the gradient buffer but own their per-view scratch and HIP stream (HipViewRenderer.render_views_pipelined), so the short,
     latency-bound kernels of view k+1 (preprocess, depth sort, tile lists) run beside the composite kernels of view k; the
     per-gaussian chains stay in view order (event-chained), so the sums are the same bits as one view after the other.
@@ -103,13 +103,13 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
 class HipViewRenderer:
     """Adapter of a GaussianRenderer3D (HIP path) to the ViewRenderer protocol."""
 
-    def __init__(self, renderer, pipeline_depth: int = 2):
+    def __init__(self, renderer, pipeline_depth: int = 3):
         self.r = renderer
         self.last_ctx = renderer.ctx            # the ctx that rendered the most recent view (introspection: counters, instance counts)
         self.pipeline_depth = max(2, int(pipeline_depth))      # views in flight in render_views_pipelined
 
     def contexts(self):
-        """every gs_ctx views are rendered through (the renderer's own, and the two twins of the pipelined mode once they exist)"""
+        """every gs_ctx views are rendered through (the renderer's own, and the twins of the pipelined mode once they exist)"""
         return [self.r.ctx] + [t.ctx for t, _ in (getattr(self, "_tw", None) or [])]
 
     @property
@@ -128,7 +128,7 @@ class HipViewRenderer:
         R.backward(self.r, dC)
         self.last_ctx = self.r.ctx
 
-    # ---- several views of one rank on two streams (multi_view_step(pipeline=True))
+    # ---- several views of one rank on `pipeline_depth` streams (multi_view_step(pipeline=True))
     def _twins(self):
         """Two more renderers over the SAME parameter tensors and the SAME flat gradient buffer (borrowed device pointers: no
         copy of the model), each with its own ctx -- i.e. its own per-view scratch (payload rows, depth order, tile lists,
@@ -152,7 +152,7 @@ class HipViewRenderer:
         return self._tw
 
     def render_views_pipelined(self, cameras, dCs) -> None:
-        """Views alternate between the two twins.  On a twin's stream: preprocess, lists, forward, composite adjoint of its view --
+        """Views alternate between the twins.  On a twin's stream: preprocess, lists, forward, composite adjoint of its view --
         nothing there touches what the other twin uses -- then the per-gaussian chain, which accumulates into the shared
         gradient buffer and therefore waits (event) for the chain of the view before it.  The first view overwrites (the lazy
         reset), the others accumulate, in view order: the same sums, bit for bit, as render_view in a loop."""
