@@ -137,10 +137,21 @@ class Context:
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
                  profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 1,
                  alpha_cull: bool = True, schedule: int = 0, slab_mode: int = 1, slab_fractions=(), slab_max_ratio: float = 0.0,
-                 debug_flags: int = 0, depth_sort: int = 0):
+                 debug_flags: int = 0, depth_sort: int = 0, cfg: "GsConfig | None" = None):
         """schedule 0 = the library default (3); slab_fractions / slab_max_ratio / debug_flags: gs_config fields for tests;
-        depth_sort 0 automatic, 1 the four-pass radix sort, 2 always key-range buckets + LDS (same permutation)."""
+        depth_sort 0 automatic, 1 the four-pass radix sort, 2 always key-range buckets + LDS (same permutation).
+        cfg: a complete gs_config to copy instead (every field: a second ctx that must take the same code paths as the first)."""
         self.L = load()
+        if cfg is not None:
+            twin = GsConfig()
+            C.memmove(C.byref(twin), C.byref(cfg), C.sizeof(GsConfig))
+            self.cfg = twin
+            self.h = C.c_void_p()
+            rc = self.L.gs_create(C.byref(self.h), device, C.byref(twin))
+            if rc != 0:
+                raise GsError(rc, (self.L.gs_last_error(None) or b"").decode())
+            self._keep = []
+            return
         cfg = default_config()
         assert cfg.struct_size == C.sizeof(GsConfig) and cfg.abi_version == GS_ABI_VERSION
         cfg.schedule = int(schedule)

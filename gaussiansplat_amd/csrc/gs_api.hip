@@ -155,7 +155,13 @@ struct gs_ctx {
     bool range_valid = false;                // the 3-D preprocess of this frame filled key_range[range_parity]
     bool dsort_buckets_used = false;         // this frame's depth order came from the bucket path (its pinned stat word is live)
     int64_t dsort_classic_until = 0;         // frame id up to which the classic sort is used (an oversize bucket was reported)
-    uint32_t *dsort_stat() { return pinned + 100 + (range_parity & 1); }
+    int dsort_stat_parity = 0;               // the parity gs_bin used for the bucket path's pinned stat word (gs_preprocess of the NEXT frame flips range_parity
+                                             // before settle_totals of this one may run)
+    uint32_t *dsort_stat() { return pinned + 100 + (dsort_stat_parity & 1); }
+    // the bucket path is possible for the frame being built (same predicate in gs_preprocess, which then folds the key range, and in gs_bin)
+    bool dsort_can_bucket() const {
+        return cfg.depth_sort != 1 && (cfg.depth_sort == 2 || (n <= gs_depth_buckets_max_n() && frame_id > dsort_classic_until));
+    }
     float *bound_image = nullptr, *bound_trans = nullptr;   // gs_bind_outputs: caller-owned device buffers the forward writes directly
     float *img() { return bound_image ? bound_image : image.as<float>(); }
     float *tr() { return bound_trans ? bound_trans : trans.as<float>(); }
@@ -581,7 +587,9 @@ int gs_preprocess(gs_ctx *c) {
     a.depth_key = c->depth_key.as<uint32_t>();
     a.rect = c->rect.as<uint16_t>();
     c->range_valid = false;
-    if (c->cfg.depth_sort != 1 && c->order() != GS_ORDER_INDEX && c->n > 0) {
+    // the key range is folded only when this frame's depth sort can take the bucket path: while the classic sort runs (the 64-frame
+    // fallback, N beyond the bucket path's limit) nothing would reset the accumulators and the atomics would be wasted
+    if (c->dsort_can_bucket() && c->order() != GS_ORDER_INDEX && c->n > 0) {
         if (!c->key_range.p) {
             HIPCHK(c, c->key_range.ensure(sizeof(uint32_t) * gs_depth_range_words()));
             HIPCHK(c, gs_depth_range_reset(c->key_range.as<uint32_t>(), c->stream));
@@ -852,12 +860,14 @@ int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
         // Two steps (256 key-range buckets, then one workgroup per bucket in LDS: 4 launches) when this frame's preprocess left the
         // key range, the mean bucket is well inside a workgroup's capacity, and no oversize bucket was reported lately; else the
         // classic four LSD passes (12 launches).  Same permutation either way.
-        const bool buckets = c->range_valid && c->cfg.depth_sort != 1 &&
-                             (c->cfg.depth_sort == 2 || (c->n <= gs_depth_buckets_max_n() && c->frame_id > c->dsort_classic_until));
+        const bool buckets = c->range_valid && c->dsort_can_bucket();
         c->dsort_buckets_used = buckets;
+        if (c->range_valid && !buckets)                 // folded but not consumed (cannot happen with one predicate; kept so that a stale union never survives)
+            HIPCHK(c, gs_depth_range_reset(c->key_range.as<uint32_t>() + (size_t)c->range_parity * gs_depth_range_parity_words(), c->stream, 1));
         if (buckets) {
             uint32_t *range = c->key_range.as<uint32_t>() + (size_t)c->range_parity * gs_depth_range_parity_words();
             uint32_t *other = c->key_range.as<uint32_t>() + (size_t)(c->range_parity ^ 1) * gs_depth_range_parity_words();
+            c->dsort_stat_parity = c->range_parity;
             *c->dsort_stat() = 0u;                      // (no kernel of an earlier frame writes this parity's word any more: two frames back)
             HIPCHK(c, gs_depth_sort_buckets(c->depth_key.as<uint32_t>(), c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, c->table.as<uint32_t>(),
                                             c->digit_total.as<uint32_t>(), perm, range, other, c->dsort_stat(), c->stream, c->cfg.rank_mode != 0));

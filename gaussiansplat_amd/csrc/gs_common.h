@@ -113,7 +113,7 @@ hipError_t gs_radix_sort_u64(uint64_t *a, uint64_t *b, int64_t n, int bit_lo, in
 size_t gs_depth_range_words();
 size_t gs_depth_range_parity_words();
 int64_t gs_depth_buckets_max_n();
-hipError_t gs_depth_range_reset(uint32_t *acc, hipStream_t s);
+hipError_t gs_depth_range_reset(uint32_t *acc, hipStream_t s, int nparity = 2);   // acc: first word of the first parity to re-arm
 hipError_t gs_depth_sort_buckets(const uint32_t *keys32, uint64_t *pairs_a, uint64_t *pairs_b, int64_t n, uint32_t *block_hist,
                                  uint32_t *digit_total, uint32_t *perm, const uint32_t *range_acc, uint32_t *reset_acc,
                                  uint32_t *host_stat, hipStream_t stream, bool ballot_ranks);

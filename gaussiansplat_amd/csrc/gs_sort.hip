@@ -57,7 +57,7 @@ __device__ __forceinline__ DsMap ds_load_map(const uint32_t *__restrict__ acc, u
     __syncthreads();
     DsMap m;
     const uint32_t lo = sh2[0], hi = sh2[1];
-    m.kmin = lo <= hi ? lo : 0u;                                            // (no finite key at all: everything goes to bucket 0)
+    m.kmin = lo <= hi ? lo : 0u;                                            // (no finite key at all: kmin = kmax = 0, key 0 -> bucket 0, every other key -> bucket 255: one bucket, sorted correctly the slow way)
     m.kmax = lo <= hi ? hi : 0u;
     m.zmin = ds_key_value(m.kmin);
     const float span = ds_key_value(m.kmax) - m.zmin;                       // may overflow to +Inf: scale 0, one bucket
@@ -596,8 +596,8 @@ __global__ void ds_reset_range_kernel(uint32_t *__restrict__ acc, int nparity) {
 size_t gs_depth_range_words() { return (size_t)2 * 2 * DS_SLOTS * DS_STRIDE; }           // two frame parities
 size_t gs_depth_range_parity_words() { return (size_t)2 * DS_SLOTS * DS_STRIDE; }
 int64_t gs_depth_buckets_max_n() { return (int64_t)DS_BUCKETS * DS_CAP_OF(1024) * 4; }     // mean bucket of four chunks (8.4 M gaussians)
-hipError_t gs_depth_range_reset(uint32_t *acc, hipStream_t s) {
-    hipLaunchKernelGGL(ds_reset_range_kernel, dim3(1), dim3(256), 0, s, acc, 2);
+hipError_t gs_depth_range_reset(uint32_t *acc, hipStream_t s, int nparity) {
+    hipLaunchKernelGGL(ds_reset_range_kernel, dim3(1), dim3(256), 0, s, acc, nparity);
     return hipGetLastError();
 }
 

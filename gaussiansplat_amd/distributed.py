@@ -44,12 +44,15 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
     """One data-parallel step over a view batch (8 views on 1 / 2 / 4 / 8 GPUs = 8 / 4 / 2 / 1 views per rank, rendered
     one after the other with the gradients ACCUMULATING, then the exchange).  Returns the flat gradient buffer summed over all
     views (identical on every rank; the caller applies its optimiser and the next step starts with reset()).
-    sync = "allreduce": the sum of the whole flat buffer.  With `overlap` and a renderer that can split its last backward
-    (render_view_until_sh / finish_geometry: the HIP renderer) the buffer is reduced as its two contiguous segments: the Δshs
-    segment (81 % of the bytes at SH degree 3) is final as soon as the last view's SH kernel has run, so its all-reduce is
-    started there (async: RCCL's own stream, event-ordered behind the kernel) and runs beside the geometry chain; the
-    all-reduce of the 11 N geometry floats follows.  Same sums, bit for bit, as ONE all-reduce of the whole buffer -- an
-    all-reduce is element-wise.  overlap = False: literally one collective.
+    sync = "allreduce": the sum of the whole flat buffer.  With `overlap`, a renderer that can split its last backward
+    (render_view_until_sh / finish_geometry: the HIP renderer) and a batch that leaves some rank exactly ONE view (8 views on
+    8 GPUs), the buffer is reduced as its two contiguous segments ON EVERY RANK: the Δshs segment (81 % of the bytes at SH
+    degree 3) is final as soon as the last view's SH kernel has run, so its all-reduce is started there (async: RCCL's own
+    stream, event-ordered behind the kernel) and runs beside the geometry chain; the all-reduce of the 11 N geometry floats
+    follows.  Same sums, bit for bit, as ONE all-reduce of the whole buffer -- an all-reduce is element-wise.  Otherwise
+    (overlap = False, every rank pipelines two or more views, or some rank has no view at all): literally one collective.
+    Which of the two it is follows from the view counts of ALL ranks, so every rank posts the same collectives in the same order
+    whatever its own share is (3 views on 2 ranks, 12 on 8, fewer views than ranks).
     pipeline (a rank with two or more views, HIP renderer): consecutive views alternate between `pipeline_depth` (3) renderers that share the model and
     the gradient buffer but own their per-view scratch and HIP stream (HipViewRenderer.render_views_pipelined), so the short,
     latency-bound kernels of view k+1 (preprocess, depth sort, tile lists) run beside the composite kernels of view k; the
@@ -63,19 +66,29 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
     mine = shard_views(len(cameras), world, rank)
     r.reset()
     if sync == "allreduce":
-        if pipeline and len(mine) > 1 and hasattr(r, "render_views_pipelined"):
+        # How many collectives a step posts, and over which segments, is decided from numbers EVERY rank computes alike -- the
+        # view counts of all ranks and the renderer's type -- never from this rank's own share: unequal shares (3 views on 2
+        # ranks, fewer views than ranks) would otherwise post mismatched collectives (gloo aborts, RCCL hangs).
+        counts = [len(shard_views(len(cameras), world, k)) for k in range(world)]
+        can_pipeline = pipeline and hasattr(r, "render_views_pipelined")
+        can_split = overlap and hasattr(r, "render_view_until_sh") and hasattr(r, "geometry_floats")
+        # two segments (Δshs first) when some rank renders exactly one view the two-step way -- then every rank reduces the same
+        # two segments, whatever path its own views took; a rank without a view has nothing to split, so min(counts) >= 1
+        two_segments = world > 1 and can_split and min(counts) >= 1 and (min(counts) == 1 or not can_pipeline)
+        if can_pipeline and len(mine) > 1:
             r.render_views_pipelined([cameras[v] for v in mine], [dCs[v] for v in mine])
-            if world > 1:
-                dist.all_reduce(r.flat, op=dist.ReduceOp.SUM, group=group)  # the ONE collective of the step
-            return r.flat
-        split = world > 1 and overlap and len(mine) > 0 and hasattr(r, "render_view_until_sh")
-        for v in (mine[:-1] if split else mine):
-            r.render_view(cameras[v], dCs[v])
-        if split:
+            last_split = False
+        else:
+            last_split = two_segments and len(mine) > 0
+            for v in (mine[:-1] if last_split else mine):
+                r.render_view(cameras[v], dCs[v])
+        if two_segments:
             geo = r.geometry_floats
-            r.render_view_until_sh(cameras[mine[-1]], dCs[mine[-1]])        # ... composite adjoint, SH kernel: Δshs is final
+            if last_split:
+                r.render_view_until_sh(cameras[mine[-1]], dCs[mine[-1]])    # ... composite adjoint, SH kernel: Δshs is final
             work = dist.all_reduce(r.flat[geo:], op=dist.ReduceOp.SUM, group=group, async_op=True)
-            r.finish_geometry()                                             # the geometry chain runs beside the collective
+            if last_split:
+                r.finish_geometry()                                         # the geometry chain runs beside the collective
             dist.all_reduce(r.flat[:geo], op=dist.ReduceOp.SUM, group=group)
             work.wait()
         elif world > 1:
@@ -110,7 +123,7 @@ class HipViewRenderer:
 
     def contexts(self):
         """every gs_ctx views are rendered through (the renderer's own, and the twins of the pipelined mode once they exist)"""
-        return [self.r.ctx] + [t.ctx for t, _ in (getattr(self, "_tw", None) or [])]
+        return [self.r.ctx] + [t.ctx for t, _ in (getattr(self, "_tw", None) or []) if t is not self.r]
 
     @property
     def flat(self):
@@ -130,24 +143,21 @@ class HipViewRenderer:
 
     # ---- several views of one rank on `pipeline_depth` streams (multi_view_step(pipeline=True))
     def _twins(self):
-        """Two more renderers over the SAME parameter tensors and the SAME flat gradient buffer (borrowed device pointers: no
-        copy of the model), each with its own ctx -- i.e. its own per-view scratch (payload rows, depth order, tile lists,
-        image; 288 GB of HBM hold many) -- and its own HIP stream."""
+        """`pipeline_depth` renderers in flight over the SAME parameter tensors and the SAME flat gradient buffer (borrowed device
+        pointers: no copy of the model, no gradient buffer of their own): the rank's own renderer is the first, the others are
+        twins with their own ctx -- i.e. their own per-view scratch (payload rows, depth order, tile lists, image; 288 GB of HBM
+        hold many) -- created from a copy of the WHOLE gs_config, so that every view takes the same code paths.  Each has its
+        own HIP stream."""
         if getattr(self, "_tw", None) is None:
             import torch
             from . import renderer as R
             r = self.r
             H, W = r.transmittance.shape
-            cfg = r.ctx.cfg
-            tw = []
-            for _ in range(self.pipeline_depth):
-                t = R.GaussianRenderer3D(r.splatData, (W, H), r.sh_degree, device=r.imageData.device.index or 0, order=int(cfg.order),
-                                         t_min=float(cfg.t_min), deterministic=bool(cfg.deterministic), alpha_cull=bool(cfg.alpha_cull),
-                                         rank_mode=int(cfg.rank_mode), slab_mode=int(cfg.slab_mode), schedule=int(cfg.schedule),
-                                         profile_stages=int(cfg.profile_stages))
-                t._splatGrads = r._splatGrads                              # ONE gradient buffer
-                t._grads = r._grads
-                tw.append((t, torch.cuda.Stream(device=r.imageData.device)))
+            dev = r.imageData.device
+            tw = [(r, torch.cuda.Stream(device=dev))]
+            for _ in range(self.pipeline_depth - 1):
+                t = R.GaussianRenderer3D(r.splatData, (W, H), r.sh_degree, device=dev.index or 0, share_grads_with=r, cfg=r.ctx.cfg)
+                tw.append((t, torch.cuda.Stream(device=dev)))
             self._tw = tw
         return self._tw
 
@@ -163,6 +173,9 @@ class HipViewRenderer:
         dev = r.imageData.device
         dCs = [(d if isinstance(d, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(d, np.float32))).to(dev, torch.float32).contiguous()
                for d in dCs]                                                # (uploads, if any, on the caller's stream: before `start`)
+        for d in dCs:                                                       # the checks R.backward makes, before anything is enqueued
+            if tuple(d.shape) != tuple(r.imageData.shape):
+                raise ValueError(f"dC has shape {tuple(d.shape)}, the image is {tuple(r.imageData.shape)}")
         cur = torch.cuda.current_stream(dev)
         start = torch.cuda.Event(); start.record(cur)
         overwrite = r._grads_lazy_zero

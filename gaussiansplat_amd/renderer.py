@@ -105,10 +105,12 @@ def initGrads(splatData: SplatData3D) -> SplatGrads3D:
 class GaussianRenderer3D:               # renderer.jl:205-219
     def __init__(self, splatData: SplatData3D, imgSize, sh_degree: int, device: int = 0, order: int = B.ORDER_DEPTH_DESC,
                  t_min: float = 1e-5, export_debug: bool = False, profile_stages: bool = False, deterministic: bool = False,
-                 alpha_cull: bool = True, rank_mode: int = 1, slab_mode: int = 1, schedule: int = 0, **ctx_kw):
+                 alpha_cull: bool = True, rank_mode: int = 1, slab_mode: int = 1, schedule: int = 0, share_grads_with=None, **ctx_kw):
+        """share_grads_with: another GaussianRenderer3D over the same splatData whose gradient buffer this one accumulates into
+        (a second view in flight, distributed.HipViewRenderer): no buffer of its own is allocated."""
         import torch
         self.splatData = splatData
-        self._splatGrads = initGrads(splatData)
+        self._splatGrads = share_grads_with._splatGrads if share_grads_with is not None else initGrads(splatData)
         self._grads_lazy_zero = False       # resetGrads() pending: the next backward overwrites
         W, H = int(imgSize[0]), int(imgSize[1])
         dev = splatData.means.device

@@ -91,10 +91,35 @@ class OracleFactoredRenderer(OracleViewRenderer):
         self.flat[11 * N:] = torch.from_numpy(acc.reshape(-1))
 
 
-def _views():
-    cams = [synthetic.scene_camera(W, view=v) for v in range(VIEWS)]
-    dCs = [synthetic.make_dC(W, H, 100 + v) for v in range(VIEWS)]
+class OraclePipelinedSplitRenderer(OracleSplitRenderer):
+    """What HipViewRenderer offers: a pipelined path for a rank with several views AND the two-step last view."""
+
+    def render_views_pipelined(self, cams, dCs):
+        for cam, dC in zip(cams, dCs):
+            OracleViewRenderer.render_view(self, cam, dC)
+
+
+def _views(nviews=VIEWS):
+    cams = [synthetic.scene_camera(W, view=v) for v in range(nviews)]
+    dCs = [synthetic.make_dC(W, H, 100 + v) for v in range(nviews)]
     return cams, dCs
+
+
+def _worker_uneven(rank, world, port, out, nviews, kind):
+    """unequal shares: every rank must post the same collectives whatever its own view count is"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cams, dCs = _views(nviews)
+        r = {"plain": OracleViewRenderer, "split": OracleSplitRenderer, "pipelined": OraclePipelinedSplitRenderer}[kind]()
+        flat = D.multi_view_step(r, cams, dCs, overlap=True, pipeline=True)
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        if rank == world - 1:
+            np.save(out, flat.numpy())
+    finally:
+        dist.destroy_process_group()
 
 
 def _worker(rank, world, port, out):
@@ -186,3 +211,20 @@ def test_two_rank_gloo_segment_allreduce_equals_one_allreduce(tmp_path):
     assert np.array_equal(a[11 * N:], b[11 * N:])                        # the Δshs segment: the same two-rank sums
     assert np.allclose(a[:11 * N], b[:11 * N], rtol=1e-13, atol=1e-15)   # the split renderer forms the geometry part as (x + g) - x + ...
     assert np.abs(a).max() > 0
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("nviews,kind", [(3, "split"), (3, "pipelined"), (3, "plain"), (1, "split"), (1, "pipelined")])
+def test_two_rank_gloo_unequal_shares_post_matching_collectives(tmp_path, nviews, kind):
+    """3 views on 2 ranks (shares 2 + 1: one rank would pipeline, the other split its only view) and fewer views than ranks
+    (shares 1 + 0): ADVICE round 3 -- the old code chose its collectives from the rank's own share and gloo aborted with a size
+    mismatch.  The result must be the plain sum over all views on every rank."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "flat_u.npy")
+    mp.spawn(_worker_uneven, args=(2, port, out, nviews, kind), nprocs=2, join=True)
+    cams, dCs = _views(nviews)
+    single = OracleViewRenderer()
+    D.multi_view_step(single, cams, dCs)
+    got, want = np.load(out), single.flat.numpy()
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
+    assert np.abs(got).max() > 0

@@ -1,0 +1,150 @@
+"""The product's DEFAULT configuration against the LITERAL reference arithmetic at the stated sizes.
+
+The reference composites every list entry (src/splat.jl:224-261: no transmittance cut, no alpha cut, no cull) and never
+normalises a quaternion (src/projection.jl:126).  tests/test_gpu_sizes.py compares the HIP path with an oracle that shares
+its early-out rule (t_min = 1e-5); here the checker is the oracle run with t_min = 0 -- every entry of every list evaluated --
+while the HIP path keeps its defaults (t_min = 1e-5, alpha_cull on, launch orders, speculative lists).  What the early-out
+cuts is bounded by t_min * sum |rgb| per pixel, far inside the pixel tolerance 1e-4 + 1e-4 |x|; this file measures it.
+
+  (a) C3 (1 M, 1920x1080, SH3) forward: pixels and transmittance vs the literal oracle;
+      C2 (100 k, 800x800, SH3) gradients vs the literal adjoint (rel-L2 <= 1e-3).
+  (c) un-normalised quaternions, |q| log-uniform in [0.7, 1.4], at the FULL C2 size: preprocess arrays and lists bit-exact,
+      pixels, gradients (incl. the radial part of dL/dq).
+  (d) the viewer export (src/examples/main.jl:35-45: NaN scrub, clamp, N0f8, imrotate) of a RENDERED image equals the
+      same export of the oracle's image up to the N0f8 rounding of pixels that differ within the pixel tolerance.
+(b), the C5 forward over all 32 400 tiles, lives in tests/test_gpu_sizes.py next to the C5 gradients.
+
+Measured errors are merged into gpurun_out/parity_sizes.json.
+"""
+import numpy as np
+import pytest
+
+from common import hip_context, rel_l2, scene_and_cameras
+from test_gpu_sizes import GRAD_REL_L2, GRADS, _pix_err, _report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(1500)
+def test_c3_default_config_against_literal_reference_forward(oracle):
+    """HIP defaults (early-out 1e-5, no-op cull) vs splatDraw as written: all 30 M list entries evaluated by the oracle."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = synthetic.CONFIGS["C3"]
+    seed = 1234 + list(synthetic.CONFIGS).index("C3")
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=0.0, omp=True)
+    ctx = hip_context(sc, cam, T, P, W, H, deg)                              # every default of gs_default_config
+    assert abs(ctx.cfg.t_min - 1e-5) < 1e-12 and ctx.cfg.alpha_cull == 1
+    ctx.preprocess(); ctx.bin()
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ref["ranges"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ref["ids"])
+    img, tr = ctx.forward_host()
+    e_img, e_tr = _pix_err(img, ref["image"]), _pix_err(tr, ref["trans"])
+    wc = ctx.work_counters_ex()
+    _report("C3_default_vs_literal_forward", dict(pixel_err_over_tol=e_img, trans_err_over_tol=e_tr, max_abs_pixel_diff=float(np.abs(img - ref["image"]).max()),
+                                                  max_abs_trans_diff=float(np.abs(tr - ref["trans"]).max()), instances=int(ctx.num_instances),
+                                                  walked_fwd=wc["walked_fwd"], evaluated_fwd=wc["evaluated_fwd"]))
+    assert wc["walked_fwd"] < ctx.num_instances                               # the early-out really cut the walk
+    assert e_img <= 1.0 and e_tr <= 1.0, (e_img, e_tr)
+    ctx.close()
+
+
+@pytest.mark.timeout(900)
+def test_c2_default_config_gradients_against_literal_adjoint(oracle):
+    """C2 fwd+bwd: HIP defaults vs the adjoint of the literal forward (t_min = 0: every entry in the chain)."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = synthetic.CONFIGS["C2"]
+    seed = 1234 + list(synthetic.CONFIGS).index("C2")
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=0.0, omp=True)
+    dC = synthetic.make_dC(W, H, seed + 1)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC,
+                      t_min=0.0, omp=True)
+    rep = {}
+    for det in (False, True):
+        ctx = hip_context(sc, cam, T, P, W, H, deg, deterministic=det)
+        ctx.preprocess(); ctx.bin()
+        assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), ref["keys"])
+        img, tr = ctx.forward_host()
+        e_img, e_tr = _pix_err(img, ref["image"]), _pix_err(tr, ref["trans"])
+        assert e_img <= 1.0 and e_tr <= 1.0, (e_img, e_tr)
+        g = ctx.grads_alloc(); ctx.backward(dC, g)
+        got = ctx.grads_read(g, deg)
+        errs = {k: rel_l2(got[k].reshape(-1), gref[k].reshape(-1)) for k in GRADS}
+        rep["deterministic" if det else "float_atomics"] = dict(pixel_err_over_tol=e_img, trans_err_over_tol=e_tr, grad_rel_l2=errs)
+        for k in GRADS:
+            assert errs[k] <= GRAD_REL_L2, (k, errs[k], det)
+        ctx.close()
+    _report("C2_default_vs_literal_adjoint", rep)
+
+
+@pytest.mark.timeout(900)
+def test_unnormalised_quaternions_at_full_c2_size(oracle):
+    """projection.jl:126 never normalises q; |q| log-uniform in [0.7, 1.4] scales every footprint by up to |q|^4 = 3.8 in area.
+    At 100 k gaussians / 800x800 / SH3: the nine preprocess arrays and the lists bit-exact, pixels, gradients."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = synthetic.CONFIGS["C2"]
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 4242)
+    rng = np.random.default_rng(4243)
+    norm = np.exp(rng.uniform(np.log(0.7), np.log(1.4), n)).astype(np.float32)
+    sc["quats"] = (sc["quats"] * norm[:, None]).astype(np.float32)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, export_debug=True)
+    ctx.preprocess()
+    for name, which in (("ts", B.ARR_TS), ("tps", B.ARR_TPS), ("cov3d", B.ARR_COV3D), ("cov2d", B.ARR_COV2D), ("invcov", B.ARR_INVCOV),
+                        ("bbs", B.ARR_BBS), ("mu", B.ARR_MU)):
+        got = ctx.get_array(which)
+        assert np.array_equal(got, ref["pre"][name].reshape(got.shape), equal_nan=True), name
+    ctx.bin()
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), ref["ranges"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), ref["ids"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), ref["keys"])
+    img, tr = ctx.forward_host()
+    e_img, e_tr = _pix_err(img, ref["image"]), _pix_err(tr, ref["trans"])
+    assert e_img <= 1.0 and e_tr <= 1.0, (e_img, e_tr)
+    dC = synthetic.make_dC(W, H, 4244)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC,
+                      t_min=1e-5, omp=True)
+    g = ctx.grads_alloc(); ctx.backward(dC, g)
+    got = ctx.grads_read(g, deg)
+    errs = {k: rel_l2(got[k].reshape(-1), gref[k].reshape(-1)) for k in GRADS}
+    q = sc["quats"].astype(np.float64)
+    rad_ref = (q * gref["quats"]).sum(1) / np.linalg.norm(q, axis=1)
+    rad_got = (q * got["quats"].astype(np.float64)).sum(1) / np.linalg.norm(q, axis=1)
+    errs["quats_radial"] = rel_l2(rad_got, rad_ref)
+    _report("C2_unnormalised_quaternions", dict(instances=int(ctx.num_instances), pixel_err_over_tol=e_img, trans_err_over_tol=e_tr, grad_rel_l2=errs))
+    assert np.linalg.norm(rad_ref) > 0.05 * np.linalg.norm(gref["quats"])      # the radial part is really there
+    for k, e in errs.items():
+        assert e <= GRAD_REL_L2, (k, e)
+    ctx.close()
+
+
+def test_viewer_export_of_a_rendered_image(oracle):
+    """SURVEY 8(f).4, examples/main.jl:35-45 on the renderer's own output: to_rgb8(renderer.imageData) against to_rgb8 of the
+    oracle's image.  A pixel whose two fp32 values straddle a rounding boundary of N0f8 may differ by ONE level; every
+    other byte must be equal, and the layout (W rows x H columns, rotated by +90 degrees) must be the reference's."""
+    from gaussiansplat_amd import export, renderer as R, synthetic
+    O = oracle
+    n, W, H, deg = 20_000, 416, 240, 3
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 606)
+    sc["shs"][:, 0, :] += np.float32(0.8)                                     # colours on both sides of the [0, 1] clamp
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5)
+    r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, sc)
+    tps = R.preprocess(r, cam); R.compactIdxs(r); R.forward(r, tps)
+    got = export.to_rgb8(r.imageData)
+    want = export.to_rgb8(ref["image"])
+    assert got.shape == want.shape == (H, W, 3) and got.dtype == np.uint8      # rot90 of Julia's [W, H]: H rows, W columns
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1
+    # the bytes that differ are exactly pixels sitting on an N0f8 rounding boundary within the pixel tolerance
+    img = np.clip(np.nan_to_num(ref["image"], nan=0.0), 0.0, 1.0) * 255.0
+    frac = np.abs(img - np.floor(img) - 0.5)                                   # distance to the boundary, in levels
+    julia = np.rot90(np.transpose(frac, (2, 1, 0)), 1, (0, 1))
+    assert np.all(julia[d > 0] <= 255.0 * 2.1e-4)
+    assert (d > 0).mean() < 1e-3
+    assert want.min() == 0 and want.max() == 255                              # both clamps were exercised
+    # unrotated: Julia's own array order [W rows, H columns]
+    assert export.to_rgb8(r.imageData, rotate=False).shape == (W, H, 3)

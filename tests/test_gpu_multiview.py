@@ -28,7 +28,7 @@ def _setup():
     return r, cams, dCs
 
 
-def _worker(rank, world, port, overlap, out):
+def _worker(rank, world, port, overlap, pipeline, nviews, out):
     import torch
     import torch.distributed as dist
     from gaussiansplat_amd import distributed as D
@@ -37,9 +37,10 @@ def _worker(rank, world, port, overlap, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         r, cams, dCs = _setup()
+        cams, dCs = cams[:nviews], dCs[:nviews]
         hv = D.HipViewRenderer(r)
-        for _ in range(2):                                              # twice: the second step runs on view-slot history and speculative lists
-            flat = D.multi_view_step(hv, cams, dCs, overlap=overlap)
+        for _ in range(2):                                              # twice: the first step overwrites lazily (resetGrads), the second runs on view-slot history and speculative lists
+            flat = D.multi_view_step(hv, cams, dCs, overlap=overlap, pipeline=pipeline)
         torch.cuda.synchronize()
         if rank == 0:
             np.save(out, flat.cpu().numpy())
@@ -52,19 +53,27 @@ def _worker(rank, world, port, overlap, out):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_ranks_equal_the_sequential_batch_bitwise(tmp_path, overlap):
+@pytest.mark.parametrize("overlap,pipeline,nviews", [
+    (True, True, 8),       # four views per rank, pipelined: ONE all-reduce
+    (False, True, 8),      # the same with overlap off: ONE all-reduce
+    (True, False, 8),      # four views per rank one after the other, the LAST in two steps: Δshs segment all-reduced (async) behind the SH
+                           # kernel beside the geometry chain, then the geometry segment -- the split path on GPU tensors
+    (True, True, 2),       # one view per rank (the 8-GPU shape): the split path on a rank's ONLY view, incl. the lazy overwrite of step 1
+    (True, True, 3),       # shares 2 + 1: one rank pipelines, the other splits -- both post the same two segment all-reduces
+])
+def test_two_ranks_equal_the_sequential_batch_bitwise(tmp_path, overlap, pipeline, nviews):
     import torch
     import torch.multiprocessing as mp
     from gaussiansplat_amd import distributed as D
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "flat2.npy")
-    mp.spawn(_worker, args=(2, port, overlap, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, overlap, pipeline, nviews, out), nprocs=2, join=True)
     got = np.load(out)
     r, cams, dCs = _setup()
+    cams, dCs = cams[:nviews], dCs[:nviews]
     hv = D.HipViewRenderer(r)
     parts = []
-    for share in (D.shard_views(VIEWS, 2, 0), D.shard_views(VIEWS, 2, 1)):
+    for share in (D.shard_views(nviews, 2, 0), D.shard_views(nviews, 2, 1)):
         D.multi_view_step(hv, [cams[v] for v in share], [dCs[v] for v in share])       # world 1: accumulates the share's views in order
         torch.cuda.synchronize()
         parts.append(hv.flat.clone())
