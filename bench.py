@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--rank-mode", type=int, default=1, help="radix-sort stable ranks (depth sort): 1 wave64 ballots (default), 0 LDS atomic-add-return (probed at gs_create)")
     ap.add_argument("--schedule", type=int, default=0, help="gs_config.schedule (0 = library default = 3; 1 = tile order; 4 = forward by the previous frame when its slot has no history)")
     ap.add_argument("--no-view-slots", action="store_true", help="do not name view slots (the forward then launches in tile order)")
+    ap.add_argument("--list-cap", type=int, default=0, help="gs_config.list_cap: 0 automatic (tile lists written as far as the view slot's previous frame walked them), 1 never, 2 also on small grids")
     ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
     ap.add_argument("--settle-frames", type=int, default=24, help="untimed frames per rank the timed pass's renderer runs BEFORE its W warm-up "
                     "steps (0: none; the same count on every rank).  A fresh renderer's first ~20 frames run up to 4 %% slower than its "
@@ -234,6 +235,19 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    devices = None
+    if world > 1:
+        # which physical device every rank sits on (PCI bus id): a launcher that maps two ranks onto one GPU would still "scale" on paper
+        pr = torch.cuda.get_device_properties(local)
+        me = {"rank": rank, "local_rank": local, "name": pr.name,
+              "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xFF, getattr(pr, "pci_device_id", 0)),
+              "uuid": str(getattr(pr, "uuid", ""))}
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
+        ids = [(d["pci"], d["uuid"]) for d in devices]
+        if len(set(ids)) != world and os.environ.get("GS_BENCH_SINGLE_DEVICE") != "1":
+            raise SystemExit(f"bench.py --gpus {world}: two ranks share a device {ids}; one process per GPU is the contract")
+
     n, W, H, deg = synthetic.CONFIGS[args.config]
     seed = 1234 + list(synthetic.CONFIGS).index("C3" if args.config == "C4" else args.config)     # C4 = C3's scene, eight views
     scene = synthetic.make_scene(n, W, H, deg, seed=seed)
@@ -258,16 +272,19 @@ def main():
 
     def make(t_min, profile_stages):
         return R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene, device=local, order=args.order, t_min=t_min,
-                             profile_stages=profile_stages, alpha_cull=not args.no_cull, rank_mode=args.rank_mode, schedule=args.schedule)
+                             profile_stages=profile_stages, alpha_cull=not args.no_cull, rank_mode=args.rank_mode, schedule=args.schedule,
+                             list_cap=args.list_cap)
 
     sync_mode = [args.grad_sync]                                                # the exchange `step` uses (N > 1)
+
+    exchange_on = [True]                                                        # False: the same step without its collectives (compute_ms)
 
     def step(r, k):
         """one step = one view batch: this rank's views one after the other (gradients accumulate), then the exchange"""
         batch = batches[k % len(batches)]
         hv = r.__dict__.setdefault("_bench_hv", D.HipViewRenderer(r, args.pipeline_depth))            # (cycle r <-> hv: collected by gc below)
         D.multi_view_step(hv, [cams[v] for v in batch], [dCs[v] for v in batch], sync=sync_mode[0], overlap=not args.no_overlap,
-                          pipeline=not args.no_pipeline)
+                          pipeline=not args.no_pipeline, exchange=exchange_on[0])
 
     def stage_stats(r, reset=False):
         """per-stage hipEvent sums of every ctx the renderer's views ran through (the pipelined view batches use two more)"""
@@ -337,6 +354,7 @@ def main():
     I = lctx.num_instances
     I1 = lctx.num_coarse_instances
     wc = lctx.work_counters_ex()
+    ls = lctx.list_stats()
     wf, wb = wc["walked_fwd"], wc["walked_bwd"]
     value = views_per_step * n * args.steps / dt / 1e6
     nranks = dist.get_world_size() if world > 1 else 1
@@ -351,6 +369,58 @@ def main():
                          "floats + all-gather of 3N colour-gradient floats per view, rebuilt into the SH gradient locally"}
         sync_mode[0] = head
     factored = world > 1 and args.grad_sync == "factored"
+    split_record = None
+    if world > 1:
+        # So that a shortfall against DESIGN.md's prediction can be split into compute and exchange from this one line:
+        # (a) compute_ms -- the same K steps with every collective left out (per rank, and the slowest rank);
+        # (b) exchange_ms -- the collectives of a step alone on the final gradient buffer, back to back, timed with events on the
+        #     stream they are posted on: the flat all-reduce of 59 N floats, and the colour-factored pair (all-reduce of 11 N floats +
+        #     all-gather of 3 N floats per view).  ms_per_step - compute_ms is what the exchange costs INSIDE a step (it partly
+        #     overlaps the geometry chain); exchange_ms is what it costs alone.
+        exchange_on[0] = False
+        kc = max(2, min(args.steps, 10))
+        t_c = timed(r, kc, 2) / kc * 1e3                                 # (MAX over ranks)
+        exchange_on[0] = True
+        mine_c = torch.tensor([0.0], dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        exchange_on[0] = False
+        for k in range(kc):
+            step(r, k)
+        torch.cuda.synchronize()
+        exchange_on[0] = True
+        mine_c[0] = (time.perf_counter() - t0) / kc * 1e3
+        per_rank = [torch.zeros_like(mine_c) for _ in range(world)]
+        dist.all_gather(per_rank, mine_c)
+        hvb = r._bench_hv
+        flat = hvb.flat
+        geo = hvb.geometry_floats
+        vpr = views_per_step // world
+        slots = torch.zeros((vpr, n, 3), dtype=torch.float32, device="cuda")
+        allc = torch.empty(world * slots.numel(), dtype=torch.float32, device="cuda")
+
+        def ev_time(fn, reps=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        ex_flat = ev_time(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM))
+        ex_two = ev_time(lambda: (dist.all_reduce(flat[geo:], op=dist.ReduceOp.SUM), dist.all_reduce(flat[:geo], op=dist.ReduceOp.SUM)))
+        ex_fact = ev_time(lambda: (dist.all_reduce(flat[:geo], op=dist.ReduceOp.SUM), dist.all_gather_into_tensor(allc, slots.reshape(-1))))
+        split_record = {"compute_ms": t_c, "compute_ms_by_rank": [float(x.item()) for x in per_rank], "compute_steps": kc,
+                        "exchange_ms": {"allreduce_flat_59N": ex_flat, "allreduce_two_segments": ex_two, "factored_allreduce_11N_plus_allgather": ex_fact},
+                        "exchange_bytes": {"allreduce_flat_59N": int(flat.numel()) * 4, "factored": int(geo) * 4 + int(slots.numel()) * 4 * world},
+                        "note": "compute_ms: the K steps of the headline with every collective left out (max over ranks; per rank beside it).  "
+                                "exchange_ms: the step's collectives alone on the final buffers, ten back to back between events on the posting stream "
+                                "(max over ranks).  ms_per_step - compute_ms = what the exchange adds inside a step."}
+        del slots, allc
 
     out = None
     if rank == 0:
@@ -402,10 +472,12 @@ def main():
                        "pipeline": (not args.no_pipeline) if views_per_step // world > 1 else None,
                        "grad_sync": args.grad_sync if world > 1 else None, "allreduce_overlap": (not args.no_overlap) if world > 1 else None,
                        "backend": args.backend if world > 1 else None,
+                       "rccl_ranks": nranks if (world > 1 and args.backend == "nccl") else None, "devices": devices,
                        "rank_mode": int(r.ctx.cfg.rank_mode), "binning_rounds": lctx.num_rounds, "schedule": int(r.ctx.cfg.schedule) or 3,
                        "view_slots": not args.no_view_slots,
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
                        "instances": I, "coarse_instances": I1, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
+                       "list_cap": args.list_cap, "lists_capped": ls["capped"], "listed_entries": ls["listed"], "list_segments_appended_by_waves": ls["extended_segments"],
                        "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "counters_of": "the last view rendered",
                        "seed": seed},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -423,6 +495,9 @@ def main():
         out["roofline"]["loop_cost"] = loop_cost_model(dom, dom_ms, wc["evaluated_bwd"] if dom == "composite_bwd" else wc["evaluated_fwd"])
         if other:
             out["factored_exchange" if other["grad_sync"] == "factored" else "allreduce_exchange"] = other
+        if split_record:
+            out.update({"compute_ms": split_record["compute_ms"], "exchange_ms": split_record["exchange_ms"]})
+            out["compute_exchange_split"] = split_record
     extras = world == 1 and views_per_step == 1
     if extras and not args.no_c4_anchor and args.config == "C3":
         # the N = 1 anchor of the C4 scaling curve, in the same run: the 8-view batch on one GPU, gradients accumulating

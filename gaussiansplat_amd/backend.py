@@ -28,12 +28,14 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_backward", "gs_backward_ex", "gs_reset_grads", "gs_loss_l1_dssim", "gs_sgd_step", "gs_comm_unique_id",
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
-           "gs_debug_tile_clock", "gs_debug_clock_mhz", "gs_rank_probe_result", "gs_num_rounds", "gs_set_view_slot", "gs_num_coarse_instances")
+           "gs_debug_tile_clock", "gs_debug_clock_mhz", "gs_rank_probe_result", "gs_num_rounds", "gs_set_view_slot", "gs_num_coarse_instances",
+           "gs_get_list_stats")
 
-GS_ABI_VERSION = 2          # include/gsplat.h; load() refuses a library that reports another version
+GS_ABI_VERSION = 3          # include/gsplat.h; load() refuses a library that reports another version
 GS_DEBUG_WIDE_CURSORS = 1
 GS_DEBUG_ALWAYS_ORDER = 2     # launch orders + side stream also on small frames (tests)
-GS_MAX_VIEW_SLOTS = 64
+GS_DEBUG_TINY_CAPS = 4        # capped lists with the minimum cap on every tile (tests: every busy tile extends its list in the composite kernel)
+GS_MAX_VIEW_SLOTS = 4096
 
 
 class GsConfig(C.Structure):
@@ -41,7 +43,7 @@ class GsConfig(C.Structure):
                 ("deterministic", C.c_int32), ("export_debug", C.c_int32), ("profile_stages", C.c_int32),
                 ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("alpha_cull", C.c_int32), ("schedule", C.c_int32),
                 ("slab_mode", C.c_int32), ("slab_max_ratio", C.c_float), ("slab_fractions", C.c_float * 3), ("debug_flags", C.c_int32),
-                ("depth_sort", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("depth_sort", C.c_int32), ("list_cap", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class GsGrads(C.Structure):
@@ -118,6 +120,7 @@ def load():
     L.gs_num_rounds.argtypes = [vp]
     L.gs_set_view_slot.argtypes = [vp, C.c_int32]
     L.gs_num_coarse_instances.argtypes = [vp]; L.gs_num_coarse_instances.restype = C.c_int64
+    L.gs_get_list_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     if L.gs_abi_version() != GS_ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} has ABI version {L.gs_abi_version()}, this binding is written for {GS_ABI_VERSION}: "
                            "rebuild with `python -m gaussiansplat_amd.build --force`")
@@ -137,9 +140,10 @@ class Context:
     def __init__(self, device: int = 0, order: int = ORDER_DEPTH_DESC, t_min: float = 1e-5, export_debug: bool = False,
                  profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 1,
                  alpha_cull: bool = True, schedule: int = 0, slab_mode: int = 1, slab_fractions=(), slab_max_ratio: float = 0.0,
-                 debug_flags: int = 0, depth_sort: int = 0, cfg: "GsConfig | None" = None):
+                 debug_flags: int = 0, depth_sort: int = 0, list_cap: int = 0, cfg: "GsConfig | None" = None):
         """schedule 0 = the library default (3); slab_fractions / slab_max_ratio / debug_flags: gs_config fields for tests;
-        depth_sort 0 automatic, 1 the four-pass radix sort, 2 always key-range buckets + LDS (same permutation).
+        depth_sort 0 automatic, 1 the four-pass radix sort, 2 always key-range buckets + LDS (same permutation);
+        list_cap 0 automatic (tile lists written as far as the view slot's previous frame walked them), 1 never, 2 also on small grids.
         cfg: a complete gs_config to copy instead (every field: a second ctx that must take the same code paths as the first)."""
         self.L = load()
         if cfg is not None:
@@ -161,6 +165,7 @@ class Context:
             cfg.slab_fractions[i] = float(f)
         cfg.debug_flags = int(debug_flags)
         cfg.depth_sort = int(depth_sort)
+        cfg.list_cap = int(list_cap)
         cfg.order, cfg.t_min = int(order), float(t_min)
         cfg.export_debug, cfg.profile_stages, cfg.deterministic = int(export_debug), int(profile_stages), int(deterministic)
         cfg.bin_path, cfg.rank_mode, cfg.alpha_cull = int(bin_path), int(rank_mode), int(alpha_cull)
@@ -386,16 +391,23 @@ class Context:
         self._chk(self.L.gs_get_work_counters_ex(self.h, o))
         return dict(walked_fwd=int(o[0]), walked_bwd=int(o[1]), evaluated_fwd=int(o[2]), evaluated_bwd=int(o[3]))
 
+    def list_stats(self) -> dict:
+        """entries written into the tile lists of the last frame, list segments appended by composite waves, capped or not"""
+        o = (C.c_int64 * 3)()
+        self._chk(self.L.gs_get_list_stats(self.h, o))
+        return dict(listed=int(o[0]), extended_segments=int(o[1]), capped=bool(o[2]))
+
     def time_composite(self, which: int, variant: int, reps: int = 10) -> float:
         ms = C.c_float()
         self._chk(self.L.gs_debug_time_composite(self.h, which, variant, reps, C.byref(ms)))
         return float(ms.value)
 
     def tile_clock(self, which: int, variant: int = 0) -> np.ndarray:
-        """[ntiles, 6] uint64 per tile {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, walked << 32 | evaluated, shader cycles
-        inside the per-entry loops, shader cycles outside them} of one composite launch (which: 0 forward, 1 backward)."""
+        """[ntiles, 8] uint64 per tile {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, walked << 32 | evaluated, shader cycles
+        inside the per-entry loops, shader cycles outside them, strip slots executed << 32 | slots with live pixels packed,
+        strips with a live pixel << 32 | live pixels} of one composite launch (which: 0 forward, 1 backward)."""
         ntiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-        out = np.zeros((ntiles, 6), np.uint64)
+        out = np.zeros((ntiles, 8), np.uint64)
         self._chk(self.L.gs_debug_tile_clock(self.h, which, variant, C.c_void_p(out.ctypes.data)))
         return out
 

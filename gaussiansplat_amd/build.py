@@ -1,11 +1,11 @@
 """Build libgsplat_hip.so in-tree with hipcc for gfx950 (no CMake, no JIT cache).
 
-    python -m gaussiansplat_amd.build [--force] [--experiments]
+    python -m gaussiansplat_amd.build [--force] [--tag NAME -DMACRO=... ...]
 
---experiments builds lib_exp/libgsplat_hip.so with -DGS_EXPERIMENTS: the kernel variants and schedules that lost their A/B
-(persistent ticket queues, the round-1 reduction tree, the software-pipelined backward, the 64-VGPR forward) and the
-environment switches of tools/abtest.py; load it with GSPLAT_HIP_LIB=.../lib_exp/libgsplat_hip.so.  The default library
-contains none of them.
+--tag NAME builds lib_NAME/libgsplat_hip.so with the given -D macros (e.g. --tag seg1k -DL2_SEG=1024): a variant for a same-box
+A/B run, loaded with GSPLAT_HIP_LIB=.../lib_NAME/libgsplat_hip.so (tools/ab_libs.sh).  The kernel variants that lost their A/B
+in rounds 1-3 (persistent ticket queues, the reduction tree, the software-pipelined backward, the 64-VGPR forward) and their
+environment switches are no longer in the tree: profiles/HISTORY.md names the commit that last had them.
 
 The preprocess translation unit is compiled with -ffp-contract=off (numeric spec: tile ids
 and depth keys must be bit-identical to the CPU oracle); the composite kernels keep hipcc's
@@ -34,6 +34,10 @@ SOURCES = {
     "gs_composite.hip": [],
     "gs_loss.hip": [],
     "gs_api.hip": [],
+    "gs_api_bin.hip": [],
+    "gs_api_composite.hip": [],
+    "gs_api_comm.hip": [],
+    "gs_api_debug.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
@@ -51,17 +55,15 @@ def _deps() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def build(force: bool = False, verbose: bool = False, experiments: bool = False, tag: str = "", defines=()) -> str:
+def build(force: bool = False, verbose: bool = False, tag: str = "", defines=()) -> str:
     """tag / defines: a variant build for same-box A/B runs (e.g. tag="p48", defines=["-DGS_PAYLOAD_QUADS=3"] -> lib_p48/)."""
-    out_dir = os.path.join(HERE, "lib_" + tag) if tag else os.path.join(HERE, "lib_exp") if experiments else OUT_DIR
+    out_dir = os.path.join(HERE, "lib_" + tag) if tag else OUT_DIR
     lib = os.path.join(out_dir, "libgsplat_hip.so")
     os.makedirs(out_dir, exist_ok=True)
     hipcc = _hipcc()
     hdr_time = _deps()
     objs, jobs = [], []
     for src, extra in SOURCES.items():
-        if experiments:
-            extra = [*extra, "-DGS_EXPERIMENTS"]
         extra = [*extra, *defines]
         s = os.path.join(CSRC, src)
         o = os.path.join(out_dir, src.replace(".hip", ".o"))
@@ -87,5 +89,5 @@ def build(force: bool = False, verbose: bool = False, experiments: bool = False,
 
 if __name__ == "__main__":
     tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else ""
-    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv, tag=tag,
+    print(build(force="--force" in sys.argv, verbose=True, tag=tag,
                 defines=[a for a in sys.argv[1:] if a.startswith("-D")]))

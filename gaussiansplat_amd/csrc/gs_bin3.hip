@@ -23,7 +23,6 @@
 // HBM traffic per instance: the 4-byte id written once (+ 6 B per COARSE instance written and read twice), against
 // 16 B per instance for gs_bin2.hip.  The tile ranges are the exclusive scan of the level-2 hit counts.
 #include "gs_common.h"
-#include <stdlib.h>
 
 #define SB 8                 // super-tile edge in tiles
 #define SB_SHIFT 3
@@ -34,17 +33,13 @@
 #define L2_THREADS 256
 
 int gs_bin3_sb_shift() { return SB_SHIFT; }
+int gs_bin3_seg() { return L2_SEG; }
 int64_t gs_bin3_max_work(int64_t coarse_instances, int ns) { return coarse_instances / L2_SEG + ns; }
 // list positions per level-1 workgroup: the bitmap (ns x G bits), its word prefix (ns x G/32 u16), 2 ns starts and the
 // staging buffer (24 G bytes) share LDS
 static size_t l1_lds_bytes(int ns, int g) { return (size_t)ns * (g / 8 + g / 16 + 8) + 24 * (size_t)g; }
 int gs_bin3_group(int ns) {
     int g = 512;                                          // measured at C3 (135 super-tiles): 1024 -> 67 us, 512 -> 60 us, 256 -> 64 us for level 1
-#ifdef GS_EXPERIMENTS
-    static int forced = -1;                               // GS_L1_G, read once per process
-    if (forced < 0) { const char *e = getenv("GS_L1_G"); const int v = e ? atoi(e) : 0; forced = (v == 256 || v == 512 || v == 1024) ? v : 0; }
-    if (forced) g = forced;
-#endif
     while (g > 256 && l1_lds_bytes(ns, g) > 72 * 1024) g >>= 1;
     return g;
 }
@@ -424,14 +419,49 @@ __global__ __launch_bounds__(L2_THREADS) void l2_count_kernel(GsBin3Args a) {
     }
 }
 
+// Capped lists (GsBin3Args.cap_src): one wave per super-tile, lane = local tile.  A tile takes the entries of the segments of its
+// super-tile's list in order until it holds gs_list_cap(walked by the slot's previous forward) of them; tile_nopen = how many
+// segments that is, tile_ext = {entries those segments give it (l2_ranges adds the list start), coarse index of the first segment it
+// does NOT take or GS_CONT_NONE when it takes them all}, smax = the largest tile_nopen of the super-tile.  The lists themselves
+// (positions, order, ranges) are those of the uncapped path: only fewer of their entries are written.
+__global__ __launch_bounds__(GS_WAVE) void l2_cap_kernel(GsBin3Args a) {
+    if (lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;
+    const int S = blockIdx.x, lane = threadIdx.x;
+    uint32_t w0 = 0;                                           // first work item of S: segments of the super-tiles before it
+    for (int b = 0; b < S; b += GS_WAVE) {
+        const int s = b + lane;
+        if (s < S) { const uint2 cr = reinterpret_cast<const uint2 *>(a.cranges)[s]; w0 += (cr.y - cr.x + (L2_SEG - 1)) / L2_SEG; }
+    }
+#pragma unroll
+    for (int d = GS_WAVE / 2; d > 0; d >>= 1) w0 += (uint32_t)__shfl_xor((int)w0, d);
+    const uint2 cr = reinterpret_cast<const uint2 *>(a.cranges)[S];
+    const uint32_t nseg = (cr.y - cr.x + (L2_SEG - 1)) / L2_SEG;
+    const int tx = (S % a.sgx) * SB + (lane & (SB - 1)), ty = (S / a.sgx) * SB + (lane >> SB_SHIFT);
+    const bool in = tx < a.gx && ty < a.gy;
+    const int t = ty * a.gx + tx;
+    const uint32_t cap = in ? gs_list_cap(a.cap_src[t]) : 0u;
+    uint32_t run = 0, k = 0;
+    for (; k < nseg && run < cap; ++k) run += a.segcnt[(size_t)(w0 + k) * (SB * SB) + lane];       // 256 coalesced bytes per segment
+    uint32_t m = in ? k : 0u;
+#pragma unroll
+    for (int d = GS_WAVE / 2; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if (lane == 0) a.smax[S] = m;
+    if (S == 0 && lane == 0 && a.ext_count) *a.ext_count = 0u;
+    if (in) {
+        a.tile_nopen[t] = k;
+        a.tile_ext[t] = make_uint2(run, k < nseg ? cr.x + k * L2_SEG : GS_CONT_NONE);
+    }
+}
+
 // tile ranges = exclusive scan of the tile counts in tile order (one workgroup); completed tiles get an empty range
+// ext (capped lists): on entry ext[t].x = entries written for tile t, on exit the entry index where its written list ends
 __global__ __launch_bounds__(1024) void l2_ranges_kernel(const uint32_t *__restrict__ tilecnt, int ntiles, const uint8_t *__restrict__ done,
                                                           uint32_t *__restrict__ ranges, const uint32_t *__restrict__ totals, uint32_t cap_coarse,
-                                                          uint32_t cap_fine) {
+                                                          uint32_t cap_fine, uint2 *__restrict__ ext) {
     __shared__ uint32_t sm[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (lists_overflow(totals, cap_coarse, cap_fine)) {                  // nothing was listed: every range empty
-        for (int t = tid; t < ntiles; t += 1024) { ranges[2 * t] = 0; ranges[2 * t + 1] = 0; }
+        for (int t = tid; t < ntiles; t += 1024) { ranges[2 * t] = 0; ranges[2 * t + 1] = 0; if (ext) ext[t] = make_uint2(0u, GS_CONT_NONE); }
         return;
     }
     uint32_t carry = 0;
@@ -454,7 +484,7 @@ __global__ __launch_bounds__(1024) void l2_ranges_kernel(const uint32_t *__restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int t = b0 + tid * 4 + k;
-            if (t < ntiles) { ranges[2 * t] = off; ranges[2 * t + 1] = off + v[k]; }
+            if (t < ntiles) { ranges[2 * t] = off; ranges[2 * t + 1] = off + v[k]; if (ext) ext[t].x += off; }
             off += v[k];
         }
         carry += all;
@@ -492,6 +522,8 @@ __global__ __launch_bounds__(L2W_THREADS) void l2_write_kernel(GsBin3Args a) {
     int S; uint32_t e0, e1, w0;
     if (lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;
     if (!find_work<L2W_THREADS>(a, sh, S, e0, e1, w0)) return;
+    const uint32_t kseg = blockIdx.x - w0;                  // this work item's segment of the super-tile's list
+    if (a.tile_nopen && kseg >= a.smax[S]) return;          // capped lists: no tile of the super-tile takes entries this deep
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ox = (S % a.sgx) * SB, oy = (S / a.sgx) * SB;
     const int cnt = (int)(e1 - e0);
@@ -520,7 +552,8 @@ __global__ __launch_bounds__(L2W_THREADS) void l2_write_kernel(GsBin3Args a) {
     }
     if (wv == 0) {                                         // tiles outside the grid or completed in an earlier round take nothing
         const int tx = ox + (lane & (SB - 1)), ty = oy + (lane >> SB_SHIFT);
-        const bool dead = tx >= a.gx || ty >= a.gy || (a.done && a.done[ty * a.gx + tx]);
+        const bool dead = tx >= a.gx || ty >= a.gy || (a.done && a.done[ty * a.gx + tx]) ||
+                          (a.tile_nopen && kseg >= a.tile_nopen[ty * a.gx + tx]);       // (|| short-circuits: tiles outside the grid are not looked up)
         const unsigned long long b = __ballot(dead);
         if (lane == 0) { sdead[0] = (uint32_t)b; sdead[1] = (uint32_t)(b >> 32); }
     }
@@ -621,8 +654,15 @@ hipError_t gs_bin3_l1_scatter(const GsBin3L1 &b, hipStream_t s) {
 
 hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s) {
     if (a.max_work <= 0) return hipSuccess;
-    hipLaunchKernelGGL(l2_count_kernel, dim3(a.max_work), dim3(L2_THREADS), 0, s, a);
-    hipLaunchKernelGGL(l2_ranges_kernel, dim3(1), dim3(1024), 0, s, a.tilecnt, a.gx * a.gy, a.done, a.ranges, a.totals, a.cap_coarse, a.cap_fine);
+    GsBin3Args b = a;
+    if (!b.cap_src || !b.tile_nopen || !b.smax || !b.tile_ext || b.done) { b.cap_src = nullptr; b.tile_nopen = nullptr; b.smax = nullptr; b.tile_ext = nullptr; }
+    hipLaunchKernelGGL(l2_count_kernel, dim3(b.max_work), dim3(L2_THREADS), 0, s, b);
+    if (b.cap_src) hipLaunchKernelGGL(l2_cap_kernel, dim3(b.ns), dim3(GS_WAVE), 0, s, b);
+    hipLaunchKernelGGL(l2_ranges_kernel, dim3(1), dim3(1024), 0, s, b.tilecnt, b.gx * b.gy, b.done, b.ranges, b.totals, b.cap_coarse, b.cap_fine, b.tile_ext);
+    return gs_bin3_write_lists(b, s);
+}
+hipError_t gs_bin3_write_lists(const GsBin3Args &a, hipStream_t s) {
+    if (a.max_work <= 0) return hipSuccess;
     if (a.wide) hipLaunchKernelGGL(l2_write_kernel<true>, dim3(a.max_work), dim3(L2W_THREADS), 0, s, a);
     else hipLaunchKernelGGL(l2_write_kernel<false>, dim3(a.max_work), dim3(L2W_THREADS), 0, s, a);
     return hipGetLastError();

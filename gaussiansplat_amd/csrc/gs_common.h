@@ -204,7 +204,21 @@ struct GsBin3Args {
     int wide;                  // the lists reach beyond 4 GB from ids_out: 64-bit store addresses
     const uint32_t *totals;    // the round's totals (GsBin3L1.totals) and the capacities they are checked against
     uint32_t cap_coarse, cap_fine;
+    // ---- capped lists (gs_config.list_cap; DESIGN.md "lists nobody walks").  cap_src != null: per tile, the list entries the view
+    // slot's previous forward walked before its early-out.  A tile's list is then WRITTEN only up to the end of the first segment
+    // (L2_SEG entries of its super-tile's list) at which it holds GS_LIST_CAP(walked) entries; the ranges still reserve the full
+    // list, and a composite wave that reaches the written end with live pixels writes the next segment's entries itself
+    // (gs_composite.hip: extend_tile_list) -- same entries, same order, so image and gradients do not change.
+    const uint32_t *cap_src;   // [tiles] or null (no caps: every list written in full)
+    uint32_t *tile_nopen;      // [tiles] segments of its super-tile's list the tile takes entries from
+    uint32_t *smax;            // [ns]    the largest tile_nopen of the super-tile (later segments have no work at all)
+    uint2 *tile_ext;           // [tiles] {written end of the list (entry index), coarse index where the unwritten rest starts or GS_CONT_NONE}
+    uint32_t *ext_count;       // one word zeroed by the cap pass: list segments appended by composite waves (GsCompositeArgs.ext_count)
 };
+#define GS_CONT_NONE 0xFFFFFFFFu
+// entries kept for a tile whose slot history walked w: a quarter more, and never less than two batches
+__host__ __device__ inline uint32_t gs_list_cap(uint32_t w) { const uint32_t c = w + (w >> 2) + 128u; return c < w ? 0xFFFFFFFFu : c; }
+int gs_bin3_seg();             // L2_SEG: coarse entries per level-2 work item
 int gs_bin3_sb_shift();
 bool gs_bin3_supported(int ns);
 int64_t gs_bin3_max_work(int64_t coarse_instances, int ns);
@@ -213,9 +227,10 @@ size_t gs_bin3_partial_words(int64_t n, int ns);
 hipError_t gs_bin3_l1_count(const GsBin3L1 &b, hipStream_t s);
 hipError_t gs_bin3_l1_scatter(const GsBin3L1 &b, hipStream_t s);
 hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s);
+hipError_t gs_bin3_write_lists(const GsBin3Args &a, hipStream_t s);      // the write pass alone (counts and ranges of the frame still valid)
 hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, uint8_t *sdone, hipStream_t s);
 
-#define GS_TILE_CLOCK_WORDS 6
+#define GS_TILE_CLOCK_WORDS 8
 #define GS_MAX_ROUNDS 4   // binning rounds (depth slabs) of one frame
 #define GS_G2D_STRIDE 16   // floats (or fixed-point words) per gaussian row of the composite backward's sums: ten used, padded to ONE
                            // 64-byte sector so that the 9-lane atomic of a (tile, splat) entry is a single memory-side request
@@ -238,20 +253,15 @@ struct GsCompositeArgs {
                                 // (2500 tiles), + 15 us at C3 (tools/abtest.py variants 10010 / 10030)
     uint32_t *tile_walked;     // list entries walked (staged) per tile; may be null
     int cull;                  // 1: drop (tile, splat) entries that are provably no-ops while staging (gs_config.alpha_cull)
-    int variant;               // kernel variant (A/B testing; 0 = default)
-    int map_mode;              // block -> tile map of the non-queued launch (0 plain; 1, 2: XCD bands, A/B only)
-    // work queue (persistent waves pull tiles from an atomic ticket counter, longest first)
-    uint32_t *queue;           // 8 ticket counters (one per XCD), zeroed before the launch; null: one wave per tile, blockIdx order
-    const uint32_t *queue_seg; // 9 bounds of the per-XCD segments of tile_order
-    const uint32_t *tile_order; // plain launch: block b composites tile_order[b] (0xFFFFFFFF: none); experiments' queues: segment x = XCD x's tiles
+    int variant;               // debug launches (gs_debug_time_composite, gs_debug_tile_clock): tens digit 1 = tile order instead of tile_order
+    const uint32_t *tile_order; // plain launch: block b composites tile_order[b] (0xFFFFFFFF: none); null: block b = tile b
     int order_len;              // entries of tile_order = blocks of the plain launch (0: gx * gy)
-    const uint32_t *tile_order_plain; // A/B: the same segments in tile order (no longest-first)
-    const uint32_t *tile_order_band;  // A/B: longest-first permutation for a plain launch (schedule 3), tile % 8 preserved
     uint32_t *tile_work;       // evaluated entries per tile (forward: the backward's exact work measure and the next launch order); may be null
     unsigned long long *zero_words; // forward: two 64-bit words zeroed by block 0 (the backward's work counters: saves a memset command); may be null
     unsigned long long *tile_clock; // debug: GS_TILE_CLOCK_WORDS per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated,
-                                    // shader cycles (s_memtime) inside the per-entry loops, shader cycles outside them (staging, waiting for the gathers)}
-    int grid_waves;            // waves to launch in queue mode
+                                    // shader cycles (s_memtime) inside the per-entry loops, shader cycles outside them (staging, waiting for the gathers),
+                                    // strip slots executed << 32 | slots if the live pixels were packed 64 to a slot, strips with a live pixel << 32 | live pixels
+                                    // (the last four summed over the evaluated entries)}
     // frames binned in depth slabs (several rounds of binning + forward)
     int nseg;                  // backward: number of list segments per tile (= rounds of the frame, >= 1)
     const uint32_t *seg_ranges[GS_MAX_ROUNDS];   // backward: per round 2 x tiles [start, end) into seg_ids[round]
@@ -261,7 +271,18 @@ struct GsCompositeArgs {
     unsigned long long *tile_dead; // forward, slab frames: 4 lane masks per tile, bit l of word p = pixel slot p of lane l is frozen
     int resume;                // forward: continue from the pixel state the previous round left in image / trans
     int final_round;           // forward: last round of the frame: transmittance is written plain (no sign flag)
+    // capped lists (GsBin3Args.cap_src): tile_ext != null -> a tile's written list ends at tile_ext[t].x; the forward extends it from
+    // the super-tile's coarse list (cranges / cids / clr) when it gets there with live pixels and stores the new end; the backward
+    // only reads tile_ext[t].x (it stops where the forward stopped, or at the end the forward left)
+    uint2 *tile_ext;
+    const uint32_t *cranges, *cids;
+    const uint16_t *clr;
+    uint32_t *ids_w;           // == ids, writable
+    int sgx;
+    uint32_t *ext_count;       // segments appended by the forward's waves (one atomic per extension: the rare path), may be null
 };
+// the written entries of capped lists, summed over the tiles: out[0] = sum (ext[t].x - ranges[2 t])
+hipError_t gs_launch_sum_listed(const uint32_t *ranges, const uint2 *ext, int n, unsigned long long *out, hipStream_t s);
 // longest-first launch order of the tiles for a plain launch (gs_composite.hip: groups of 8 x 8 tiles dealt to the XCDs by work,
 // GS_LPT_BUCKETS work classes inside an XCD's list; one workgroup).  order: gs_lpt_order_len(gx, gy) entries, holes = 0xFFFFFFFF.
 // zero14 (may be null): fourteen 64-bit words zeroed on the way (the backward's work and ticket counters: saves a memset command)
@@ -273,8 +294,6 @@ hipError_t gs_launch_clock_probe(unsigned long long *out, hipStream_t s);
 hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsigned long long *out, hipStream_t s);
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
                                     unsigned long long *zero14 = nullptr, int buckets = 0);
-hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s);
-int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body = 0);   // occupancy x CUs (body: A/B variant)
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);
 

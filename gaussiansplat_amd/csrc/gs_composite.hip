@@ -16,21 +16,16 @@
 // as D - prefix (D = C_final . dC), so T is recomputed exactly as in the forward and never divided
 // back.
 //
-// Scheduling.  Tiles differ a lot in work (the early-out point, the share of no-op entries, ragged image edges), and a
-// wave lives as long as its tile: with one wave per tile in blockIdx order the last third of the kernel runs at a
-// fraction of the occupancy (profiles/: 3.6 of 6 waves per SIMD on average at C3).  So the kernels are persistent: a
-// grid of exactly the resident waves pulls tiles from an atomic ticket counter, heaviest tile first (tile_order: for
-// the backward the forward's per-tile count of evaluated entries, its exact work; for the forward the list length).
-// Every wave drains (ticket >= tiles ends the loop), no wave waits on another, so no residency assumption is made.
+// Scheduling.  Tiles differ a lot in work (the early-out point, the share of no-op entries, ragged image edges) and a wave
+// lives as long as its tile, so the launch ORDER decides how ragged the end of the kernel is: a plain launch over a
+// longest-first permutation of the tiles (tile_lpt_order_kernel below; groups of 8 x 8 tiles dealt to the XCDs so that the
+// tiles listing a gaussian share one L2).  Persistent waves on ticket queues were measured slower (profiles/HISTORY.md).
 //
 // Per-splat gradient sums (backward).  Nine sums over the tile's 256 pixels are needed per (tile, splat).  Each lane
 // first adds its four pixels, then the 64 x 9 partials are transposed through LDS: nine conflict-free ds_write_b32 rows
 // [component][lane], then lane (c, s) = (l >> 2, l & 3), l < 36, reads the sixteen partials of quarter s of component
 // c with four ds_read_b128 and adds them; two quad-permute DPP adds finish, and nine lanes issue ONE atomic
-// instruction covering the gaussian's row.  That is 17 adds per entry on the VALU -- the unit these kernels are bound
-// by -- against 7 select-select-add folds + 9 butterfly adds (37 instructions, 15 of them 4-cycle v_cndmask) for the
-// reduce-scatter tree on ds_swizzle/ds_bpermute it replaces (kept as variant 1), and its one LDS round trip is taken
-// off the critical path: the reads of entry k are consumed after the pixel arithmetic of entry k+1.
+// instruction covering the gaussian's row: 17 adds per entry on the VALU -- the unit these kernels are bound by.
 //
 // While staging a 64-entry batch each lane also bounds the largest alpha its entry can reach on this
 // tile (rect_can_contribute); entries that are no-ops in fp32 are dropped and the batch is compacted in
@@ -45,11 +40,8 @@
 // template instantiation and as mul + sub in another, so "cull on" and "cull off" differed in the last bit of T.
 #pragma clang fp contract(off)
 
-#ifndef GS_ABL
-#define GS_ABL 0
-#endif
-#ifndef GS_BWD3_MINW
-#define GS_BWD3_MINW 5              // __launch_bounds__ waves/SIMD of backward body 3: 96 VGPRs (unconstrained: 104 -> 4 waves)
+#ifndef GS_BWD_MINW
+#define GS_BWD_MINW 5               // __launch_bounds__ waves/SIMD of the backward: 96 VGPRs (unconstrained: 104 -> 4 waves)
 #endif
 #ifndef GS_FWD_MINW
 #define GS_FWD_MINW 5               // __launch_bounds__ waves/SIMD of the forward (89 VGPRs)
@@ -58,8 +50,11 @@
 #define GS_FWD_UNROLL 2             // entries interleaved in the forward's per-entry loop
 #endif
 constexpr int kFwdUnroll = GS_FWD_UNROLL;
-#include <cstdlib>
 #define CB 64                       // splats staged per batch
+#ifndef L2_SEG
+#define L2_SEG 2048                 // gs_bin3.hip: coarse entries per level-2 work item (gs_bin3_seg() on the host side)
+#endif
+__device__ __forceinline__ int gs_bin3_seg_const() { return L2_SEG; }
 #define NEG_HALF_LOG2E (-0.72134752044448170368f)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -68,54 +63,15 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float vgpr_const(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-#ifdef GS_EXPERIMENTS
-// Workgroup -> tile map of the non-queued launch (A/B only).  Measured on MI355X at C3 (tools/abtest.py): the plain
-// order is 5 % faster than giving each XCD a contiguous band of tiles or whole tile rows.  Speed only, never correctness.
-__device__ __forceinline__ int tile_of_block(int b, int ntiles, int gx, int mode) {
-    if (mode == 0) return b;                       // plain order (default)
-    if (mode == 2) {                               // tile rows dealt round-robin to the XCDs
-        const int xcd = b & 7, idx = b >> 3;
-        return ((idx / gx) * 8 + xcd) * gx + idx % gx;
-    }
-    const int per = (ntiles + 7) >> 3;             // mode 1: one contiguous band of tiles per XCD
-    return (b & 7) * per + (b >> 3);
-}
-#endif
-
-// Next tile of this wave: a ticket from the work queue (persistent launch) or the block's own tile (first call only).
-// The queue is eight ticket counters, one per XCD, over eight segments of tile_order: segment x holds the tiles with
-// tile % 8 == x, heaviest first.  A wave pulls from the segment of the XCD it runs on (HW_REG_XCC_ID), so vertically
-// adjacent tiles (tile + gx: same residue for the 8-aligned grids of 1080p and 4K) share their splat payloads in that
-// XCD's L2 -- the placement the plain launch gets from the round-robin dispatch, and worth 13 % of the forward at C3
-// (profiles/: one shared counter vs plain launch).  When its segment is exhausted it steals from the next ones, so the
-// kernel ends balanced across the chip.  Placement is a speed matter only: any wave may process any tile.
-__device__ __forceinline__ int next_tile(const GsCompositeArgs &a, int ntiles, bool first) {
-#ifdef GS_EXPERIMENTS
-    if (a.queue) {
-        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 7u;       // HW_REG_XCC_ID
-        for (uint32_t i = 0; i < 8; ++i) {
-            const uint32_t x = (xcc + i) & 7u;
-            const uint32_t lo = a.queue_seg[x], hi = a.queue_seg[x + 1];
-            if (lo >= hi) continue;
-            uint32_t t = 0;
-            if (threadIdx.x == 0) t = atomicAdd(a.queue + x, 1u);
-            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + lo;
-            if (t < hi) return a.tile_order ? (int)a.tile_order[t] : (int)t;
-        }
-        return -1;
-    }
-#endif
-    if (!first) return -1;
-    if (a.tile_order) {                                                  // schedule 3 / 4: plain launch over a launch order (holes: GS_LPT_NONE)
+// The tile of this workgroup: its own index, or -- plain launch over a launch order (gs_config.schedule 3 / 4) -- order[blockIdx]
+// (holes of the order: GS_LPT_NONE).  -1: nothing to do.
+__device__ __forceinline__ int tile_of_block(const GsCompositeArgs &a, int ntiles) {
+    if (a.tile_order) {
         if ((int)blockIdx.x >= (a.order_len > 0 ? a.order_len : ntiles)) return -1;
         const uint32_t t = a.tile_order[blockIdx.x];
         return t < (uint32_t)ntiles ? (int)t : -1;
     }
-#ifdef GS_EXPERIMENTS
-    const int tile = tile_of_block(blockIdx.x, ntiles, a.gx, a.map_mode);
-#else
     const int tile = (int)blockIdx.x;
-#endif
     return tile < ntiles ? tile : -1;
 }
 
@@ -211,13 +167,45 @@ __device__ __forceinline__ Entry load_entry(const float4 *sp, const float *syhi,
     return e;
 }
 
+// ---------------------------------------------------------------- capped lists: the wave writes the rest of its tile's list itself
+// gs_bin wrote the tile's list only up to the end of a segment of its super-tile's coarse list (GsBin3Args.cap_src: what the view
+// slot's previous forward walked, and a quarter more).  A forward wave that gets to the written end with pixels still taking
+// entries appends the hits of the NEXT segment -- the same test and the same order as l2_write_kernel (gs_bin3.hip), into the
+// entries the tile's range reserves for them -- and goes on; cont moves to the following segment (GS_CONT_NONE after the last).
+// Returns the new written end.  Rare by construction (a camera jump under a reused slot, a tile that saturated later than last
+// time); the walk, the batch boundaries and therefore image, transmittance and gradients are those of the full list.
+__device__ __forceinline__ uint32_t extend_tile_list(const GsCompositeArgs &a, const int tile, uint32_t &cont, uint32_t s1) {
+    const int lane = threadIdx.x;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int S = (ty >> 3) * a.sgx + (tx >> 3);
+    const uint32_t lx = (uint32_t)(tx & 7), ly = (uint32_t)(ty & 7);
+    const uint32_t c1 = a.cranges[2 * S + 1];
+    const uint32_t seg = (uint32_t)gs_bin3_seg_const();
+    const uint32_t e_end = min(cont + seg, c1);
+    for (uint32_t e0 = cont; e0 < e_end; e0 += GS_WAVE) {
+        const uint32_t e = e0 + (uint32_t)lane;
+        bool hit = false;
+        uint32_t id = 0;
+        if (e < e_end) {
+            const uint32_t lr = a.clr[e];
+            hit = (lr & 7u) <= lx && lx <= ((lr >> 3) & 7u) && ((lr >> 6) & 7u) <= ly && ly <= ((lr >> 9) & 7u);
+            id = a.cids[e];
+        }
+        const uint64_t bal = __ballot(hit);
+        if (hit) a.ids_w[s1 + (uint32_t)slot_of(bal)] = id;
+        s1 += (uint32_t)__popcll(bal);
+    }
+    cont = e_end < c1 ? e_end : GS_CONT_NONE;
+    if (lane == 0 && a.ext_count) atomicAdd(a.ext_count, 1u);
+    __threadfence();                                        // the wave reads these ids back: stores complete, this CU's L1 lines dropped
+    return s1;
+}
+
 // ---------------------------------------------------------------- forward
-template <bool EARLY, bool CULL, bool LEAN, bool CLK, bool SLAB>
+template <bool EARLY, bool CULL, bool CLK, bool SLAB>
 // SLAB: the frame is binned in depth slabs (several rounds; resume / tile_pos / tile_done / tile_dead): its own instantiation, the
 // single-round kernel carries none of that state (with it the compiler spilled: 96 VGPRs + 28 bytes of scratch against 90).
 // CLK: per-tile debug clocks (gs_debug_tile_clock); a separate instantiation so that the production kernel carries none of it.
-// LEAN (A/B variant 2 of the forward): no register prefetch of the next batch and no 2-entry interleave, to fit 64 VGPRs =
-// eight waves per SIMD, i.e. every tile of a 1080p frame resident at once.
 // (Skipping the dead 16 x 4 strips of an entry with wave-uniform branches, as the backward does, was measured on the forward
 // too: 0.352 vs 0.357 ms at C3 -- its per-strip work is a 12-instruction dependent chain, the branches cost what they save.)
 __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, const float nbig) {
@@ -225,7 +213,11 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
     const float fx = (float)px;
-    const uint32_t s0 = a.ranges[2 * tile], s1 = a.ranges[2 * tile + 1];
+    const uint32_t s0 = a.ranges[2 * tile];
+    uint32_t s1 = a.ranges[2 * tile + 1];
+    uint32_t cont = GS_CONT_NONE;                                  // capped lists: where the unwritten rest of the list starts in the coarse list
+    const bool capped = !SLAB && EARLY && a.tile_ext != nullptr;
+    if (capped) { const uint2 ex = a.tile_ext[tile]; s1 = ex.x; cont = ex.y; }
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);     // first pixel of the tile (1-based)
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
@@ -266,15 +258,22 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     // behind a second dependent round trip to memory.  A tile whose batches keep few entries (light tiles, the ones that run
     // when the chip is emptying) is bound by exactly this chain: one exposed load latency per batch instead of two.
     uint32_t id2 = 0;
-    if (!LEAN) {
-        const uint32_t pos2 = pos + min((uint32_t)CB - (gp0 & (CB - 1)), s1 - s0);      // first position of the second batch + lane
+    uint32_t gp = gp0;                                                  // list position of `base` in the tile's whole list
+    uint32_t base = s0;
+    unsigned long long t_loop = 0, t_stage = 0, t_mark = 0;             // debug clocks (a.tile_clock): shader cycles inside / outside the per-entry loops
+    // debug (a.tile_clock): per-entry strip slots executed, the slots live pixels compacted to 64 per slot would need, the strips with
+    // any live pixel, and live pixels, each summed over the evaluated entries (frozen-pixel work inside live strips)
+    unsigned long long clk_exec = 0, clk_ideal = 0, clk_alive = 0, clk_pix = 0;
+    uint32_t clk_live = 0, clk_strips = 0;
+    if (CLK) t_mark = __builtin_amdgcn_s_memtime();
+    for (;;) {                                                          // (capped lists: once more per segment the wave appends itself)
+    bool stopped = false;
+    {
+        const uint32_t pos2 = pos + min((uint32_t)CB - (gp & (CB - 1)), s1 - base);     // first position of the second batch + lane
         if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; n3 = pay4[4 * g + 3]; }
         if (pos2 < s1) id2 = a.ids[pos2];
     }
-    uint32_t gp = gp0;                                                  // list position of `base` in the tile's whole list
-    unsigned long long t_loop = 0, t_stage = 0, t_mark = 0;             // debug clocks (a.tile_clock): shader cycles inside / outside the per-entry loops
-    if (CLK) t_mark = __builtin_amdgcn_s_memtime();
-    for (uint32_t base = s0; base < s1;) {
+    for (; base < s1;) {
         const uint32_t phase = gp & (CB - 1);
         const int cnt = (int)min((uint32_t)CB - phase, s1 - base);      // batches end at multiples of CB of the WHOLE list
         if (EARLY && phase == 0) {
@@ -284,15 +283,15 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
                 if (!dead[p] && T[p] < a.t_min) { dead[p] = true; Tdead[p] = T[p]; T[p] = 0.0f; }
                 live = live || !dead[p];
             }
-            if (__ballot(live) == 0ull) break;
+            if (__ballot(live) == 0ull) { stopped = true; break; }
+        }
+        if (CLK && (phase == 0 || base == s0)) {                         // debug: live pixels / strips with a live pixel in this batch
+            clk_live = 0; clk_strips = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { const uint64_t m = __ballot(!dead[p]); clk_live += (uint32_t)__popcll(m); clk_strips += m ? 1u : 0u; }
         }
         uint32_t strips;
         bool keep;
-        if (LEAN) {
-            n0 = n1 = n2 = n3 = make_float4(0.f, 0.f, 0.f, 0.f);
-            pos = base + lane;
-            if (pos < s1) { const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; n3 = pay4[4 * g + 3]; }
-        }
         stage_record<false>(n0, n1, n3, tx0, ty0, keep, strips);
         int slot = lane, nk = cnt;
         if (!CULL) keep = true;
@@ -309,13 +308,13 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         __syncthreads();
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
-        if (!LEAN) {
+        {
             if (pos < s1) { const size_t g = id2; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; n3 = pay4[4 * g + 3]; }
             const uint32_t pos2 = pos + min((uint32_t)CB, s1 - base);                   // (batches after the first start at multiples of CB)
             if (base < s1 && pos2 < s1) id2 = a.ids[pos2];
         }
         if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
-#pragma clang loop unroll_count(LEAN ? 1 : kFwdUnroll)
+#pragma clang loop unroll_count(kFwdUnroll)
         for (int k = 0; k < nk; ++k) {
             const Entry e = load_entry(sp, syhi, k);
             const float dX = fx - e.q0.x;
@@ -335,9 +334,20 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             }
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
-        if (!LEAN) first_use_here(n0, n1, n2, n3);
-        if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t; }
+        first_use_here(n0, n1, n2, n3);
+        if (CLK) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t;
+            clk_exec += 4ull * (uint32_t)nk; clk_ideal += (unsigned long long)nk * ((clk_live + 63u) >> 6);
+            clk_alive += (unsigned long long)nk * clk_strips; clk_pix += (unsigned long long)nk * clk_live;
+        }
     }
+    if (!capped || stopped || cont == GS_CONT_NONE) break;
+    // the written list is used up, its pixels still take entries and the super-tile's list goes on: append the next segment's hits
+    // (whether the pixels are frozen at the next batch boundary is decided by the loop above, at the same position as in the full list)
+    s1 = extend_tile_list(a, tile, cont, s1);
+    pos = base + lane;
+    }
+    if (capped && lane == 0) a.tile_ext[tile] = make_uint2(s1, cont);   // (unchanged unless the list was extended) the backward's list end
     bool anylive = false;
 #pragma unroll
     for (int p = 0; p < 4; ++p) anylive = anylive || !dead[p];
@@ -372,69 +382,28 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
         c[3] = ((unsigned long long)walked << 32) | evaluated;
         c[4] = t_loop; c[5] = t_stage;
+        c[6] = (clk_exec << 32) | (clk_ideal & 0xFFFFFFFFull); c[7] = (clk_alive << 32) | (clk_pix & 0xFFFFFFFFull);
     }
 }
 
-template <bool EARLY, int MINW, bool CULL, bool LEAN = false, bool CLK = false, bool SLAB = false>
+template <bool EARLY, int MINW, bool CULL, bool CLK = false, bool SLAB = false>
 __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     if (a.zero_words && blockIdx.x == 0 && threadIdx.x < 2) a.zero_words[threadIdx.x] = 0ull;
-    for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
-        forward_tile<EARLY, CULL, LEAN, CLK, SLAB>(a, tile, sp, syhi, nbig);
-        __syncthreads();                                                // the next tile restages sp[]
-    }
+    const int tile = tile_of_block(a, ntiles);
+    if (tile >= 0) forward_tile<EARLY, CULL, CLK, SLAB>(a, tile, sp, syhi, nbig);
 }
 
-// ---------------------------------------------------------------- wave64 reductions
-// (a) the transposed reduction through LDS (default): see the header comment.  RS floats per component row: 64 lanes
-// + 4 of padding, so that the sixteen-float quarters read with ds_read_b128 by lanes (c, s) fall on distinct banks
-// (start bank (4 c + 16 s) mod 64 inside every 16-lane service group).
+// ---------------------------------------------------------------- wave64 reduction of the nine per-splat sums
+// The transposed reduction through LDS (header comment).  RS floats per component row: 64 lanes + 4 of padding, so that the
+// sixteen-float quarters read with ds_read_b128 by lanes (c, s) fall on distinct banks (start bank (4 c + 16 s) mod 64 inside
+// every 16-lane service group).  (Round 1's reduce-scatter tree on ds_swizzle / ds_bpermute and a software-pipelined form of
+// this one were measured slower and are gone: profiles/HISTORY.md.)
 #define RS 68
 #define RED_FLOATS (9 * RS)
-// (b) the reduce-scatter tree on the LDS crossbar (variant 1, kept for A/B): eight of the nine sums go through a tree over
-// the six lane bits -- a fold pairs two registers, so one add sums BOTH across one lane bit and leaves value A in the
-// lower lanes and value B in the upper ones; 4 + 2 + 1 folds bring eight registers down to one whose 8-lane groups each
-// hold one value, three butterfly steps finish inside the groups.  The ninth sum is a plain six-step butterfly.
-template <int PATTERN>
-__device__ __forceinline__ float swz_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN));
-}
-// lower lanes of the bit <- a(l) + a(partner) ; upper lanes <- b(partner) + b(l)
-template <int PATTERN>
-__device__ __forceinline__ float fold_swz(float a, float b, bool upper) {
-    const float send = upper ? a : b, keep = upper ? b : a;
-    return keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), PATTERN));
-}
-__device__ __forceinline__ float fold32_lds(float a, float b, bool upper, int xaddr) {
-    const float send = upper ? a : b, keep = upper ? b : a;
-    return keep + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(send)));
-}
-// every lane of the 8-lane group (16r .. 16r+7) ends with the wave total of (v0, v2, v1, v3)[r], of group
-// (16r+8 .. 16r+15) with that of (v4, v6, v5, v7)[r]
-__device__ __forceinline__ float reduce8_lds(const float (&v)[9], int lane, int xaddr) {
-    const bool u32 = (lane & 32) != 0, u16 = (lane & 16) != 0, u8 = (lane & 8) != 0;
-    const float b0 = fold32_lds(v[0], v[1], u32, xaddr), b1 = fold32_lds(v[2], v[3], u32, xaddr);
-    const float b2 = fold32_lds(v[4], v[5], u32, xaddr), b3 = fold32_lds(v[6], v[7], u32, xaddr);
-    const float c0 = fold_swz<0x401F>(b0, b1, u16), c1 = fold_swz<0x401F>(b2, b3, u16);       // xor 16
-    float d = fold_swz<0x201F>(c0, c1, u8);                                                  // xor 8
-    d = swz_add<0x101F>(d); d = swz_add<0x081F>(d); d = swz_add<0x041F>(d);                  // xor 4, 2, 1
-    return d;
-}
-__device__ __forceinline__ float wave_sum_lds(float v, int xaddr) {
-    v = swz_add<0x041F>(v); v = swz_add<0x081F>(v); v = swz_add<0x101F>(v); v = swz_add<0x201F>(v); v = swz_add<0x401F>(v);
-    return v + __int_as_float(__builtin_amdgcn_ds_bpermute(xaddr, __float_as_int(v)));
-}
-// tree variant: lane 16r+7 adds (v0, v2, v1, v3)[r], lane 16r+15 adds (v4, v6, v5, v7)[r], lane 62 v8 -> g2d columns
-__device__ __forceinline__ int out_component_tree(int lane) {
-    const int row = lane >> 4, pos = lane & 15;
-    if (pos == 7) return row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
-    if (pos == 15) return row == 0 ? 4 : row == 1 ? 6 : row == 2 ? 5 : 7;
-    if (lane == 62) return 9;
-    return -1;
-}
 
 // g2d row of a gaussian: [dr dg db | S0 Sx Sy Sxx Sxy (unused) Syy] -- the colour gradient and the raw moments
 // S.. = sum over pixels of dd * {1, dX, dY, dX^2, dX dY, dY^2}, dd = d L / d(log alpha); gs_g2d_to_grads (gs_common.h)
@@ -468,38 +437,22 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
                                                const float (&dCr)[4], const float (&dCg)[4], const float (&dCb)[4],
                                                float (&T)[4], float (&S)[4], float (&v)[9], bool &any, const uint32_t live) {
     const float dX = fx - e.q0.x;
-#if GS_ABL & 16
-    const float A0 = fmaf(e.q1.x * dX, dX, e.q0.z);
-#else
     const float ex = dX - __builtin_amdgcn_fmed3f(dX, e.q0.w, e.q1.w);
     const float A0 = fmaf(nbig, fabsf(ex), fmaf(e.q1.x * dX, dX, e.q0.z));
-#endif
     const float B0 = e.q1.y * dX;
     float ar = 0.0f, ag = 0.0f, ab = 0.0f, q0s = 0.0f, q1s = 0.0f, q2s = 0.0f, asum = 0.0f;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         if (!((live >> p) & 1u)) continue;                        // wave-uniform branch: a dead strip costs nothing
         const float dY = fy[p] - e.q0.y;
-#if GS_ABL & 16
-        const float xp = fmaf(dY, fmaf(e.q1.z, dY, B0), A0);
-#else
         const float ey = dY - __builtin_amdgcn_fmed3f(dY, e.q2.w, e.yhi);
         const float xp = fmaf(nbig, fabsf(ey), fmaf(dY, fmaf(e.q1.z, dY, B0), A0));
-#endif
-#if GS_ABL & 8
-        const float al = xp * 1.0e-3f;
-#else
         const float al = fast_exp2(xp);
-#endif
         asum += al;
         const float w = al * T[p];
         const float cdot = fmaf(e.q2.x, dCr[p], fmaf(e.q2.y, dCg[p], e.q2.z * dCb[p]));
         S[p] = fmaf(-cdot, w, S[p]);
-#if GS_ABL & 8
-        const float inv = (1.0f - al) * 0.5f;
-#else
         const float inv = fast_rcp(1.0f - al);
-#endif
         const float dalpha = fmaf(T[p], cdot, -(S[p] * inv));
         const float dd = -(al * dalpha);
         const float ddy = dd * dY;
@@ -516,13 +469,7 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
     v[6] = dX * qx; v[7] = dX * q1s; v[8] = q2s;
 }
 
-// Diagnostic builds (tools/ablate.sh, never shipped; run with t_min = 0 so that the walked and evaluated entries do not depend
-// on the arithmetic).  -DGS_ABL is a bit mask: 1 drops the cross-lane reduction and the atomic of body 3 (the nine partials are
-// kept alive by an empty asm), 2 drops only the atomic, 8 replaces v_exp_f32 / v_rcp_f32 by one multiply each, 16 drops the
-// pixel-box penalty (v_med3 + sub + fma per axis), 32 reuses one staged entry (no LDS reads of the payload).  Outputs are wrong
-// by construction.
-// RED: 2 transposed LDS reduction, software pipelined (default); 1 reduce-scatter tree on ds_swizzle / ds_bpermute
-template <bool EARLY, bool DET, int RED, bool CULL, bool CLK>
+template <bool EARLY, bool DET, bool CULL, bool CLK>
 __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, uint32_t *sid, uint32_t *sstrip,
                                               float *red, const float nbig) {
     const int lane = threadIdx.x;
@@ -533,10 +480,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
-    // tree variant
-    const int ocomp_tree = out_component_tree(lane);
-    const int xaddr = (lane ^ 32) << 2;                                  // ds_bpermute address of the partner lane
-    // transposed variant: lane (c, s) = (rl >> 2, rl & 3) sums quarter s of component c; lanes >= 36 mirror lanes 0..27
+    // transposed reduction: lane (c, s) = (rl >> 2, rl & 3) sums quarter s of component c; lanes >= 36 mirror lanes 0..27
     // (same addresses: broadcasts, no bank conflicts), their sums are not used
     const int rl = lane < 36 ? lane : lane - 36;
     const float *rrow = red + (rl >> 2) * RS + (rl & 3) * 16;
@@ -562,20 +506,15 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     uint32_t nid = 0;
-    // pipeline state of the transposed reduction: the sixteen partials read back for the previous entry
+    // the sixteen partials a lane reads back of the entry being reduced
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
     uint32_t pend_gid = 0;
-    bool pend = false;
-    auto finish = [&]() {                                                // sums of the pending entry -> one atomic
+    auto finish = [&]() {                                                // sums of the entry -> one atomic
         float s = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w));
         s += ((r2.x + r2.y) + (r2.z + r2.w)) + ((r3.x + r3.y) + (r3.z + r3.w));
         s += dpp_xor1(s);
         s += dpp_xor2(s);
-#if GS_ABL & 2
-        asm volatile("" :: "v"(s));
-#else
         if (ocomp_t >= 0) add_to_row<DET>(a, pend_gid, ocomp_t, s);
-#endif
     };
     // The tile's list is the concatenation of its segments, one per binning round of the frame (one segment unless the
     // frame was binned in depth slabs); batches end at multiples of CB of the WHOLE list, as in the forward.
@@ -583,10 +522,14 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     uint32_t alive = 0xFu;                                                // strips with a live pixel (refreshed at every batch boundary)
     bool stop = false;
     unsigned long long t_loop = 0, t_stage = 0, t_mark = 0;               // debug clocks (a.tile_clock)
+    unsigned long long clk_exec = 0, clk_ideal = 0, clk_alive = 0, clk_pix = 0;   // (see the forward)
+    uint32_t clk_live = 0, clk_strips = 0;
     if (CLK) t_mark = __builtin_amdgcn_s_memtime();
     for (int sg = 0; sg < a.nseg && !stop; ++sg) {
     const uint32_t *ids = a.seg_ids[sg];
-    const uint32_t s0 = a.seg_ranges[sg][2 * tile], s1 = a.seg_ranges[sg][2 * tile + 1];
+    const uint32_t s0 = a.seg_ranges[sg][2 * tile];
+    // capped lists: the list ends where gs_bin -- or the forward, if it had to go further -- stopped writing it (>= what the forward walked)
+    const uint32_t s1 = a.tile_ext ? a.tile_ext[tile].x : a.seg_ranges[sg][2 * tile + 1];
     uint32_t pos = s0 + lane;
     uint32_t id2 = 0;                                                     // ids run two batches ahead, payload rows one (see the forward)
     {
@@ -607,6 +550,11 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
                 if (__ballot(!dead[p]) != 0ull) alive |= 1u << p;           // strip p still has a pixel that takes entries
             }
             if (alive == 0u) { stop = true; break; }
+        }
+        if (CLK && (phase == 0 || gp == 0)) {
+            clk_live = 0; clk_strips = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { const uint64_t m = __ballot(!dead[p]); clk_live += (uint32_t)__popcll(m); clk_strips += m ? 1u : 0u; }
         }
         uint32_t strips;
         bool keep;
@@ -645,80 +593,31 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             if (base < s1 && pos2 < s1) id2 = ids[pos2];
         }
         if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
-        if (RED == 2) {
-            // software pipeline: arithmetic of entry k | loads of entry k+1 | sums + atomic of entry k-1 (its sixteen
-            // partials were read back during the arithmetic) | partials of entry k -> LDS, read back transposed
-            // (two named entry sets alternate, so the loop carries no register copies)
-            auto step = [&](const Entry &cur, const uint32_t gcur, Entry &nxt, uint32_t &gnxt, const int k) {
-                float v[9];
-                bool any;
-                backward_entry(cur, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
-                const uint32_t gid_k = (uint32_t)__builtin_amdgcn_readfirstlane((int)gcur);
-                __builtin_amdgcn_sched_barrier(0);
-                nxt = load_entry(sp, syhi, k + 1);                       // slot nk <= CB exists (one spare slot), value unused
-                gnxt = sid[k + 1];
-                if (!CULL && __ballot(any) == 0ull) return;              // nobody in the tile touched it
-                if (pend) finish();
-                __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < nk; ++k) {
+            const Entry e = load_entry(sp, syhi, k);
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
+            float v[9];
+            bool any = true;
+            backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
+            if (!CULL && __ballot(any) == 0ull) continue;                // nobody in the tile touched it
 #pragma unroll
-                for (int c = 0; c < 9; ++c) wrow[c * RS] = v[c];         // LDS serves one wave's accesses in order: these
-                const float4 *rr = reinterpret_cast<const float4 *>(rrow);   // stores precede the loads below, and follow
-                r0 = rr[0]; r1 = rr[1]; r2 = rr[2]; r3 = rr[3];          // the previous entry's loads
-                pend_gid = gid_k; pend = true;
-            };
-            Entry eA = load_entry(sp, syhi, 0), eB;
-            uint32_t gA = sid[0], gB;
-            int k = 0;
-            for (; k + 1 < nk; k += 2) { step(eA, gA, eB, gB, k); step(eB, gB, eA, gA, k + 1); }
-            if (k < nk) step(eA, gA, eB, gB, k);
-        } else if (RED == 3) {                                           // transposed reduction, summed in the same iteration
-#if GS_ABL & 32
-            Entry e = load_entry(sp, syhi, 0);
-#endif
-            for (int k = 0; k < nk; ++k) {
-#if GS_ABL & 32
-                asm volatile("" : "+v"(e.q0.x), "+v"(e.q0.y), "+v"(e.q1.x), "+v"(e.q2.x));     // opaque: no hoisting out of the loop
-                const uint32_t gid = 0;
-#else
-                const Entry e = load_entry(sp, syhi, k);
-                const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
-#endif
-                float v[9];
-                bool any = true;
-                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
-                if (!CULL && __ballot(any) == 0ull) continue;
-#if GS_ABL & 1
-#pragma unroll
-                for (int c = 0; c < 9; ++c) asm volatile("" :: "v"(v[c]));
-                (void)gid;
-#else
-#pragma unroll
-                for (int c = 0; c < 9; ++c) wrow[c * RS] = v[c];
-                const float4 *rr = reinterpret_cast<const float4 *>(rrow);
-                r0 = rr[0]; r1 = rr[1]; r2 = rr[2]; r3 = rr[3];
-                pend_gid = gid;
-                finish();
-#endif
-            }
-        } else {
-            for (int k = 0; k < nk; ++k) {
-                const Entry e = load_entry(sp, syhi, k);
-                const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
-                float v[9];
-                bool any;
-                backward_entry(e, fx, fy, nbig, dCr, dCg, dCb, T, S, v, any, live_of(k));
-                if (!CULL && __ballot(any) == 0ull) continue;            // nobody in the tile touched it
-                const float d = reduce8_lds(v, lane, xaddr);
-                const float t9 = wave_sum_lds(v[8], xaddr);
-                if (ocomp_tree >= 0) add_to_row<DET>(a, gid, ocomp_tree, lane == 62 ? t9 : d);
-            }
+            for (int c = 0; c < 9; ++c) wrow[c * RS] = v[c];             // LDS serves one wave's accesses in order: the reads below see these
+            const float4 *rr = reinterpret_cast<const float4 *>(rrow);
+            r0 = rr[0]; r1 = rr[1]; r2 = rr[2]; r3 = rr[3];
+            pend_gid = gid;
+            finish();
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
         first_use_here(n0, n1, n2, n3);
-        if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t; }
+        if (CLK) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t;
+            const uint64_t below = nk >= 64 ? ~0ull : ((1ull << nk) - 1ull);
+            clk_exec += CULL ? (unsigned long long)(__popcll(mq[0] & below) + __popcll(mq[1] & below) + __popcll(mq[2] & below) + __popcll(mq[3] & below)) : 4ull * (uint32_t)nk;
+            clk_ideal += (unsigned long long)nk * ((clk_live + 63u) >> 6);
+            clk_alive += (unsigned long long)nk * clk_strips; clk_pix += (unsigned long long)nk * clk_live;
+        }
     }
     }
-    if (RED == 2 && pend) finish();
     if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
     if (lane == 0 && a.tile_walked) a.tile_walked[tile] = walked;
     if (lane == 0 && a.tile_work) a.tile_work[tile] = evaluated;
@@ -727,67 +626,22 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
         c[3] = ((unsigned long long)walked << 32) | evaluated;
         c[4] = t_loop; c[5] = t_stage;
+        c[6] = (clk_exec << 32) | (clk_ideal & 0xFFFFFFFFull); c[7] = (clk_alive << 32) | (clk_pix & 0xFFFFFFFFull);
     }
 }
 
-template <bool EARLY, int MINW, bool DET, int RED, bool CULL, bool CLK = false>
+template <bool EARLY, int MINW, bool DET, bool CULL, bool CLK = false>
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
-    __shared__ float4 sp[(CB + 1) * 3];                                  // one spare slot: the pipelined loop loads entry k+1
-    __shared__ float syhi[CB + 1];
-    __shared__ uint32_t sid[CB + 1];
+    __shared__ float4 sp[CB * 3];
+    __shared__ float syhi[CB];
+    __shared__ uint32_t sid[CB];
     __shared__ uint32_t sstrip[CB];
-    __shared__ __attribute__((aligned(16))) float red[RED >= 2 ? RED_FLOATS : 4];
+    __shared__ __attribute__((aligned(16))) float red[RED_FLOATS];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
-    for (int tile = next_tile(a, ntiles, true); tile >= 0; tile = next_tile(a, ntiles, false)) {
-        backward_tile<EARLY, DET, RED, CULL, CLK>(a, tile, sp, syhi, sid, sstrip, red, nbig);
-        __syncthreads();
-    }
+    const int tile = tile_of_block(a, ntiles);
+    if (tile >= 0) backward_tile<EARLY, DET, CULL, CLK>(a, tile, sp, syhi, sid, sstrip, red, nbig);
 }
-
-#ifdef GS_EXPERIMENTS
-// ---------------------------------------------------------------- tile order (per XCD, longest first)
-// One workgroup: tiles are keyed by (tile % 8, work / max in 256 steps, descending) and counting-sorted; seg[0..8] are the
-// bounds of the eight per-XCD segments of `order`.  work = work[t], or the list length ranges[2t+1] - ranges[2t]
-// (ranges_mode), or 0 for every tile (src == null: tile order inside each segment).  Tiles inside a bucket keep no
-// particular order (a speed hint only, never correctness).
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles,
-                                                           uint32_t *__restrict__ order, uint32_t *__restrict__ seg) {
-    __shared__ uint32_t hist[2048];
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t wmax;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    hist[tid] = 0; hist[tid + 1024] = 0;
-    if (tid == 0) wmax = 1;
-    __syncthreads();
-    auto work = [&](int t) -> uint32_t { return !src ? 0u : ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t]; };
-    uint32_t m = 0;
-    for (int t = tid; t < ntiles; t += 1024) m = max(m, work(t));
-    atomicMax(&wmax, m);
-    __syncthreads();
-    const float scale = 255.0f / (float)wmax;
-    auto bucket = [&](int t) -> int { return (t & 7) * 256 + 255 - (int)((float)work(t) * scale); };         // bucket 0 of a segment = heaviest
-    for (int t = tid; t < ntiles; t += 1024) atomicAdd(&hist[bucket(t)], 1u);
-    __syncthreads();
-    {                                                                    // exclusive scan of 2048 counters: thread t owns [2t, 2t+2)
-        const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1], sm = c0 + c1;
-        uint32_t incl = sm;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        uint32_t off = 0;
-        for (int k = 0; k < w; ++k) off += wsum[k];
-        const uint32_t run = off + incl - sm;
-        hist[2 * tid] = run; hist[2 * tid + 1] = run + c0;
-        if ((tid & 127) == 0) seg[tid >> 7] = run;                       // bucket 256 x: start of segment x
-        if (tid == 1023) seg[8] = run + sm;
-    }
-    __syncthreads();
-    for (int t = tid; t < ntiles; t += 1024) order[atomicAdd(&hist[bucket(t)], 1u)] = (uint32_t)t;
-}
-
-#endif  // GS_EXPERIMENTS
 
 // Longest-first order for a PLAIN launch (gs_config.schedule 3 / 4).  The dispatcher hands workgroups out in blockIdx order,
 // round-robin over the XCDs: block b runs on XCD b % 8.  order[8 j + x] is therefore the j-th tile of XCD x, and the kernel
@@ -949,30 +803,7 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
     return hipGetLastError();
 }
 
-#ifdef GS_EXPERIMENTS
-hipError_t gs_launch_tile_order(const uint32_t *work_or_ranges, int ranges_mode, int ntiles, uint32_t *order, uint32_t *seg, hipStream_t s) {
-    if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, work_or_ranges, ranges_mode, ntiles, order, seg);
-    return hipGetLastError();
-}
-#endif
-
-// ---------------------------------------------------------------- launchers
-// variant (A/B, tools/abtest.py; 0 = default): units digit = kernel body (backward: 3 transposed LDS reduction (default); 2 the same,
-// software pipelined at 96 VGPRs; 1 reduce-scatter tree; forward: 1), tens digit = scheduling (0 as the caller set it up: queue + order when given; 1 one wave per tile in
-// blockIdx order; 2 queue in tile order, no longest-first).
-// Profiling aid (GS_EXPERIMENTS builds): GS_DEBUG_EXTRA_LDS=<bytes> adds that much dynamic LDS to every composite launch, which lowers the
-// waves resident per CU (160 KiB / (static + extra)) without touching the code -- the occupancy sweep of tools/ablate.sh.
-static size_t debug_extra_lds() {
-#ifdef GS_EXPERIMENTS
-    static long v = -1;
-    if (v < 0) { const char *e = getenv("GS_DEBUG_EXTRA_LDS"); v = e ? atol(e) : 0; if (v < 0) v = 0; }
-    return (size_t)v;
-#else
-    return 0;
-#endif
-}
-
+// ---------------------------------------------------------------- small helpers and launchers
 // the per-tile work counters of a composite launch, summed when somebody asks (gs_get_work_counters, the radix binning paths)
 __global__ __launch_bounds__(1024) void sum_tiles_kernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, int n,
                                                           unsigned long long *__restrict__ out) {
@@ -984,6 +815,21 @@ __global__ __launch_bounds__(1024) void sum_tiles_kernel(const uint32_t *__restr
     if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = sa; sm[1][threadIdx.x >> 6] = sb; }
     __syncthreads();
     if (threadIdx.x < 2) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += sm[threadIdx.x][k]; out[threadIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void sum_listed_kernel(const uint32_t *__restrict__ ranges, const uint2 *__restrict__ ext, int n,
+                                                           unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long sm[16];
+    unsigned long long sa = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) sa += ext[i].x - ranges[2 * i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sa += __shfl_down(sa, d);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sa;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += sm[k]; out[0] = t; }
+}
+hipError_t gs_launch_sum_listed(const uint32_t *ranges, const uint2 *ext, int n, unsigned long long *out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_listed_kernel, dim3(1), dim3(1024), 0, s, ranges, ext, n, out);
+    return hipGetLastError();
 }
 hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsigned long long *out, hipStream_t s) {
     hipLaunchKernelGGL(sum_tiles_kernel, dim3(1), dim3(1024), 0, s, a, b, n, out);
@@ -1003,29 +849,14 @@ hipError_t gs_launch_clock_probe(unsigned long long *out, hipStream_t s) {
 }
 
 static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {
-#ifdef GS_EXPERIMENTS
-    if (a.queue) return dim3((unsigned)max(1, min(a.grid_waves > 0 ? a.grid_waves : ntiles, ntiles)));
-    if (a.tile_order && a.order_len > 0) return dim3((unsigned)a.order_len);
-    return dim3(a.map_mode == 2 ? ((a.gy + 7) / 8) * 8 * a.gx : ((ntiles + 7) / 8) * 8);
-#else
     if (a.tile_order && a.order_len > 0) return dim3((unsigned)a.order_len);
     return dim3(((ntiles + 7) / 8) * 8);
-#endif
 }
 
+// variant (debug launches, gs_debug_time_composite / gs_debug_tile_clock): tens digit 1 = tile order instead of the frame's launch order
 static GsCompositeArgs apply_sched_variant(const GsCompositeArgs &a0) {
     GsCompositeArgs a = a0;
-#ifdef GS_EXPERIMENTS
-    const int sched = (a.variant / 10) % 10;
-    if (sched == 1) { a.queue = nullptr; a.tile_order = nullptr; }
-    else if (sched == 2 && a.tile_order_plain) a.tile_order = a.tile_order_plain;      // per-XCD segments in tile order
-    else if (sched == 3) { a.queue = nullptr; a.tile_order = a.tile_order_band; }       // plain launch, longest first inside the residue classes
-#else
-    const int sched = (a.variant / 10) % 10;                                            // debug launches (gs_debug_*): 1 = tile order, 3 = the given order
-    a.queue = nullptr;
-    if (sched == 1) a.tile_order = nullptr;
-    else if (sched == 3 && a.tile_order_band) a.tile_order = a.tile_order_band;
-#endif
+    if ((a.variant / 10) % 10 == 1) { a.tile_order = nullptr; a.order_len = 0; }
     return a;
 }
 
@@ -1035,99 +866,47 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
-#ifdef GS_EXPERIMENTS
-#define GS_F(E) do { if (a.variant % 10 == 2 && a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 8, true, true>), grid, block, debug_extra_lds(), s, a); \
-                     else if (a.variant % 10 == 6 && a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, 6, true>), grid, block, debug_extra_lds(), s, a); \
-                     else if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, GS_FWD_MINW, true>), grid, block, debug_extra_lds(), s, a); \
-                     else hipLaunchKernelGGL((composite_fwd_kernel<E, GS_FWD_MINW, false>), grid, block, debug_extra_lds(), s, a); } while (0)
-#else
-#define GS_F(E) do { if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<E, GS_FWD_MINW, true>), grid, block, debug_extra_lds(), s, a); \
-                     else hipLaunchKernelGGL((composite_fwd_kernel<E, GS_FWD_MINW, false>), grid, block, debug_extra_lds(), s, a); } while (0)
-#endif
+    if (a.tile_ext && (gs_bin3_seg() != L2_SEG || !early || !a.cranges || !a.cids || !a.clr || !a.ids_w || a.tile_pos)) return hipErrorInvalidValue;
     if (a.tile_pos) {                                                     // a round of a slab frame (t_min > 0 by construction: plan_rounds)
         if (!early || a.tile_clock) return hipErrorInvalidValue;
-        if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<true, 5, true, false, false, true>), grid, block, debug_extra_lds(), s, a);
-        else hipLaunchKernelGGL((composite_fwd_kernel<true, 5, false, false, false, true>), grid, block, debug_extra_lds(), s, a);
+        // built for FOUR waves per SIMD: the resume / tile_pos / tile_done / tile_dead state needs ~120 VGPRs, and at five (96) it spilled 12-14 of them
+        if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<true, 4, true, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((composite_fwd_kernel<true, 4, false, false, true>), grid, block, 0, s, a);
         return hipGetLastError();
     }
     if (a.tile_clock) {                                                   // debug clocks: instantiations of their own (alpha_cull on only)
         if (!a.cull) return hipErrorInvalidValue;
-        if (early) hipLaunchKernelGGL((composite_fwd_kernel<true, 5, true, false, true>), grid, block, debug_extra_lds(), s, a);
-        else hipLaunchKernelGGL((composite_fwd_kernel<false, 5, true, false, true>), grid, block, debug_extra_lds(), s, a);
+        if (early) hipLaunchKernelGGL((composite_fwd_kernel<true, GS_FWD_MINW, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((composite_fwd_kernel<false, GS_FWD_MINW, true, true>), grid, block, 0, s, a);
         return hipGetLastError();
     }
-    if (early) GS_F(true); else GS_F(false);
-#undef GS_F
+    if (early) {
+        if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<true, GS_FWD_MINW, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((composite_fwd_kernel<true, GS_FWD_MINW, false>), grid, block, 0, s, a);
+    } else {
+        if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<false, GS_FWD_MINW, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((composite_fwd_kernel<false, GS_FWD_MINW, false>), grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
 
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
-    GsCompositeArgs a = apply_sched_variant(a0);
+    const GsCompositeArgs a = apply_sched_variant(a0);
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
     const bool early = a.t_min > 0.0f;
-#ifdef GS_EXPERIMENTS
-    if (a.queue && a.variant % 10 != 0 && a.variant % 10 != 3) {           // A/B body: its own resident-wave count
-        const int w = gs_composite_resident_waves(1, early, a.g2d_fixed != nullptr, a.cull != 0, a.variant % 10);
-        if (w > 0) a.grid_waves = w;
-    }
-#endif
     const dim3 grid = composite_grid(a, ntiles), block(64);
-#define GS_B2(E, M, D, Z) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, true>), grid, block, debug_extra_lds(), s, a); \
-                               else hipLaunchKernelGGL((composite_bwd_kernel<E, M, D, Z, false>), grid, block, debug_extra_lds(), s, a); } while (0)
-#define GS_B(E, M, Z) do { if (a.g2d_fixed) GS_B2(E, M, true, Z); else GS_B2(E, M, false, Z); } while (0)
+#define GS_B2(E, D) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, true>), grid, block, 0, s, a); \
+                         else hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, false>), grid, block, 0, s, a); } while (0)
+#define GS_B(E) do { if (a.g2d_fixed) GS_B2(E, true); else GS_B2(E, false); } while (0)
     if (a.tile_clock) {                                                   // debug clocks: instantiations of their own (alpha_cull on, float atomics only)
         if (!a.cull || a.g2d_fixed) return hipErrorInvalidValue;
-        if (early) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_BWD3_MINW, false, 3, true, true>), grid, block, debug_extra_lds(), s, a);
-        else hipLaunchKernelGGL((composite_bwd_kernel<false, GS_BWD3_MINW, false, 3, true, true>), grid, block, debug_extra_lds(), s, a);
+        if (early) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_BWD_MINW, false, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((composite_bwd_kernel<false, GS_BWD_MINW, false, true, true>), grid, block, 0, s, a);
         return hipGetLastError();
     }
-#ifdef GS_EXPERIMENTS
-    const int body = (a.variant % 10 == 1 || a.variant % 10 == 2) ? a.variant % 10 : 3;
-    // body 2 holds the sixteen partials of the previous entry across the pixel arithmetic: 96 VGPRs, 5 waves/SIMD (measured slower
-    // than body 3: the loop gains nothing from the hidden LDS round trip); body 1 is round 1's reduce-scatter tree
-    if (body == 2) { if (early) GS_B(true, 5, 2); else GS_B(false, 5, 2); }
-    else if (body == 1) { if (early) GS_B(true, 1, 1); else GS_B(false, 1, 1); }
-    else
-#endif
-    { if (early) GS_B(true, GS_BWD3_MINW, 3); else GS_B(false, GS_BWD3_MINW, 3); }
+    if (early) GS_B(true); else GS_B(false);
 #undef GS_B
 #undef GS_B2
     return hipGetLastError();
 }
-
-#ifdef GS_EXPERIMENTS
-// Resident waves of a kernel on this device: occupancy (waves of 64 per CU) x CUs.  The persistent grid is exactly this
-// size, so every launched wave is resident from the start and the queue is the only scheduler.  body: 0 = default.
-typedef void (*CompositeKernel)(GsCompositeArgs);
-template <bool E, bool D, bool C>
-static CompositeKernel bwd_kernel_of(int body) {
-    if (body == 1) return composite_bwd_kernel<E, 1, D, 1, C>;
-    if (body == 2) return composite_bwd_kernel<E, 5, D, 2, C>;
-    return composite_bwd_kernel<E, GS_BWD3_MINW, D, 3, C>;
-}
-int gs_composite_resident_waves(int which, bool early, bool det, bool cull, int body) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    CompositeKernel f = nullptr;
-    if (which == 0) {
-        f = early ? (cull ? composite_fwd_kernel<true, GS_FWD_MINW, true> : composite_fwd_kernel<true, GS_FWD_MINW, false>)
-                  : (cull ? composite_fwd_kernel<false, GS_FWD_MINW, true> : composite_fwd_kernel<false, GS_FWD_MINW, false>);
-    } else {
-        const int k = (early ? 4 : 0) | (det ? 2 : 0) | (cull ? 1 : 0);
-        switch (k) {
-            case 0: f = bwd_kernel_of<false, false, false>(body); break;
-            case 1: f = bwd_kernel_of<false, false, true>(body); break;
-            case 2: f = bwd_kernel_of<false, true, false>(body); break;
-            case 3: f = bwd_kernel_of<false, true, true>(body); break;
-            case 4: f = bwd_kernel_of<true, false, false>(body); break;
-            case 5: f = bwd_kernel_of<true, false, true>(body); break;
-            case 6: f = bwd_kernel_of<true, true, false>(body); break;
-            default: f = bwd_kernel_of<true, true, true>(body); break;
-        }
-    }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(f), 64, 0) != hipSuccess || per_cu <= 0) return 0;
-    return per_cu * cus;
-}
-#endif  // GS_EXPERIMENTS

@@ -419,19 +419,11 @@ hipError_t gs_launch_sh_from_views(int64_t n, int sh_degree, const float *means,
 }
 
 // gaussians per workgroup of the SH kernel: its LDS tile is (3K + 1) floats per gaussian (49 at SH degree 3), so 256 gaussians
-// allow three workgroups per CU, 128 six (GS_EXPERIMENTS builds: GS_SHBWD_T = 64 / 128 / 256)
+// allow three workgroups per CU, 128 six (64 / 128 / 256 measured equal: profiles/HISTORY.md)
 #ifndef GS_SHBWD_THREADS
 #define GS_SHBWD_THREADS 256
 #endif
-static int sh_bwd_threads() {
-#ifdef GS_EXPERIMENTS
-    static int v = 0;
-    if (!v) { const char *e = getenv("GS_SHBWD_T"); const int t = e ? atoi(e) : 0; v = (t == 64 || t == 128 || t == 256) ? t : GS_SHBWD_THREADS; }
-    return v;
-#else
-    return GS_SHBWD_THREADS;
-#endif
-}
+static int sh_bwd_threads() { return GS_SHBWD_THREADS; }
 hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera &cam, hipStream_t s, int phases) {
     if (a.n <= 0) return hipSuccess;
     const int T = sh_bwd_threads();

@@ -40,7 +40,7 @@ def shard_views(num_views: int, world: int, rank: int) -> list[int]:
 
 
 def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=None, sync: str = "allreduce",
-                    overlap: bool = True, pipeline: bool = True) -> "torch.Tensor":
+                    overlap: bool = True, pipeline: bool = True, exchange: bool = True) -> "torch.Tensor":
     """One data-parallel step over a view batch (8 views on 1 / 2 / 4 / 8 GPUs = 8 / 4 / 2 / 1 views per rank, rendered
     one after the other with the gradients ACCUMULATING, then the exchange).  Returns the flat gradient buffer summed over all
     views (identical on every rank; the caller applies its optimiser and the next step starts with reset()).
@@ -58,12 +58,25 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
     latency-bound kernels of view k+1 (preprocess, depth sort, tile lists) run beside the composite kernels of view k; the
     per-gaussian chains stay in view order (event-chained), so the sums are the same bits as one view after the other.
     sync = "factored": see the module docstring (needs a renderer with render_view_factored / color_slots / sh_from_views, and
-    the same number of views on every rank)."""
+    the same number of views on every rank).
+    exchange = False (measurement only, bench.py's compute_ms): this rank's share of the views exactly as in a real step -- the same
+    kernels on the same streams -- but no collective is posted; the buffer then holds the rank's partial sums."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = shard_views(len(cameras), world, rank)
+    if not exchange:
+        class _NoExchange:                                                  # stands in for torch.distributed below: every collective is a no-op
+            class ReduceOp: SUM = None
+            class _Done:
+                def wait(self): pass
+            @staticmethod
+            def all_reduce(*a, **k): return _NoExchange._Done()
+            @staticmethod
+            def all_gather_into_tensor(out, inp, **k):
+                out.view(-1)[rank * inp.numel():(rank + 1) * inp.numel()].copy_(inp.view(-1)); return _NoExchange._Done()
+        dist = _NoExchange
     r.reset()
     if sync == "allreduce":
         # How many collectives a step posts, and over which segments, is decided from numbers EVERY rank computes alike -- the
@@ -127,6 +140,11 @@ class HipViewRenderer:
 
     @property
     def flat(self):
+        # Between render_view_until_sh and finish_geometry of a rank's ONLY view the lazy reset is still pending for the geometry
+        # segment (its chain overwrites it) while the Δshs segment is already final: looking at the buffer then must not
+        # materialise the zero fill (renderer.splatGrads does), or the async all-reduce would sum a wiped Δshs segment.
+        if getattr(self, "_mid_split", False):
+            return self.r._splatGrads.flat
         return self.r.splatGrads.flat
 
     def reset(self) -> None:
@@ -208,11 +226,13 @@ class HipViewRenderer:
         self._dC = dC
         R.backward(self.r, dC, phase="composite")
         R.backward(self.r, dC, phase="params_sh")
+        self._mid_split = True
         self.last_ctx = self.r.ctx
 
     def finish_geometry(self) -> None:
         from . import renderer as R
         R.backward(self.r, self._dC, phase="params_geom")
+        self._mid_split = False
 
     # ---- colour-factored exchange
     @property

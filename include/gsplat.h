@@ -46,8 +46,10 @@ extern "C" {
 
 /* 2: gs_config carries abi_version (gs_create refuses any other value: a caller built against another header fails loudly
  *    instead of running with shifted fields); schedule 0 now means "library default"; view slots (gs_set_view_slot);
- *    speculative binning (no host wait inside gs_bin); GS_BWD_PARAMS_SH / _GEOM; 64-byte payload and gradient rows. */
-#define GS_ABI_VERSION 2
+ *    speculative binning (no host wait inside gs_bin); GS_BWD_PARAMS_SH / _GEOM; 64-byte payload and gradient rows.
+ * 3: gs_config.list_cap (capped tile lists from the view slot's history; a former reserved word, sizeof unchanged); 4096 view
+ *    slots; gs_get_list_stats. */
+#define GS_ABI_VERSION 3
 
 typedef enum {
     GS_OK = 0,
@@ -99,16 +101,16 @@ typedef struct {
                                  < 7.5e-9*|rgb|).  The lists (gs_bin) are unchanged.  0: evaluate every entry. */
     int32_t schedule;         /* composite kernels (speed only: every mode gives the same image and, up to atomic order, gradients):
                                  0 the library default (= 3);
-                                 3 one wave per tile, plain launch over a longest-first permutation of the tiles that keeps
-                                   tile % 8 (the XCD a block lands on): the backward by the forward's per-tile count of evaluated
+                                 3 one wave per tile, plain launch over a longest-first permutation of the tiles (groups of 8 x 8
+                                   tiles dealt to the XCDs): the backward by the forward's per-tile count of evaluated
                                    entries of the same frame (C3: 0.84 -> 0.74 ms); the forward by the count the last forward
                                    rendered under the same VIEW SLOT measured (gs_set_view_slot: training cycles over a fixed
                                    camera set), in tile order when the slot has no history yet;
                                  4 as 3, and a forward without slot history uses the work of this ctx's PREVIOUS forward
                                    (pays when consecutive frames see similar views);
                                  1 one wave per tile in launch (tile) order.
-                                 Builds with -DGS_EXPERIMENTS also have 10 / 12: persistent waves pulling tiles from per-XCD ticket
-                                 counters, heaviest first / in tile order (both measured slower: profiles/)     */
+                                 (Persistent waves pulling tiles from per-XCD ticket counters were measured slower and are gone:
+                                 profiles/HISTORY.md.)                                                                          */
     int32_t slab_mode;        /* binning in depth slabs (speed only; image, transmittance and deterministic-mode gradients are
                                  bit-identical either way): 1 (default) automatic -- when the previous frame walked under 3 % of
                                  its tile instances before the transmittance early-out stopped every tile (with the two-level
@@ -127,10 +129,23 @@ typedef struct {
                                  per bucket: inside LDS up to 8192 pairs, else through global memory in chunks; 4 launches) for 3-D frames
                                  of up to 8.4 M gaussians, the four-pass LSD radix sort (12 launches) otherwise and for 64 frames after
                                  a frame whose depths piled up in one bucket (more than eight chunks); 1 always the four-pass sort; 2 always the two-step sort (tests)                          */
-    int32_t reserved[5];      /* sizeof(gs_config) == 96                                                                       */
+    int32_t list_cap;         /* capped tile lists (speed only; image, transmittance and deterministic-mode gradients are bit-identical
+                                 either way).  The reference allocates and fills every tile's list in full (forward.jl:139-142:
+                                 hitIdxs of maxBinSize per tile), although with the transmittance early-out a dense scene walks a
+                                 fraction of it (C3: 28 %, C5: 6 % of the entries).  0 (default) automatic: when the frame's VIEW SLOT
+                                 (gs_set_view_slot) has rendered this image size before, gs_bin writes every tile's list only as far
+                                 as that frame walked it (+ 25 % + 128 entries, rounded up to a segment of the two-level binning); a
+                                 composite wave that gets to the written end with pixels still taking entries writes the next
+                                 segment of its tile's list itself and goes on, so nothing depends on the history being right.
+                                 Engages on grids of more than 5120 tiles (below that the write pass is a few microseconds).
+                                 1 never; 2 also on small grids (tests).  GS_ARR_TILE_RANGES is always the full ranges; asking for
+                                 GS_ARR_SORTED_IDS / _KEYS of a capped frame first writes the unwritten rest.                   */
+    int32_t reserved[4];      /* sizeof(gs_config) == 96                                                                       */
 } gs_config;
 #define GS_DEBUG_WIDE_CURSORS 1   /* two-level binning: 64-bit list cursors although the lists fit 32-bit byte offsets (tests)    */
 #define GS_DEBUG_ALWAYS_ORDER 2    /* longest-first launch orders (and their side stream) also on grids with fewer tiles than wave slots (tests) */
+#define GS_DEBUG_TINY_CAPS 4       /* capped lists with the minimum cap on every tile, history or not: every tile that walks more than its
+                                      first segment extends its list in the composite kernel (tests)                               */
 
 typedef struct gs_ctx gs_ctx;
 
@@ -180,9 +195,11 @@ int gs_set_camera(gs_ctx *ctx, const float T[16], const float P[16], float fx, f
 /* Optional: name the view about to be rendered (call before gs_preprocess; e.g. the `id` of the camera in cameras.json,
  * camera.jl:119-151).  A training loop cycles over a fixed camera set, and how the work of a frame is spread over the tiles is a
  * property of the view: the ctx keeps, per slot 0 .. GS_MAX_VIEW_SLOTS - 1, the longest-first tile order of the last frame
- * rendered under that slot and launches the next forward of the same slot in that order (gs_config.schedule 3 / 4).  Speed
- * only -- a stale or wrong slot costs nothing but the benefit.  slot < 0 (default): the frame belongs to no slot. */
-#define GS_MAX_VIEW_SLOTS 64
+ * rendered under that slot and launches the next forward of the same slot in that order (gs_config.schedule 3 / 4), and how
+ * many entries of its list each tile walked, which caps the lists gs_bin writes for the slot's next frame (gs_config.list_cap).  Speed
+ * only -- a stale or wrong slot costs nothing but the benefit.  slot < 0 (default): the frame belongs to no slot.  A slot costs
+ * three arrays of one word per tile (100 KB at 1080p), allocated when it is first rendered. */
+#define GS_MAX_VIEW_SLOTS 4096
 int gs_set_view_slot(gs_ctx *ctx, int32_t slot);
 
 /* preprocess(renderer): projection, 2-D covariance + inverse, bounding box, SH colour,
@@ -336,6 +353,11 @@ int gs_get_stage_stats(gs_ctx *ctx, double sum_ms[GS_STAGE_COUNT], int64_t count
  * (== gs_num_instances when t_min == 0; fewer with the transmittance early-out). */
 int gs_get_work_counters(gs_ctx *ctx, int64_t *walked_fwd, int64_t *walked_bwd);
 
+/* Tile lists of the last frame: out = {entries actually written into the tile lists (== gs_num_instances unless the lists were
+ * capped, gs_config.list_cap; includes what composite waves appended), list segments appended by composite waves (0 when the
+ * slot's history covered the frame), 1 if the frame's lists were capped else 0}.  Call after gs_forward; synchronises. */
+int gs_get_list_stats(gs_ctx *ctx, int64_t out[3]);
+
 /* out = {walked_fwd, walked_bwd, evaluated_fwd, evaluated_bwd}: `evaluated` counts the walked entries that
  * survived the alpha_cull no-op test and were evaluated per pixel (== walked when alpha_cull == 0). */
 int gs_get_work_counters_ex(gs_ctx *ctx, int64_t out[4]);
@@ -346,9 +368,11 @@ int gs_get_work_counters_ex(gs_ctx *ctx, int64_t out[4]);
 int gs_debug_time_composite(gs_ctx *ctx, int which, int variant, int reps, float *mean_ms);
 
 /* Profiling aid: one launch of the composite forward (which=0) or backward (which=1) kernel of the current frame with
- * per-tile clocks.  out (HOST): 6 x gx*gy uint64 per tile {start, end (100 MHz s_memrealtime ticks), HW_ID | XCC_ID << 32,
+ * per-tile clocks.  out (HOST): 8 x gx*gy uint64 per tile {start, end (100 MHz s_memrealtime ticks), HW_ID | XCC_ID << 32,
  * walked << 32 | evaluated, shader cycles inside the per-entry loops, shader cycles outside them (staging a batch and waiting
- * for its gathers)}.  tools/tile_tail.py turns it into the occupancy-over-time and tail summary under profiles/. */
+ * for its gathers), per-entry strip slots executed << 32 | the slots needed if the tile's live pixels were packed 64 to a slot,
+ * strips holding a live pixel << 32 | live pixels (the last four summed over the evaluated entries)}.
+ * tools/tile_tail.py turns it into the occupancy-over-time, tail and frozen-pixel summaries under profiles/. */
 int gs_debug_tile_clock(gs_ctx *ctx, int which, int variant, uint64_t *out);
 
 /* Profiling hook: the shader clock (MHz) the chip runs at right now, from one wave that counts s_memtime cycles over 20 us of

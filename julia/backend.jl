@@ -18,7 +18,7 @@ const GS_MEM_HOST = Cint(0)
 const GS_MEM_DEVICE = Cint(1)
 @enum GsOrder::Cint GS_ORDER_INDEX = 0 GS_ORDER_DEPTH_DESC = 1 GS_ORDER_DEPTH_ASC = 2
 
-const GS_ABI_VERSION = Cint(2)               # include/gsplat.h: the header this glue is written against
+const GS_ABI_VERSION = Cint(3)               # include/gsplat.h: the header this glue is written against
 
 mutable struct GsConfig                      # must mirror gs_config (96 bytes)
     struct_size::Int32
@@ -38,7 +38,8 @@ mutable struct GsConfig                      # must mirror gs_config (96 bytes)
     slab_fractions::NTuple{3, Float32}
     debug_flags::Int32
     depth_sort::Int32
-    reserved::NTuple{5, Int32}
+    list_cap::Int32                          # capped tile lists: 0 automatic, 1 never, 2 also on small grids
+    reserved::NTuple{4, Int32}
 end
 
 struct GsGrads                               # gs_grads: device pointers, may be C_NULL
@@ -64,7 +65,7 @@ function check(r::HipRenderer, rc::Cint)
 end
 
 function defaultConfig()
-    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, 0, ntuple(_ -> Int32(0), 5))
+    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, 0, 0, ntuple(_ -> Int32(0), 4))
     ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
     # a library built from another header would read this struct with shifted fields: refuse it here, loudly
     (hip_abiVersion() == GS_ABI_VERSION && cfg.abi_version == GS_ABI_VERSION && cfg.struct_size == sizeof(GsConfig)) ||
@@ -228,6 +229,12 @@ hip_numInstances(r::HipRenderer) = ccall((:gs_num_instances, libgs), Int64, (Ptr
 hip_numCoarseInstances(r::HipRenderer) = ccall((:gs_num_coarse_instances, libgs), Int64, (Ptr{Cvoid},), r.ctx)
 hip_abiVersion() = ccall((:gs_abi_version, libgs), Cint, ())
 hip_numRounds(r::HipRenderer) = ccall((:gs_num_rounds, libgs), Cint, (Ptr{Cvoid},), r.ctx)
+# tile lists of the last frame: (entries written, list segments appended by composite waves, 1 if the lists were capped)
+function hip_listStats(r::HipRenderer)
+    out = zeros(Int64, 3)
+    check(r, ccall((:gs_get_list_stats, libgs), Cint, (Ptr{Cvoid}, Ptr{Int64}), r.ctx, out))
+    return out
+end
 
 # renderer scratch arrays (gs_array ids of include/gsplat.h; e.g. 11 = sortIdxs, 12 = tile ranges, 13 = sorted ids) into a host array
 function hip_getArray!(r::HipRenderer, which::Integer, dst::Array)

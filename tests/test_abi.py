@@ -33,12 +33,12 @@ def test_header_symbols_exported(lib):
 
 def test_abi_version_and_config_layout(lib):
     from gaussiansplat_amd import backend
-    assert lib.gs_abi_version() == backend.GS_ABI_VERSION == 2
+    assert lib.gs_abi_version() == backend.GS_ABI_VERSION == 3
     cfg = backend.default_config()
-    assert cfg.struct_size == C.sizeof(backend.GsConfig) == 96 and cfg.abi_version == 2
-    assert cfg.schedule == 3 and cfg.slab_mode == 1 and cfg.debug_flags == 0 and cfg.slab_max_ratio == 0.0
+    assert cfg.struct_size == C.sizeof(backend.GsConfig) == 96 and cfg.abi_version == 3
+    assert cfg.schedule == 3 and cfg.slab_mode == 1 and cfg.debug_flags == 0 and cfg.slab_max_ratio == 0.0 and cfg.list_cap == 0
     hdr = open(os.path.join(ROOT, "include", "gsplat.h")).read()
-    assert re.search(r"#define GS_ABI_VERSION\s+2\b", hdr)
+    assert re.search(r"#define GS_ABI_VERSION\s+3\b", hdr)
     assert cfg.tile_size == 16 and cfg.order == backend.ORDER_DEPTH_DESC and abs(cfg.t_min - 1e-5) < 1e-12
 
 

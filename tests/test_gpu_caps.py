@@ -1,0 +1,189 @@
+"""Capped tile lists (gs_config.list_cap; DESIGN.md "lists nobody walks") must be invisible.
+
+gs_bin writes every tile's list only as far as the frame's view slot walked it last time (+ 25 % + 128 entries, rounded up to a
+segment of the two-level binning); a composite wave that reaches the written end with live pixels appends the next segment of its
+tile's list itself (gs_composite.hip: extend_tile_list).  Same entries, same order, same 64-entry batch boundaries as the full
+lists, so: image and transmittance BIT-identical, deterministic-mode gradients BIT-identical, float-atomic gradients to atomic-order
+noise, tile ranges the full ranges, and GS_ARR_SORTED_IDS / _KEYS (which first writes the unwritten rest) bit-exact vs the oracle.
+Cases: history that is exact (no extension), a camera jump under a reused slot (extensions), the minimum cap on every tile
+(GS_DEBUG_TINY_CAPS: every busy tile extends, incl. tiles that never saturate and walk their whole list), a grid with ragged
+edges, slots beyond the old limit of 64, and the cap switched off."""
+import numpy as np
+import pytest
+
+from common import hip_context, rel_l2, scene_and_cameras
+
+pytestmark = pytest.mark.gpu
+GRADS = ("means", "scales", "quats", "opacities", "shs")
+
+
+def _set_cam(ctx, cam, W, H):
+    from gaussiansplat_amd import camera as gcam
+    T = gcam.compute_transform(cam); P = gcam.compute_projection(cam, W, H)
+    ctx.set_camera(T, P, float(np.float32(cam.fx)), float(np.float32(cam.fy)), float(np.float32(cam.near)), float(np.float32(cam.far)),
+                   cam.eye, cam.lookAt, W, H)
+
+
+def _frame(ctx, dC, deg, slot=None):
+    if slot is not None:
+        ctx.set_view_slot(slot)
+    ctx.preprocess(); ctx.bin()
+    img, tr = ctx.forward_host()
+    st = ctx.list_stats()
+    g = ctx.grads_alloc()
+    ctx.backward(dC, g)
+    grads = ctx.grads_read(g, deg)
+    return dict(img=img, tr=tr, grads=grads, wc=ctx.work_counters_ex(), st=st, inst=ctx.num_instances)
+
+
+def _same_bits(a, b, det=True):
+    assert np.array_equal(a["img"], b["img"]) and np.array_equal(a["tr"], b["tr"])
+    assert a["wc"]["walked_fwd"] == b["wc"]["walked_fwd"] == b["wc"]["walked_bwd"]
+    assert a["wc"]["evaluated_fwd"] == b["wc"]["evaluated_fwd"] == b["wc"]["evaluated_bwd"]
+    for k in GRADS:
+        if det:
+            assert np.array_equal(a["grads"][k], b["grads"][k]), k
+        else:
+            assert rel_l2(b["grads"][k].reshape(-1), a["grads"][k].reshape(-1)) <= 1e-5, k
+
+
+def _dense_scene(n, W, H, deg, seed, grow=1.0):
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
+    sc["scales"] = (sc["scales"] + np.float32(grow)).astype(np.float32)     # dense: pixels freeze long before their lists end
+    return sc, cam, T, P, ocam
+
+
+@pytest.mark.parametrize("det", [True, False])
+def test_capped_lists_from_slot_history_are_invisible(oracle, det):
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    n, W, H, deg = 120_000, 648, 470, 2                                       # 41 x 30 tiles (ragged both ways), 6 x 4 super-tiles
+    sc, cam, T, P, ocam = _dense_scene(n, W, H, deg, 31)
+    dC = synthetic.make_dC(W, H, 31)
+    plain = hip_context(sc, cam, T, P, W, H, deg, deterministic=det, list_cap=1, slab_mode=0)
+    ref = _frame(plain, dC, deg, slot=7)
+    assert not ref["st"]["capped"] and ref["st"]["listed"] == ref["inst"]
+    assert ref["wc"]["walked_fwd"] < 0.5 * ref["inst"]                         # the scene is dense enough for caps to matter
+    ctx = hip_context(sc, cam, T, P, W, H, deg, deterministic=det, list_cap=2, slab_mode=0)
+    f1 = _frame(ctx, dC, deg, slot=7)                                          # no history yet: full lists
+    assert not f1["st"]["capped"]
+    _same_bits(ref, f1, det)
+    for rep in range(3):                                                       # history from the same view: capped, nothing to extend
+        f = _frame(ctx, dC, deg, slot=7)
+        assert f["st"]["capped"] and f["st"]["extended_segments"] == 0, f["st"]
+        assert f["wc"]["walked_fwd"] <= f["st"]["listed"] < 0.8 * f["inst"], (f["st"], f["inst"], f["wc"])
+        _same_bits(ref, f, det)
+    # the full ranges are always there; asking for the ids writes the unwritten rest, and the frame still finishes
+    ctx.set_view_slot(7); ctx.preprocess(); ctx.bin()
+    oref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+    assert np.array_equal(ctx.get_array(B.ARR_TILE_RANGES), oref["ranges"])
+    img, tr = ctx.forward_host()
+    assert ctx.list_stats()["capped"]
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_IDS), oref["ids"])
+    assert np.array_equal(ctx.get_array(B.ARR_SORTED_KEYS), oref["keys"])
+    assert not ctx.list_stats()["capped"]
+    g = ctx.grads_alloc(); ctx.backward(dC, g)
+    got = ctx.grads_read(g, deg)
+    assert np.array_equal(img, ref["img"]) and np.array_equal(tr, ref["tr"])
+    for k in GRADS:
+        if det:
+            assert np.array_equal(got[k], ref["grads"][k]), k
+    # a frame under another slot has no history: full lists again
+    f = _frame(ctx, dC, deg, slot=2000)                                        # (slots up to 4095: the old limit was 64)
+    assert not f["st"]["capped"]
+    _same_bits(ref, f, det)
+    plain.close(); ctx.close()
+
+
+def test_camera_jump_under_a_reused_slot_extends_lists_in_the_kernel():
+    """The slot's history comes from another view: many tiles walk further than their cap.  The waves append what they need."""
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg = 150_000, 640, 480, 1
+    sc, cam, T, P, ocam = _dense_scene(n, W, H, deg, 32, grow=0.6)
+    # the right third of the scene is made nearly transparent: those tiles never saturate and walk their whole lists in view A
+    far = sc["means"][:, 0] > np.quantile(sc["means"][:, 0], 0.66)
+    sc["opacities"][far] = np.float32(-6.0)
+    dC = synthetic.make_dC(W, H, 32)
+    camA = synthetic.scene_camera(W, view=0)
+    camB = synthetic.scene_camera(W, view=4)                                   # from behind: the transparent third is on the other side
+    ctx = hip_context(sc, cam, T, P, W, H, deg, deterministic=True, list_cap=2, slab_mode=0)
+    plain = hip_context(sc, cam, T, P, W, H, deg, deterministic=True, list_cap=1, slab_mode=0)
+    _set_cam(ctx, camA, W, H); _set_cam(plain, camA, W, H)
+    a0 = _frame(plain, dC, deg, slot=5)
+    for _ in range(2):
+        a = _frame(ctx, dC, deg, slot=5)
+        _same_bits(a0, a)
+    assert a["st"]["capped"]
+    _set_cam(ctx, camB, W, H); _set_cam(plain, camB, W, H)                     # the jump: slot 5 now shows view B
+    b0 = _frame(plain, dC, deg, slot=5)
+    b = _frame(ctx, dC, deg, slot=5)
+    assert b["st"]["capped"] and b["st"]["extended_segments"] > 0, b["st"]
+    _same_bits(b0, b)
+    b2 = _frame(ctx, dC, deg, slot=5)                                          # the history has caught up
+    assert b2["st"]["capped"] and b2["st"]["extended_segments"] == 0, b2["st"]
+    _same_bits(b0, b2)
+    ctx.close(); plain.close()
+
+
+@pytest.mark.parametrize("n,W,H,deg,grow", [(120_000, 648, 470, 2, 1.0), (40_000, 256, 208, 3, 0.3), (300, 96, 64, 0, 0.0)])
+def test_minimum_caps_everywhere(oracle, n, W, H, deg, grow):
+    """GS_DEBUG_TINY_CAPS: every tile's list is written up to its first segment(s) only; every tile that walks further extends
+    its list -- also the tiles that never saturate, which end up appending their whole list.  Bits as with full lists, and vs
+    the oracle within the usual bars."""
+    from gaussiansplat_amd import backend as B, synthetic
+    O = oracle
+    sc, cam, T, P, ocam = _dense_scene(n, W, H, deg, 33, grow=grow)
+    dC = synthetic.make_dC(W, H, 33)
+    for det in (True, False):
+        plain = hip_context(sc, cam, T, P, W, H, deg, deterministic=det, list_cap=1, slab_mode=0)
+        ref = _frame(plain, dC, deg); plain.close()
+        ctx = hip_context(sc, cam, T, P, W, H, deg, deterministic=det, slab_mode=0, debug_flags=B.GS_DEBUG_TINY_CAPS)
+        for rep in range(2):
+            f = _frame(ctx, dC, deg)
+            assert f["st"]["capped"]
+            if n >= 40_000:
+                assert f["st"]["extended_segments"] > 0
+            assert f["st"]["listed"] <= f["inst"]
+            _same_bits(ref, f, det)
+        ctx.close()
+    oref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, oref["ranges"], oref["ids"], dC, t_min=1e-5, omp=True)
+    assert np.all(np.abs(f["img"] - oref["image"]) <= 1e-4 + 1e-4 * np.abs(oref["image"]))
+    assert np.all(np.abs(f["tr"] - oref["trans"]) <= 1e-4 + 1e-4 * np.abs(oref["trans"]))
+    for k in GRADS:
+        assert rel_l2(f["grads"][k].reshape(-1), gref[k].reshape(-1)) <= 1e-3, k
+
+
+def test_caps_engage_by_default_only_on_large_grids_and_through_the_renderer_mirror():
+    """Default list_cap = 0: off on a grid of fewer tiles than wave slots, on at 1080p once the camera's slot has history; the
+    Python mirror names the slot by camera.id.  Two cameras alternate, as in bench.py."""
+    import torch
+    from gaussiansplat_amd import renderer as R, synthetic
+    n, W, H, deg = synthetic.CONFIGS["C3"]
+    sc = synthetic.make_scene(n, W, H, deg, seed=1236)
+    r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, sc, deterministic=True)
+    rp = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, sc, deterministic=True, list_cap=1)
+    dC = torch.as_tensor(synthetic.make_dC(W, H, 5)).cuda()
+    cams = [synthetic.scene_camera(W, view=0), synthetic.scene_camera(W, view=4)]
+    out = {}
+    for rr, name in ((rp, "plain"), (r, "capped")):
+        res = []
+        for i in range(6):
+            cam = cams[i % 2]
+            R.resetGrads(rr)
+            tps = R.preprocess(rr, cam); R.compactIdxs(rr); R.forward(rr, tps); R.backward(rr, dC)
+            torch.cuda.synchronize()
+            res.append((rr.imageData.cpu().numpy().copy(), rr.transmittance.cpu().numpy().copy(), rr.splatGrads.flat.cpu().numpy().copy(),
+                        rr.ctx.list_stats(), rr.ctx.num_instances))
+        out[name] = res
+    for i in range(6):
+        p, c = out["plain"][i], out["capped"][i]
+        assert np.array_equal(p[0], c[0]) and np.array_equal(p[1], c[1]) and np.array_equal(p[2], c[2]), i
+        assert not p[3]["capped"]
+        assert c[3]["capped"] == (i >= 2), (i, c[3])                            # the slot's first frame has no history
+        if i >= 2:
+            assert c[3]["extended_segments"] == 0 and c[3]["listed"] < 0.6 * c[4], (c[3], c[4])
+    small = R.getRenderer("GAUSSIAN_3D", (640, 480, 3), (16, 16), None, synthetic.make_scene(50_000, 640, 480, 1, seed=3))
+    for i in range(3):
+        tps = R.preprocess(small, synthetic.scene_camera(640)); R.compactIdxs(small); R.forward(small, tps)
+        assert not small.ctx.list_stats()["capped"]

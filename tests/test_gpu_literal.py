@@ -130,7 +130,7 @@ def test_viewer_export_of_a_rendered_image(oracle):
     O = oracle
     n, W, H, deg = 20_000, 416, 240, 3
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 606)
-    sc["shs"][:, 0, :] += np.float32(0.8)                                     # colours on both sides of the [0, 1] clamp
+    sc["shs"][:, 0, :] *= np.float32(8.0)                                     # sh2color = 0.28 dc + 0.5 with dc ~ N(0, 2.4): pixels below 0 and above 1
     ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5)
     r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, sc)
     tps = R.preprocess(r, cam); R.compactIdxs(r); R.forward(r, tps)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the per-gaussian backward kernels (SH kernel + geometry chain) of a frame on their own (GPU box):
 
-    [GS_SHBWD_T=128 GSPLAT_HIP_LIB=.../lib_exp/libgsplat_hip.so] python3 tools/ab_params.py [C3] [reps]
+    [GSPLAT_HIP_LIB=.../lib_TAG/libgsplat_hip.so] python3 tools/ab_params.py [C3] [reps]      (variant: build --tag TAG -DGS_SHBWD_THREADS=128)
 
 One frame is rendered, its composite adjoint run once, then GS_BWD_PARAMS_ONLY | GS_BWD_PARAMS_SH and | GS_BWD_PARAMS_GEOM are
 repeated back to back and timed with stream events (overwrite mode, as in the first backward after a reset)."""
@@ -23,7 +23,7 @@ dC = torch.as_tensor(synthetic.make_dC(W, H, 1)).cuda()
 r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, scene)
 tps = R.preprocess(r, cam); R.compactIdxs(r); R.forward(r, tps)
 R.backward(r, dC, phase="composite")
-out = {"config": cfg, "GS_SHBWD_T": os.environ.get("GS_SHBWD_T")}
+out = {"config": cfg, "lib": os.environ.get("GSPLAT_HIP_LIB")}
 for phase in ("params_sh", "params_geom", "params"):
     for _ in range(3):
         r.ctx.backward(dC.data_ptr(), r._grads, overwrite=True, phase=phase)

@@ -9,10 +9,9 @@ from gaussiansplat_amd import synthetic, backend as B
 import torch
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
-# variant = body + 10 * scheduling (gs_composite.hip launchers).  Scheduling: 1 one wave per tile in tile order, 3 plain launch over
-# the frame's longest-first order (production).  Bodies other than the default and the queue schedules 0 / 2 exist only in
-# GS_EXPERIMENTS builds (GSPLAT_HIP_LIB=gaussiansplat_amd/lib_exp/libgsplat_hip.so): forward 2 = 64-VGPR lean loop, 6 = the
-# default loop built for six waves per SIMD; backward 1 = reduce-scatter tree, 2 = software-pipelined transposed reduction.
+# variant tens digit = scheduling (gs_composite.hip: apply_sched_variant): 1 one wave per tile in tile order, 3 (or 0) the frame's
+# longest-first launch order (production); + 1000 the other alpha_cull setting; + 10000 with the two work-counter atomics per tile.
+# Other kernel BODIES are compared as whole libraries: python -m gaussiansplat_amd.build --tag NAME -D... and tools/ab_libs.sh.
 variants_f = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["10", "30"])]
 variants_b = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["10", "30"])]
 n, W, H, deg = synthetic.CONFIGS[cfg]

@@ -4,8 +4,7 @@
     python3 tools/tile_tail.py [C3] [out.json]
 
 For every scheduling variant (tens digit: 1 = one wave per tile in launch (tile) order; 3 = plain launch over the frame's
-longest-first order (gs_config.schedule 3: what the backward and the next forward of the view slot use); GS_EXPERIMENTS builds
-also 0 / 2 = persistent waves on per-XCD ticket queues) and both kernels it launches once with gs_debug_tile_clock and reports
+longest-first order (gs_config.schedule 3: what the backward and the next forward of the view slot use)) and both kernels it launches once with gs_debug_tile_clock and reports
   * kernel span (first start .. last end, 100 MHz s_memrealtime ticks -> microseconds),
   * the concurrency profile: time-weighted mean of waves in flight, and the share of the span spent below 50 % / 25 % of
     the peak concurrency (the tail),
@@ -80,6 +79,17 @@ def analyse(clk):
     # in-kernel shader-cycle stamps: per-entry loops vs everything else (staging a batch, waiting for its gathers, prologue/epilogue)
     loop_cyc = clk[ran, 4].astype(np.float64) if clk.shape[1] > 4 else np.zeros(len(dur))
     stage_cyc = clk[ran, 5].astype(np.float64) if clk.shape[1] > 5 else np.zeros(len(dur))
+    # frozen-pixel work inside live strips: per evaluated entry the kernel executes `exec` strip slots (forward:
+    # always 4; backward: the strips the entry's box can reach that still hold a live pixel); if the tile's live pixels were
+    # packed 64 to a slot it would need `ideal`; `alive` = strips holding any live pixel, `pix` = live pixels.
+    frozen = None
+    if clk.shape[1] > 7:
+        ex = (clk[ran, 6] >> np.uint64(32)).astype(np.float64); ideal = (clk[ran, 6] & np.uint64(0xFFFFFFFF)).astype(np.float64)
+        alive = (clk[ran, 7] >> np.uint64(32)).astype(np.float64); pix = (clk[ran, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64)
+        evs = max(float(evaluated.sum()), 1.0)
+        frozen = {"strip_slots_executed_per_entry": float(ex.sum() / evs), "strips_with_a_live_pixel_per_entry": float(alive.sum() / evs),
+                  "slots_if_live_pixels_packed_per_entry": float(ideal.sum() / evs), "live_pixels_per_entry": float(pix.sum() / evs),
+                  "packed_over_executed": float(ideal.sum() / max(ex.sum(), 1.0)), "live_pixel_share_of_executed_lanes": float(pix.sum() / max(64.0 * ex.sum(), 1.0))}
     # least squares: tile duration ~ a * walked + b * evaluated + c  (what a launch order should sort by)
     A = np.stack([walked.astype(np.float64), evaluated.astype(np.float64), np.ones(len(dur))], 1)
     coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
@@ -103,6 +113,7 @@ def analyse(clk):
         "walked_per_evaluated_by_decile": [float(walked[d].sum() / max(evaluated[d].sum(), 1)) for d in dec],
         "duration_fit_ticks": {"per_walked": float(coef[0]), "per_evaluated": float(coef[1]), "const": float(coef[2]),
                                "rms_residual_over_mean": float(np.sqrt((resid ** 2).mean()) / dur.mean())},
+        "frozen_pixels": frozen,
     }
 
 
@@ -117,9 +128,6 @@ def main():
     g = ctx.grads_alloc(); ctx.backward(dC, g); ctx.synchronize()
     res = {"config": cfg, "instances": ctx.num_instances, "work": ctx.work_counters_ex()}
     variants = {"fwd": [10, 30], "bwd": [10, 30]}
-    if "lib_exp" in os.environ.get("GSPLAT_HIP_LIB", ""):
-        variants["fwd"] += [36]                                          # the forward built for six waves per SIMD
-    res["lpt_buckets_env"] = os.environ.get("GS_LPT_BUCKETS")
     for which, name in ((0, "fwd"), (1, "bwd")):
         for v in variants[name]:
             a = analyse(ctx.tile_clock(which, v))
@@ -129,7 +137,7 @@ def main():
                                                          "share_of_span_below_50pct_of_peak", "t90_over_span",
                                                          "evaluated_per_simd_max_over_mean", "simd_finish_spread_us",
                                                          "simd_time_share_by_resident_waves_0_to_8", "simd_entries_per_us_by_resident_waves_0_to_8", "stage_share_of_stamped_cycles",
-                                                         "duration_fit_ticks")}), flush=True)
+                                                         "duration_fit_ticks", "frozen_pixels")}), flush=True)
     os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)
