@@ -345,6 +345,26 @@ def main():
     gc.collect()
     torch.cuda.empty_cache()
 
+    # Beside the headline (N = 1, single-view configs): the same K steps (a) on a FRESH renderer with the driver's W warm-up steps
+    # only -- no settle frames: what the first frames of a run cost (settle transient) -- and (b) without view slots: no
+    # launch-order history and no list caps, i.e. every frame rendered as if its camera had never been seen.
+    side_runs = {}
+    if world == 1 and views_per_step == 1 and args.settle_frames > 0 and not args.no_view_slots:
+        ru = make(args.t_min, 0)
+        side_runs["ms_per_step_unsettled"] = timed(ru, args.steps, args.warmup) / args.steps * 1e3
+        del ru
+        gc.collect(); torch.cuda.empty_cache()
+        keep = {v: c.id for v, c in cams.items()}
+        for c in cams.values():
+            c.id = None
+        rn = make(args.t_min, 0)
+        side_runs["no_view_slot_history"] = {"ms_per_step": timed(rn, args.steps, args.warmup, settle_frames=args.settle_frames) / args.steps * 1e3,
+                                             "what": "the same steps with no view slot named: the forward launches in tile order and every tile list is written in full"}
+        del rn
+        for v, c in cams.items():
+            c.id = keep[v]
+        gc.collect(); torch.cuda.empty_cache()
+
     # Pass B: THE timed region -- W warmup steps, then exactly K steps between barriers + synchronize.
     r = make(args.t_min, 2 + STAGES.index(dom))
     dt = timed(r, args.steps, args.warmup, settle_frames=args.settle_frames)
@@ -462,6 +482,7 @@ def main():
             "metric": "fwd+bwd Msplats/sec at 1M Gaussians, 1920x1080, SH deg 3" if args.config in ("C3", "C4") else f"fwd+bwd Msplats/sec ({args.config})",
             "value": value, "unit": "Msplats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            **side_runs,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": what + "; synthetic scene of SURVEY 8d with the quaternions NORMALISED (8d leaves N(0,1)^4 raw: the reference "
                                           "never normalises q and |q| scales every footprint by |q|^4; un-normalised q is parity-tested, "

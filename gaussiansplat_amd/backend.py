@@ -403,11 +403,11 @@ class Context:
         return float(ms.value)
 
     def tile_clock(self, which: int, variant: int = 0) -> np.ndarray:
-        """[ntiles, 8] uint64 per tile {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, walked << 32 | evaluated, shader cycles
+        """[ntiles, 14] uint64 per tile {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, walked << 32 | evaluated, shader cycles
         inside the per-entry loops, shader cycles outside them, strip slots executed << 32 | slots with live pixels packed,
         strips with a live pixel << 32 | live pixels} of one composite launch (which: 0 forward, 1 backward)."""
         ntiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-        out = np.zeros((ntiles, 8), np.uint64)
+        out = np.zeros((ntiles, 14), np.uint64)
         self._chk(self.L.gs_debug_tile_clock(self.h, which, variant, C.c_void_p(out.ctypes.data)))
         return out
 

@@ -118,8 +118,9 @@ static int two_level_lists(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, 
 
 // Capped lists: whose history, if any, caps the lists of the frame being binned (null: every list is written in full).  Engages on
 // one-round frames of the two-level path with the early-out on, when the frame's view slot has rendered this grid before, and --
-// unless gs_config.list_cap = 2 -- only on grids with more tiles than wave slots (below that the write pass is a few microseconds
-// and the extra launch costs more than it saves, like the launch orders: lpt_schedule).
+// unless gs_config.list_cap = 2 -- only when the ctx's previous frame walked less than GS_LIST_CAP_MAX_RATIO of its list entries on a
+// grid with more tiles than wave slots.
+#define GS_LIST_CAP_MAX_RATIO 0.15
 static int list_cap_source(gs_ctx *c, int rounds, const uint32_t **out) {
     *out = nullptr;
     const int64_t ntiles = (int64_t)c->gx * c->gy, grid = ((int64_t)c->gx << 32) | (int64_t)c->gy;
@@ -132,7 +133,9 @@ static int list_cap_source(gs_ctx *c, int rounds, const uint32_t **out) {
         *out = c->zero_tiles.as<uint32_t>();
         return GS_OK;
     }
-    if (ntiles <= 5120 && c->cfg.list_cap != 2) return GS_OK;
+    // Engages where it pays (measured, profiles/r04b_kernel_stats_*): the write pass is bound by its entries only when most of them
+    // are never walked -- C5 (6 % walked): 591 -> 129 us; at C3 (28 % walked) the pass goes 45 -> 37 us and the cap pass costs that.
+    if (c->cfg.list_cap != 2 && (ntiles <= 5120 || !(c->walked_ratio >= 0.0 && c->walked_ratio < GS_LIST_CAP_MAX_RATIO))) return GS_OK;
     const int k = order_index(c);
     if (k == GS_MAX_VIEW_SLOTS && c->cfg.schedule != 4) return GS_OK;          // frames without a slot: history only under schedule 4
     if (c->slots[k].walked_grid != grid || !c->slots[k].walked.p) return GS_OK;

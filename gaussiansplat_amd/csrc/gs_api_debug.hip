@@ -269,7 +269,7 @@ int gs_get_list_stats(gs_ctx *c, int64_t out[3]) {
     if (!c->frame_capped || c->n_rounds != 1) return GS_OK;
     unsigned long long *d = reinterpret_cast<unsigned long long *>(static_cast<char *>(c->counters.p) + 160), h = 0;
     uint32_t e = 0;
-    HIPCHK(c, gs_launch_sum_listed(c->ranges.as<uint32_t>(), c->tile_ext.as<uint2>(), c->gx * c->gy, d, c->stream));
+    HIPCHK(c, gs_launch_sum_listed(c->tile_ext.as<uint2>(), c->gx * c->gy, d, c->stream));
     HIPCHK(c, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&e, c->ext_count(), sizeof(e), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

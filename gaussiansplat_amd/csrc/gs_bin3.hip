@@ -421,7 +421,7 @@ __global__ __launch_bounds__(L2_THREADS) void l2_count_kernel(GsBin3Args a) {
 
 // Capped lists (GsBin3Args.cap_src): one wave per super-tile, lane = local tile.  A tile takes the entries of the segments of its
 // super-tile's list in order until it holds gs_list_cap(walked by the slot's previous forward) of them; tile_nopen = how many
-// segments that is, tile_ext = {entries those segments give it (l2_ranges adds the list start), coarse index of the first segment it
+// segments that is, tile_ext = {entries those segments give it = the written LENGTH of its list, coarse index of the first segment it
 // does NOT take or GS_CONT_NONE when it takes them all}, smax = the largest tile_nopen of the super-tile.  The lists themselves
 // (positions, order, ranges) are those of the uncapped path: only fewer of their entries are written.
 __global__ __launch_bounds__(GS_WAVE) void l2_cap_kernel(GsBin3Args a) {
@@ -454,10 +454,9 @@ __global__ __launch_bounds__(GS_WAVE) void l2_cap_kernel(GsBin3Args a) {
 }
 
 // tile ranges = exclusive scan of the tile counts in tile order (one workgroup); completed tiles get an empty range
-// ext (capped lists): on entry ext[t].x = entries written for tile t, on exit the entry index where its written list ends
 __global__ __launch_bounds__(1024) void l2_ranges_kernel(const uint32_t *__restrict__ tilecnt, int ntiles, const uint8_t *__restrict__ done,
                                                           uint32_t *__restrict__ ranges, const uint32_t *__restrict__ totals, uint32_t cap_coarse,
-                                                          uint32_t cap_fine, uint2 *__restrict__ ext) {
+                                                          uint32_t cap_fine, uint2 *__restrict__ ext) {      // ext (capped lists): reset when nothing is listed
     __shared__ uint32_t sm[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (lists_overflow(totals, cap_coarse, cap_fine)) {                  // nothing was listed: every range empty
@@ -484,7 +483,7 @@ __global__ __launch_bounds__(1024) void l2_ranges_kernel(const uint32_t *__restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int t = b0 + tid * 4 + k;
-            if (t < ntiles) { ranges[2 * t] = off; ranges[2 * t + 1] = off + v[k]; if (ext) ext[t].x += off; }
+            if (t < ntiles) { ranges[2 * t] = off; ranges[2 * t + 1] = off + v[k]; }
             off += v[k];
         }
         carry += all;

@@ -212,7 +212,7 @@ struct GsBin3Args {
     const uint32_t *cap_src;   // [tiles] or null (no caps: every list written in full)
     uint32_t *tile_nopen;      // [tiles] segments of its super-tile's list the tile takes entries from
     uint32_t *smax;            // [ns]    the largest tile_nopen of the super-tile (later segments have no work at all)
-    uint2 *tile_ext;           // [tiles] {written end of the list (entry index), coarse index where the unwritten rest starts or GS_CONT_NONE}
+    uint2 *tile_ext;           // [tiles] {written length of the list (entries from its range start), coarse index where the unwritten rest starts or GS_CONT_NONE}
     uint32_t *ext_count;       // one word zeroed by the cap pass: list segments appended by composite waves (GsCompositeArgs.ext_count)
 };
 #define GS_CONT_NONE 0xFFFFFFFFu
@@ -230,7 +230,7 @@ hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s);
 hipError_t gs_bin3_write_lists(const GsBin3Args &a, hipStream_t s);      // the write pass alone (counts and ranges of the frame still valid)
 hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, uint8_t *sdone, hipStream_t s);
 
-#define GS_TILE_CLOCK_WORDS 8
+#define GS_TILE_CLOCK_WORDS 14
 #define GS_MAX_ROUNDS 4   // binning rounds (depth slabs) of one frame
 #define GS_G2D_STRIDE 16   // floats (or fixed-point words) per gaussian row of the composite backward's sums: ten used, padded to ONE
                            // 64-byte sector so that the 9-lane atomic of a (tile, splat) entry is a single memory-side request
@@ -261,7 +261,8 @@ struct GsCompositeArgs {
     unsigned long long *tile_clock; // debug: GS_TILE_CLOCK_WORDS per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated,
                                     // shader cycles (s_memtime) inside the per-entry loops, shader cycles outside them (staging, waiting for the gathers),
                                     // strip slots executed << 32 | slots if the live pixels were packed 64 to a slot, strips with a live pixel << 32 | live pixels
-                                    // (the last four summed over the evaluated entries)}
+                                    // (the last four summed over the evaluated entries); forward only: six words = the evaluated entries by the
+                                    // slots K = 1 .. 4 they would run on if live pixels were packed {anywhere, by whole rows, inside their column}}
     // frames binned in depth slabs (several rounds of binning + forward)
     int nseg;                  // backward: number of list segments per tile (= rounds of the frame, >= 1)
     const uint32_t *seg_ranges[GS_MAX_ROUNDS];   // backward: per round 2 x tiles [start, end) into seg_ids[round]
@@ -271,7 +272,7 @@ struct GsCompositeArgs {
     unsigned long long *tile_dead; // forward, slab frames: 4 lane masks per tile, bit l of word p = pixel slot p of lane l is frozen
     int resume;                // forward: continue from the pixel state the previous round left in image / trans
     int final_round;           // forward: last round of the frame: transmittance is written plain (no sign flag)
-    // capped lists (GsBin3Args.cap_src): tile_ext != null -> a tile's written list ends at tile_ext[t].x; the forward extends it from
+    // capped lists (GsBin3Args.cap_src): tile_ext != null -> a tile's written list has tile_ext[t].x entries; the forward extends it from
     // the super-tile's coarse list (cranges / cids / clr) when it gets there with live pixels and stores the new end; the backward
     // only reads tile_ext[t].x (it stops where the forward stopped, or at the end the forward left)
     uint2 *tile_ext;
@@ -281,8 +282,8 @@ struct GsCompositeArgs {
     int sgx;
     uint32_t *ext_count;       // segments appended by the forward's waves (one atomic per extension: the rare path), may be null
 };
-// the written entries of capped lists, summed over the tiles: out[0] = sum (ext[t].x - ranges[2 t])
-hipError_t gs_launch_sum_listed(const uint32_t *ranges, const uint2 *ext, int n, unsigned long long *out, hipStream_t s);
+// the written entries of capped lists, summed over the tiles: out[0] = sum ext[t].x
+hipError_t gs_launch_sum_listed(const uint2 *ext, int n, unsigned long long *out, hipStream_t s);
 // longest-first launch order of the tiles for a plain launch (gs_composite.hip: groups of 8 x 8 tiles dealt to the XCDs by work,
 // GS_LPT_BUCKETS work classes inside an XCD's list; one workgroup).  order: gs_lpt_order_len(gx, gy) entries, holes = 0xFFFFFFFF.
 // zero14 (may be null): fourteen 64-bit words zeroed on the way (the backward's work and ticket counters: saves a memset command)

@@ -217,7 +217,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     uint32_t s1 = a.ranges[2 * tile + 1];
     uint32_t cont = GS_CONT_NONE;                                  // capped lists: where the unwritten rest of the list starts in the coarse list
     const bool capped = !SLAB && EARLY && a.tile_ext != nullptr;
-    if (capped) { const uint2 ex = a.tile_ext[tile]; s1 = ex.x; cont = ex.y; }
+    if (capped) { const uint2 ex = a.tile_ext[tile]; s1 = s0 + ex.x; cont = ex.y; }
     const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);     // first pixel of the tile (1-based)
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
@@ -265,6 +265,11 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     // any live pixel, and live pixels, each summed over the evaluated entries (frozen-pixel work inside live strips)
     unsigned long long clk_exec = 0, clk_ideal = 0, clk_alive = 0, clk_pix = 0;
     uint32_t clk_live = 0, clk_strips = 0;
+    // ... and, for three ways of packing the live pixels into fewer 64-lane slots, the evaluated entries by the slots K = 1 .. 4 they
+    // would run on: any pixel anywhere (K = ceil(live / 64)); whole pixel ROWS moved (a lane keeps its column: K = ceil(rows with a
+    // live pixel / 4)); pixels moved inside their COLUMN (K = ceil(fullest column / 4))
+    uint32_t clk_hist[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    int clk_k[3] = {4, 4, 4};
     if (CLK) t_mark = __builtin_amdgcn_s_memtime();
     for (;;) {                                                          // (capped lists: once more per segment the wave appends itself)
     bool stopped = false;
@@ -287,8 +292,17 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         }
         if (CLK && (phase == 0 || base == s0)) {                         // debug: live pixels / strips with a live pixel in this batch
             clk_live = 0; clk_strips = 0;
+            uint32_t rows = 0, colcnt[16];
+            for (int cidx = 0; cidx < 16; ++cidx) colcnt[cidx] = 0;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { const uint64_t m = __ballot(!dead[p]); clk_live += (uint32_t)__popcll(m); clk_strips += m ? 1u : 0u; }
+            for (int p = 0; p < 4; ++p) {
+                const uint64_t m = __ballot(!dead[p]); clk_live += (uint32_t)__popcll(m); clk_strips += m ? 1u : 0u;
+                for (int r4 = 0; r4 < 4; ++r4) rows += ((m >> (16 * r4)) & 0xFFFFull) ? 1u : 0u;
+                for (int cidx = 0; cidx < 16; ++cidx) colcnt[cidx] += (uint32_t)__popcll(m & (0x0001000100010001ull << cidx));
+            }
+            uint32_t cmax = 0;
+            for (int cidx = 0; cidx < 16; ++cidx) cmax = max(cmax, colcnt[cidx]);
+            clk_k[0] = (int)((clk_live + 63u) >> 6); clk_k[1] = (int)((rows + 3u) >> 2); clk_k[2] = (int)((cmax + 3u) >> 2);
         }
         uint32_t strips;
         bool keep;
@@ -339,6 +353,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t;
             clk_exec += 4ull * (uint32_t)nk; clk_ideal += (unsigned long long)nk * ((clk_live + 63u) >> 6);
             clk_alive += (unsigned long long)nk * clk_strips; clk_pix += (unsigned long long)nk * clk_live;
+            for (int w = 0; w < 3; ++w) if (clk_k[w] >= 1 && clk_k[w] <= 4) clk_hist[w][clk_k[w] - 1] += (uint32_t)nk;
         }
     }
     if (!capped || stopped || cont == GS_CONT_NONE) break;
@@ -347,7 +362,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     s1 = extend_tile_list(a, tile, cont, s1);
     pos = base + lane;
     }
-    if (capped && lane == 0) a.tile_ext[tile] = make_uint2(s1, cont);   // (unchanged unless the list was extended) the backward's list end
+    if (capped && lane == 0) a.tile_ext[tile] = make_uint2(s1 - s0, cont);   // (unchanged unless the list was extended) the backward's list length
     bool anylive = false;
 #pragma unroll
     for (int p = 0; p < 4; ++p) anylive = anylive || !dead[p];
@@ -383,6 +398,10 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         c[3] = ((unsigned long long)walked << 32) | evaluated;
         c[4] = t_loop; c[5] = t_stage;
         c[6] = (clk_exec << 32) | (clk_ideal & 0xFFFFFFFFull); c[7] = (clk_alive << 32) | (clk_pix & 0xFFFFFFFFull);
+        for (int w = 0; w < 3; ++w) {
+            c[8 + 2 * w] = ((unsigned long long)clk_hist[w][0] << 32) | clk_hist[w][1];
+            c[9 + 2 * w] = ((unsigned long long)clk_hist[w][2] << 32) | clk_hist[w][3];
+        }
     }
 }
 
@@ -529,7 +548,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const uint32_t *ids = a.seg_ids[sg];
     const uint32_t s0 = a.seg_ranges[sg][2 * tile];
     // capped lists: the list ends where gs_bin -- or the forward, if it had to go further -- stopped writing it (>= what the forward walked)
-    const uint32_t s1 = a.tile_ext ? a.tile_ext[tile].x : a.seg_ranges[sg][2 * tile + 1];
+    const uint32_t s1 = a.tile_ext ? s0 + a.tile_ext[tile].x : a.seg_ranges[sg][2 * tile + 1];
     uint32_t pos = s0 + lane;
     uint32_t id2 = 0;                                                     // ids run two batches ahead, payload rows one (see the forward)
     {
@@ -816,19 +835,18 @@ __global__ __launch_bounds__(1024) void sum_tiles_kernel(const uint32_t *__restr
     __syncthreads();
     if (threadIdx.x < 2) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += sm[threadIdx.x][k]; out[threadIdx.x] = t; }
 }
-__global__ __launch_bounds__(1024) void sum_listed_kernel(const uint32_t *__restrict__ ranges, const uint2 *__restrict__ ext, int n,
-                                                           unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(1024) void sum_listed_kernel(const uint2 *__restrict__ ext, int n, unsigned long long *__restrict__ out) {
     __shared__ unsigned long long sm[16];
     unsigned long long sa = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) sa += ext[i].x - ranges[2 * i];
+    for (int i = threadIdx.x; i < n; i += 1024) sa += ext[i].x;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) sa += __shfl_down(sa, d);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sa;
     __syncthreads();
     if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < 16; ++k) t += sm[k]; out[0] = t; }
 }
-hipError_t gs_launch_sum_listed(const uint32_t *ranges, const uint2 *ext, int n, unsigned long long *out, hipStream_t s) {
-    hipLaunchKernelGGL(sum_listed_kernel, dim3(1), dim3(1024), 0, s, ranges, ext, n, out);
+hipError_t gs_launch_sum_listed(const uint2 *ext, int n, unsigned long long *out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_listed_kernel, dim3(1), dim3(1024), 0, s, ext, n, out);
     return hipGetLastError();
 }
 hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsigned long long *out, hipStream_t s) {

@@ -137,7 +137,8 @@ typedef struct {
                                  as that frame walked it (+ 25 % + 128 entries, rounded up to a segment of the two-level binning); a
                                  composite wave that gets to the written end with pixels still taking entries writes the next
                                  segment of its tile's list itself and goes on, so nothing depends on the history being right.
-                                 Engages on grids of more than 5120 tiles (below that the write pass is a few microseconds).
+                                 Engages when the ctx's previous frame walked less than 15 % of its list entries on a grid of more
+                                 than 5120 tiles (measured: at 28 % walked the shorter write pass only pays for the extra cap pass).
                                  1 never; 2 also on small grids (tests).  GS_ARR_TILE_RANGES is always the full ranges; asking for
                                  GS_ARR_SORTED_IDS / _KEYS of a capped frame first writes the unwritten rest.                   */
     int32_t reserved[4];      /* sizeof(gs_config) == 96                                                                       */
@@ -368,10 +369,11 @@ int gs_get_work_counters_ex(gs_ctx *ctx, int64_t out[4]);
 int gs_debug_time_composite(gs_ctx *ctx, int which, int variant, int reps, float *mean_ms);
 
 /* Profiling aid: one launch of the composite forward (which=0) or backward (which=1) kernel of the current frame with
- * per-tile clocks.  out (HOST): 8 x gx*gy uint64 per tile {start, end (100 MHz s_memrealtime ticks), HW_ID | XCC_ID << 32,
+ * per-tile clocks.  out (HOST): 14 x gx*gy uint64 per tile {start, end (100 MHz s_memrealtime ticks), HW_ID | XCC_ID << 32,
  * walked << 32 | evaluated, shader cycles inside the per-entry loops, shader cycles outside them (staging a batch and waiting
  * for its gathers), per-entry strip slots executed << 32 | the slots needed if the tile's live pixels were packed 64 to a slot,
- * strips holding a live pixel << 32 | live pixels (the last four summed over the evaluated entries)}.
+ * strips holding a live pixel << 32 | live pixels (the last four summed over the evaluated entries), and (forward) six words: the
+ * evaluated entries by the number of 64-lane slots they would need with live pixels packed anywhere / by whole rows / inside columns}.
  * tools/tile_tail.py turns it into the occupancy-over-time, tail and frozen-pixel summaries under profiles/. */
 int gs_debug_tile_clock(gs_ctx *ctx, int which, int variant, uint64_t *out);
 

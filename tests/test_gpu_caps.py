@@ -155,12 +155,14 @@ def test_minimum_caps_everywhere(oracle, n, W, H, deg, grow):
 
 
 def test_caps_engage_by_default_only_on_large_grids_and_through_the_renderer_mirror():
-    """Default list_cap = 0: off on a grid of fewer tiles than wave slots, on at 1080p once the camera's slot has history; the
-    Python mirror names the slot by camera.id.  Two cameras alternate, as in bench.py."""
+    """Default list_cap = 0: on at 1080p once the camera's slot has history AND the ctx's previous frame walked under 15 % of its list
+    entries (a dense scene); off at C3's 28 % (the write pass does not pay there: profiles/r04b_kernel_stats_C3*) and on a grid of fewer
+    tiles than wave slots.  The Python mirror names the slot by camera.id.  Two cameras alternate, as in bench.py."""
     import torch
     from gaussiansplat_amd import renderer as R, synthetic
-    n, W, H, deg = synthetic.CONFIGS["C3"]
+    n, W, H, deg = 400_000, 1920, 1080, 3
     sc = synthetic.make_scene(n, W, H, deg, seed=1236)
+    sc["scales"] = (sc["scales"] + np.float32(1.0)).astype(np.float32)        # dense: under 15 % of the entries are walked
     r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, sc, deterministic=True)
     rp = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, sc, deterministic=True, list_cap=1)
     dC = torch.as_tensor(synthetic.make_dC(W, H, 5)).cuda()
@@ -183,7 +185,15 @@ def test_caps_engage_by_default_only_on_large_grids_and_through_the_renderer_mir
         assert c[3]["capped"] == (i >= 2), (i, c[3])                            # the slot's first frame has no history
         if i >= 2:
             assert c[3]["extended_segments"] == 0 and c[3]["listed"] < 0.6 * c[4], (c[3], c[4])
-    small = R.getRenderer("GAUSSIAN_3D", (640, 480, 3), (16, 16), None, synthetic.make_scene(50_000, 640, 480, 1, seed=3))
-    for i in range(3):
+    assert out["capped"][5][3]["listed"] < 0.4 * out["capped"][5][4]
+    dense_small = synthetic.make_scene(50_000, 640, 480, 1, seed=3)
+    dense_small["scales"] = (dense_small["scales"] + np.float32(1.0)).astype(np.float32)
+    small = R.getRenderer("GAUSSIAN_3D", (640, 480, 3), (16, 16), None, dense_small)
+    for i in range(4):
         tps = R.preprocess(small, synthetic.scene_camera(640)); R.compactIdxs(small); R.forward(small, tps)
-        assert not small.ctx.list_stats()["capped"]
+        assert not small.ctx.list_stats()["capped"]                             # 1200 tiles: fewer than wave slots
+    n3, W3, H3, d3 = synthetic.CONFIGS["C3"]
+    c3 = R.getRenderer("GAUSSIAN_3D", (W3, H3, 3), (16, 16), None, synthetic.make_scene(n3, W3, H3, d3, seed=1236))
+    for i in range(4):
+        tps = R.preprocess(c3, synthetic.scene_camera(W3)); R.compactIdxs(c3); R.forward(c3, tps)
+        assert not c3.ctx.list_stats()["capped"]                                # 28 % of the entries walked: full lists

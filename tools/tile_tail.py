@@ -90,6 +90,13 @@ def analyse(clk):
         frozen = {"strip_slots_executed_per_entry": float(ex.sum() / evs), "strips_with_a_live_pixel_per_entry": float(alive.sum() / evs),
                   "slots_if_live_pixels_packed_per_entry": float(ideal.sum() / evs), "live_pixels_per_entry": float(pix.sum() / evs),
                   "packed_over_executed": float(ideal.sum() / max(ex.sum(), 1.0)), "live_pixel_share_of_executed_lanes": float(pix.sum() / max(64.0 * ex.sum(), 1.0))}
+        if clk.shape[1] > 13 and clk[ran, 8:14].sum() > 0:              # forward: evaluated entries by the slots K they would need
+            for w, name in enumerate(("any_pixel_anywhere", "whole_rows", "inside_columns")):
+                h = [float((clk[ran, 8 + 2 * w] >> np.uint64(32)).sum()), float((clk[ran, 8 + 2 * w] & np.uint64(0xFFFFFFFF)).sum()),
+                     float((clk[ran, 9 + 2 * w] >> np.uint64(32)).sum()), float((clk[ran, 9 + 2 * w] & np.uint64(0xFFFFFFFF)).sum())]
+                tot = max(sum(h), 1.0)
+                frozen["entries_share_by_slots_1_to_4_" + name] = [round(x / tot, 4) for x in h]
+                frozen["mean_slots_" + name] = sum((k + 1) * x for k, x in enumerate(h)) / tot
     # least squares: tile duration ~ a * walked + b * evaluated + c  (what a launch order should sort by)
     A = np.stack([walked.astype(np.float64), evaluated.astype(np.float64), np.ones(len(dur))], 1)
     coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
