@@ -308,7 +308,8 @@ def main():
         for k in range(warmup):
             step(r, k0 + k)
         torch.cuda.synchronize()
-        stage_stats(r, reset=True)
+        if int(r.ctx.cfg.profile_stages):
+            stage_stats(r, reset=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -34,6 +34,8 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
 GS_ABI_VERSION = 3          # include/gsplat.h; load() refuses a library that reports another version
 GS_DEBUG_WIDE_CURSORS = 1
 GS_DEBUG_ALWAYS_ORDER = 2     # launch orders + side stream also on small frames (tests)
+GS_DEBUG_SUPER16 = 8          # two-level binning: super-tiles of 16 x 16 tiles whatever the grid (tests)
+GS_DEBUG_SUPER8 = 16          # ... of 8 x 8 tiles whatever the grid
 GS_DEBUG_TINY_CAPS = 4        # capped lists with the minimum cap on every tile (tests: every busy tile extends its list in the composite kernel)
 GS_MAX_VIEW_SLOTS = 4096
 
@@ -403,11 +405,11 @@ class Context:
         return float(ms.value)
 
     def tile_clock(self, which: int, variant: int = 0) -> np.ndarray:
-        """[ntiles, 14] uint64 per tile {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, walked << 32 | evaluated, shader cycles
+        """[ntiles, 15] uint64 per tile {start, end (100 MHz ticks), HW_ID | XCC_ID << 32, walked << 32 | evaluated, shader cycles
         inside the per-entry loops, shader cycles outside them, strip slots executed << 32 | slots with live pixels packed,
         strips with a live pixel << 32 | live pixels} of one composite launch (which: 0 forward, 1 backward)."""
         ntiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-        out = np.zeros((ntiles, 14), np.uint64)
+        out = np.zeros((ntiles, 15), np.uint64)
         self._chk(self.L.gs_debug_tile_clock(self.h, which, variant, C.c_void_p(out.ctypes.data)))
         return out
 

@@ -56,7 +56,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (!(c0.slab_max_ratio >= 0.0f && c0.slab_max_ratio <= 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_max_ratio must be in [0, 1]");
     for (int i = 0; i < 3; ++i)
         if (!(c0.slab_fractions[i] >= 0.0f && c0.slab_fractions[i] < 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_fractions must be in [0, 1)");
-    if (c0.debug_flags & ~(GS_DEBUG_WIDE_CURSORS | GS_DEBUG_ALWAYS_ORDER | GS_DEBUG_TINY_CAPS)) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown debug_flags");
+    if (c0.debug_flags & ~(GS_DEBUG_WIDE_CURSORS | GS_DEBUG_ALWAYS_ORDER | GS_DEBUG_TINY_CAPS | GS_DEBUG_SUPER16 | GS_DEBUG_SUPER8)) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown debug_flags");
     if (c0.depth_sort < 0 || c0.depth_sort > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: depth_sort must be 0, 1 or 2");
     if (c0.list_cap < 0 || c0.list_cap > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: list_cap must be 0, 1 or 2");
     int ndev = 0;

@@ -54,7 +54,7 @@ static int plan_rounds(gs_ctx *c) {
 // the totals on the device with these numbers and list nothing when a buffer would overflow.
 static GsBin3L1 two_level_args(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, int64_t nr, const uint8_t *sdone, size_t cap_coarse, size_t cap_fine) {
     GsBin3L1 b{};
-    b.rect = c->rect.as<uint16_t>(); b.perm = perm_slab; b.sdone = sdone; b.n = n_all; b.n_slab = nr; b.sgx = c->sgx; b.ns = c->sgx * c->sgy;
+    b.rect = c->rect.as<uint16_t>(); b.perm = perm_slab; b.sdone = sdone; b.n = n_all; b.n_slab = nr; b.sgx = c->sgx; b.ns = c->sgx * c->sgy; b.sbs = c->sbs;
     b.rect_sorted = c->rect_sorted.as<uint32_t>(); b.table = c->l1_table.as<uint32_t>(); b.row_total = c->l1_rows.as<uint32_t>();
     b.partials = c->l1_partials.as<uint32_t>(); b.totals = c->bin_totals(); b.cranges = c->cranges.as<uint32_t>();
     b.cids = c->cids.as<uint32_t>(); b.clr = c->clr.as<uint16_t>();
@@ -94,12 +94,12 @@ static int two_level_lists(gs_ctx *c, const uint32_t *perm_slab, int64_t n_all, 
     const int64_t max_work = gs_bin3_max_work((int64_t)coarse, ns);
     HIPCHK(c, c->cids.ensure(sizeof(uint32_t) * coarse));
     HIPCHK(c, c->clr.ensure(sizeof(uint16_t) * coarse));
-    HIPCHK(c, c->segcnt.ensure(sizeof(uint32_t) * 64 * (size_t)max_work));
+    HIPCHK(c, c->segcnt.ensure(sizeof(uint32_t) * ((size_t)1 << (2 * c->sbs)) * (size_t)max_work));
     HIPCHK(c, gs_bin3_l1_scatter(two_level_args(c, perm_slab, n_all, nr, sdone, coarse, fine), c->stream));
     GsBin3Args a{};
     a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>(); a.ranges = ranges; a.tilecnt = c->tilecnt.as<uint32_t>();
     a.done = done; a.segcnt = c->segcnt.as<uint32_t>(); a.ids_out = ids_out;
-    a.gx = c->gx; a.gy = c->gy; a.sgx = c->sgx; a.ns = ns; a.max_work = (int)max_work;
+    a.gx = c->gx; a.gy = c->gy; a.sgx = c->sgx; a.ns = ns; a.sbs = c->sbs; a.max_work = (int)max_work;
     a.wide = (uint64_t)fine * 4ull >= (1ull << 32) || (c->cfg.debug_flags & GS_DEBUG_WIDE_CURSORS) != 0;
     a.totals = c->bin_totals(); a.cap_coarse = (uint32_t)std::min<size_t>(coarse, 0xFFFFFFFEu); a.cap_fine = (uint32_t)std::min<size_t>(fine, 0xFFFFFFFEu);
     if (cap_src && !done) {
@@ -153,7 +153,7 @@ static int bin_round_two_level(gs_ctx *c, int r) {
     HIPCHK(c, c->sdone.ensure((size_t)ns));
     {
         StageTimer t(c, GS_STAGE_COUNT_SCAN);
-        HIPCHK(c, gs_launch_super_done(c->tile_done.as<uint8_t>(), c->gx, c->gy, c->sgx, c->sgy, c->sdone.as<uint8_t>(), c->stream));
+        HIPCHK(c, gs_launch_super_done(c->tile_done.as<uint8_t>(), c->gx, c->gy, c->sgx, c->sgy, c->sbs, c->sdone.as<uint8_t>(), c->stream));
         if (int rc = two_level_count(c, perm, nr, nr, c->sdone.as<uint8_t>())) return rc;
     }
     HIPCHK(c, hipMemcpyAsync(c->pinned, c->bin_totals(), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -315,7 +315,8 @@ extern "C" int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     const int bin_path = c->cfg.bin_path;
     const bool fast = bin_path != 1 && passes <= 2 && hi_bits + gid_bits <= 32 && gs_tile_ranges_supported(c->gx, c->gy);
     // two-level path (gs_bin3.hip): lists per super-tile of 8 x 8 tiles first; its bitmap must fit in LDS
-    const int sb = 1 << gs_bin3_sb_shift();
+    c->sbs = gs_bin3_sb_shift(c->gx, c->gy, (c->cfg.debug_flags & GS_DEBUG_SUPER16) ? 4 : (c->cfg.debug_flags & GS_DEBUG_SUPER8) ? 3 : 0);
+    const int sb = 1 << c->sbs;
     c->sgx = (c->gx + sb - 1) / sb; c->sgy = (c->gy + sb - 1) / sb;
     c->two_level = fast && bin_path == 0 && gs_bin3_supported(c->sgx * c->sgy);
     c->tile_bits = tile_bits; c->gid_bits = gid_bits; c->lo_bits = lo_bits; c->hi_bits = hi_bits; c->fast_bin = fast;

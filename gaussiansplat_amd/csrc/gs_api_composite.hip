@@ -78,7 +78,7 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.tile_order = order; a.order_len = order ? gs_lpt_order_len(c->gx, c->gy) : 0;
     if (c->frame_capped && R == 1) {                                        // capped lists: the wave extends its tile's list when it must
         a.tile_ext = c->tile_ext.as<uint2>(); a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>();
-        a.ids_w = c->ids.as<uint32_t>(); a.sgx = c->sgx; a.ext_count = c->ext_count();
+        a.ids_w = c->ids.as<uint32_t>(); a.sgx = c->sgx; a.sbs = c->sbs; a.ext_count = c->ext_count();
     }
     if (R > 1) { a.tile_pos = c->tile_pos.as<uint32_t>(); a.tile_done = c->tile_done.as<uint8_t>(); a.tile_dead = c->tile_dead.as<unsigned long long>(); }
     StageTimer t(c, GS_STAGE_COMPOSITE_FWD);                               // the kernel alone

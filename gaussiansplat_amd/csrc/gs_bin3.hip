@@ -24,15 +24,20 @@
 // 16 B per instance for gs_bin2.hip.  The tile ranges are the exclusive scan of the level-2 hit counts.
 #include "gs_common.h"
 
-#define SB 8                 // super-tile edge in tiles
-#define SB_SHIFT 3
+// Super-tile edge: 8 tiles (SBS = 3), or 16 tiles (SBS = 4) on grids whose 8 x 8 super-tiles would be more than GS_BIN3_NS8_MAX:
+// level 1 works per (chunk of positions, super-tile) and its cost per position grows with the number of super-tiles (4K: 510 of
+// 8 x 8 -- l1_scatter 444 us at C5 -- against 135 of 16 x 16, the count of a 1080p frame), while level 2 only tests twice the rows.
+#define GS_BIN3_NS8_MAX 256
 #define L1_THREADS 256
 #ifndef L2_SEG
 #define L2_SEG 2048          // entries of a super-tile list per workgroup
 #endif
 #define L2_THREADS 256
 
-int gs_bin3_sb_shift() { return SB_SHIFT; }
+int gs_bin3_sb_shift(int gx, int gy, int force) {
+    if (force == 3 || force == 4) return force;
+    return ((gx + 7) / 8) * ((gy + 7) / 8) > GS_BIN3_NS8_MAX ? 4 : 3;
+}
 int gs_bin3_seg() { return L2_SEG; }
 int64_t gs_bin3_max_work(int64_t coarse_instances, int ns) { return coarse_instances / L2_SEG + ns; }
 // list positions per level-1 workgroup: the bitmap (ns x G bits), its word prefix (ns x G/32 u16), 2 ns starts and the
@@ -43,7 +48,7 @@ int gs_bin3_group(int ns) {
     while (g > 256 && l1_lds_bytes(ns, g) > 72 * 1024) g >>= 1;
     return g;
 }
-bool gs_bin3_supported(int ns) { return l1_lds_bytes(ns, 256) <= 140 * 1024 && ns < (1 << 20); }
+bool gs_bin3_supported(int ns) { return l1_lds_bytes(ns, 256) <= 140 * 1024 && ns < (1 << 16); }     // (l1_scatter packs S << 16 | clipped rectangle)
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
@@ -71,6 +76,7 @@ struct L1Args {
     const uint8_t *sdone;        // per super-tile: completed in an earlier round, takes no entries (null: none)
     int64_t n, n_slab;           // positions summed for the frame's instance count / positions listed by this round
     int sgx, ns, G, nwg;         // super-tile grid, positions per workgroup, workgroups covering n_slab
+    int sbs;                     // log2 of the super-tile edge in tiles (3 or 4)
     uint2 *rect_sorted;          // [n_slab] rectangles in list order (written by l1_hist, read by l1_scatter)
     uint32_t *table;             // [ns][nwg] coarse instances per (super-tile, workgroup) -> exclusive scan along nwg
     uint32_t *row_total;         // [ns]
@@ -78,7 +84,7 @@ struct L1Args {
     uint32_t *totals;            // [3] the sums of `partials` (0xFFFFFFFF: does not fit 32 bits)
     uint32_t *cranges;           // [ns][2]
     uint32_t *cids;              // coarse lists: gaussian ids in (super-tile, list order)
-    uint16_t *clr;               //               rectangle clipped to the super-tile: lx0 | lx1 << 3 | ly0 << 6 | ly1 << 9
+    uint16_t *clr;               //               rectangle clipped to the super-tile: lx0 | lx1 << sbs | ly0 << 2 sbs | ly1 << 3 sbs
     int nwg_all;
     uint32_t *tilecnt;           // [ntiles] zeroed here for the level-2 count pass
     int ntiles;
@@ -126,7 +132,7 @@ __device__ __forceinline__ void l1_bitmap(const L1Args &a, uint32_t *bm, int64_t
     fine_all = area;
     if (s >= a.n_slab) return;
     fine_slab = area;
-    const int cx0 = (int)(x0 - 1u) >> SB_SHIFT, cx1 = (int)(x1 - 1u) >> SB_SHIFT, cy0 = (int)(y0 - 1u) >> SB_SHIFT, cy1 = (int)(y1 - 1u) >> SB_SHIFT;
+    const int cx0 = (int)(x0 - 1u) >> a.sbs, cx1 = (int)(x1 - 1u) >> a.sbs, cy0 = (int)(y0 - 1u) >> a.sbs, cy1 = (int)(y1 - 1u) >> a.sbs;
     const uint32_t bit = 1u << (b & 31);
     uint32_t *col = bm + (b >> 5);
     for (int cy = cy0; cy <= cy1; ++cy)
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(1024) void l1_scatter_kernel(L1Args a) {
     uint32_t *gstart = bm + a.ns * wpr;                                 // [ns] first position of (S, this workgroup) in the coarse lists
     uint32_t *lstart = gstart + a.ns;                                   // [ns] first staging slot of S
     uint32_t *st_id = lstart + a.ns;                                    // [cap] staged gaussian ids, grouped by super-tile
-    uint32_t *st_ls = st_id + cap;                                      // [cap] clipped rectangle | S << 12
+    uint32_t *st_ls = st_id + cap;                                      // [cap] clipped rectangle | S << 16
     uint16_t *pre = reinterpret_cast<uint16_t *>(st_ls + cap);          // [ns][wpr] set bits of the row below word w
     const int chunk = l1_chunk((int)blockIdx.x, a.nwg);
     const int64_t base = (int64_t)chunk * a.G;
@@ -315,20 +321,21 @@ __global__ __launch_bounds__(1024) void l1_scatter_kernel(L1Args a) {
     const uint32_t x0 = rr.x & 0xFFFFu;
     if (x0 != 0u && s < a.n_slab) {
         const int fx0 = (int)x0 - 1, fx1 = (int)(rr.x >> 16) - 1, fy0 = (int)(rr.y & 0xFFFFu) - 1, fy1 = (int)(rr.y >> 16) - 1;
-        const int cx0 = fx0 >> SB_SHIFT, cx1 = fx1 >> SB_SHIFT, cy0 = fy0 >> SB_SHIFT, cy1 = fy1 >> SB_SHIFT;
+        const int sbs = a.sbs, SB = 1 << sbs;
+        const int cx0 = fx0 >> sbs, cx1 = fx1 >> sbs, cy0 = fy0 >> sbs, cy1 = fy1 >> sbs;
         const uint32_t below = (1u << (tid & 31)) - 1u;
         const int w = tid >> 5;
         for (int cy = cy0; cy <= cy1; ++cy) {
-            const int oy = cy << SB_SHIFT;
-            const uint32_t lry = (uint32_t)(((max(fy0, oy) - oy) << 6) | ((min(fy1, oy + SB - 1) - oy) << 9));
+            const int oy = cy << sbs;
+            const uint32_t lry = (uint32_t)(((max(fy0, oy) - oy) << (2 * sbs)) | ((min(fy1, oy + SB - 1) - oy) << (3 * sbs)));
             for (int cx = cx0; cx <= cx1; ++cx) {
                 const int S = cy * a.sgx + cx;
                 if (a.sdone && a.sdone[S]) continue;
                 const uint32_t rank = pre[S * wpr + w] + (uint32_t)__popc(bm[S * wpr + w] & below);
-                const int ox = cx << SB_SHIFT;
-                const uint32_t lr = lry | (uint32_t)((max(fx0, ox) - ox) | ((min(fx1, ox + SB - 1) - ox) << 3));
+                const int ox = cx << sbs;
+                const uint32_t lr = lry | (uint32_t)((max(fx0, ox) - ox) | ((min(fx1, ox + SB - 1) - ox) << sbs));
                 const uint32_t lp = lstart[S] + rank;
-                if (lp < cap) { st_id[lp] = gid; st_ls[lp] = lr | ((uint32_t)S << 12); }
+                if (lp < cap) { st_id[lp] = gid; st_ls[lp] = lr | ((uint32_t)S << 16); }
                 else { const uint32_t pos = gstart[S] + rank; a.cids[pos] = gid; a.clr[pos] = (uint16_t)lr; }
             }
         }
@@ -336,10 +343,10 @@ __global__ __launch_bounds__(1024) void l1_scatter_kernel(L1Args a) {
     __syncthreads();
     const uint32_t staged = min(lcarry, cap);
     for (uint32_t j = tid; j < staged; j += nt) {                       // runs: consecutive slots of a super-tile are consecutive list positions
-        const uint32_t ls = st_ls[j], S = ls >> 12;
+        const uint32_t ls = st_ls[j], S = ls >> 16;
         const uint32_t pos = gstart[S] + (j - lstart[S]);
         a.cids[pos] = st_id[j];
-        a.clr[pos] = (uint16_t)(ls & 0xFFFu);
+        a.clr[pos] = (uint16_t)(ls & 0xFFFFu);
     }
 }
 
@@ -350,28 +357,29 @@ template <int NT>
 __device__ bool find_work(const GsBin3Args &a, uint32_t *sh, int &S, uint32_t &e0, uint32_t &e1, uint32_t &w0) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t w = blockIdx.x;
-    if (tid == 0) { sh[8] = 0xFFFFFFFFu; sh[9] = 0; }
+    constexpr int R = NT / GS_WAVE;                        // sh[0 .. R): the waves' sums; sh[R .. R + 4): the work item found
+    if (tid == 0) { sh[R] = 0xFFFFFFFFu; sh[R + 1] = 0; }
     uint32_t carry = 0;
     for (int base = 0; base < a.ns; base += NT) {
         const int s = base + tid;
         uint32_t nseg = 0, c0 = 0, c1 = 0;
         if (s < a.ns) { const uint2 cr = reinterpret_cast<const uint2 *>(a.cranges)[s]; c0 = cr.x; c1 = cr.y; nseg = (c1 - c0 + (L2_SEG - 1)) / L2_SEG; }
         const uint32_t incl = wave_incl_scan_u32(nseg, lane);
-        __syncthreads();                                   // sh[0..7] free again (and the initial sh[8] visible)
+        __syncthreads();                                   // sh[0 .. R) free again (and the initial sh[R] visible)
         if (lane == 63) sh[wv] = incl;
         __syncthreads();
         uint32_t woff = 0, all = 0;
 #pragma unroll
         for (int k = 0; k < NT / GS_WAVE; ++k) { if (k < wv) woff += sh[k]; all += sh[k]; }
         const uint32_t excl = carry + woff + incl - nseg;
-        if (nseg && excl <= w && w < excl + nseg) { sh[8] = (uint32_t)s; sh[9] = excl; sh[10] = c0; sh[11] = c1; }
+        if (nseg && excl <= w && w < excl + nseg) { sh[R] = (uint32_t)s; sh[R + 1] = excl; sh[R + 2] = c0; sh[R + 3] = c1; }
         carry += all;
         if (carry > w) break;                              // uniform: carry is the same in every thread
     }
     __syncthreads();
-    if (sh[8] == 0xFFFFFFFFu) return false;
-    S = (int)sh[8]; w0 = sh[9];
-    const uint32_t c0 = sh[10], c1 = sh[11];
+    if (sh[R] == 0xFFFFFFFFu) return false;
+    S = (int)sh[R]; w0 = sh[R + 1];
+    const uint32_t c0 = sh[R + 2], c1 = sh[R + 3];
     e0 = c0 + (w - w0) * L2_SEG;
     e1 = min(c1, e0 + L2_SEG);
     return true;
@@ -381,8 +389,10 @@ __device__ bool find_work(const GsBin3Args &a, uint32_t *sh, int &S, uint32_t &e
 // 16 private copies (lane & 15) keep the lanes of one LDS atomic instruction off each other's cells (rectangles that
 // cover the whole super-tile all hit the same four corners).
 #define CNT_COPIES 16
-#define CNT_CELLS ((SB + 1) * (SB + 1))
+template <int SBS>
 __global__ __launch_bounds__(L2_THREADS) void l2_count_kernel(GsBin3Args a) {
+    constexpr int SB = 1 << SBS, CNT_CELLS = (SB + 1) * (SB + 1);
+    static_assert(SB * SB <= L2_THREADS, "one thread per local tile");
     __shared__ int diff[CNT_COPIES * CNT_CELLS];
     __shared__ uint32_t sh[12];
     int S; uint32_t e0, e1, w0;
@@ -394,22 +404,22 @@ __global__ __launch_bounds__(L2_THREADS) void l2_count_kernel(GsBin3Args a) {
     int *my = diff + (tid & (CNT_COPIES - 1)) * CNT_CELLS;
     for (uint32_t e = e0 + tid; e < e1; e += L2_THREADS) {
         const uint32_t lr = a.clr[e];
-        const int lx0 = lr & 7, lx1 = (lr >> 3) & 7, ly0 = (lr >> 6) & 7, ly1 = (lr >> 9) & 7;
+        const int lx0 = lr & (SB - 1), lx1 = (lr >> SBS) & (SB - 1), ly0 = (lr >> (2 * SBS)) & (SB - 1), ly1 = (lr >> (3 * SBS)) & (SB - 1);
         atomicAdd(&my[ly0 * (SB + 1) + lx0], 1);
         atomicAdd(&my[ly0 * (SB + 1) + lx1 + 1], -1);
         atomicAdd(&my[(ly1 + 1) * (SB + 1) + lx0], -1);
         atomicAdd(&my[(ly1 + 1) * (SB + 1) + lx1 + 1], 1);
     }
     __syncthreads();
-    if (tid < CNT_CELLS) {
+    for (int cell = tid; cell < CNT_CELLS; cell += L2_THREADS) {
         int s = 0;
 #pragma unroll
-        for (int c = 0; c < CNT_COPIES; ++c) s += diff[c * CNT_CELLS + tid];
-        diff[tid] = s;                                     // copy 0 now holds the sum (each cell is read and written by its own thread)
+        for (int c = 0; c < CNT_COPIES; ++c) s += diff[c * CNT_CELLS + cell];
+        diff[cell] = s;                                    // copy 0 now holds the sum (each cell is read and written by its own thread)
     }
     __syncthreads();
     if (tid < SB * SB) {
-        const int ty = tid >> SB_SHIFT, tx = tid & (SB - 1);
+        const int ty = tid >> SBS, tx = tid & (SB - 1);
         int s = 0;
         for (int y = 0; y <= ty; ++y)
             for (int x = 0; x <= tx; ++x) s += diff[y * (SB + 1) + x];
@@ -424,7 +434,9 @@ __global__ __launch_bounds__(L2_THREADS) void l2_count_kernel(GsBin3Args a) {
 // segments that is, tile_ext = {entries those segments give it = the written LENGTH of its list, coarse index of the first segment it
 // does NOT take or GS_CONT_NONE when it takes them all}, smax = the largest tile_nopen of the super-tile.  The lists themselves
 // (positions, order, ranges) are those of the uncapped path: only fewer of their entries are written.
+template <int SBS>
 __global__ __launch_bounds__(GS_WAVE) void l2_cap_kernel(GsBin3Args a) {
+    constexpr int SB = 1 << SBS;
     if (lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;
     const int S = blockIdx.x, lane = threadIdx.x;
     uint32_t w0 = 0;                                           // first work item of S: segments of the super-tiles before it
@@ -436,21 +448,24 @@ __global__ __launch_bounds__(GS_WAVE) void l2_cap_kernel(GsBin3Args a) {
     for (int d = GS_WAVE / 2; d > 0; d >>= 1) w0 += (uint32_t)__shfl_xor((int)w0, d);
     const uint2 cr = reinterpret_cast<const uint2 *>(a.cranges)[S];
     const uint32_t nseg = (cr.y - cr.x + (L2_SEG - 1)) / L2_SEG;
-    const int tx = (S % a.sgx) * SB + (lane & (SB - 1)), ty = (S / a.sgx) * SB + (lane >> SB_SHIFT);
-    const bool in = tx < a.gx && ty < a.gy;
-    const int t = ty * a.gx + tx;
-    const uint32_t cap = in ? gs_list_cap(a.cap_src[t]) : 0u;
-    uint32_t run = 0, k = 0;
-    for (; k < nseg && run < cap; ++k) run += a.segcnt[(size_t)(w0 + k) * (SB * SB) + lane];       // 256 coalesced bytes per segment
-    uint32_t m = in ? k : 0u;
+    uint32_t m = 0;
+    for (int lt = lane; lt < SB * SB; lt += GS_WAVE) {                  // local tiles: one per lane (8 x 8) or four (16 x 16)
+        const int tx = (S % a.sgx) * SB + (lt & (SB - 1)), ty = (S / a.sgx) * SB + (lt >> SBS);
+        const bool in = tx < a.gx && ty < a.gy;
+        const int t = ty * a.gx + tx;
+        const uint32_t cap = in ? gs_list_cap(a.cap_src[t]) : 0u;
+        uint32_t run = 0, k = 0;
+        for (; k < nseg && run < cap; ++k) run += a.segcnt[(size_t)(w0 + k) * (SB * SB) + lt];       // 256 coalesced bytes per segment and wave
+        m = max(m, in ? k : 0u);
+        if (in) {
+            a.tile_nopen[t] = k;
+            a.tile_ext[t] = make_uint2(run, k < nseg ? cr.x + k * L2_SEG : GS_CONT_NONE);
+        }
+    }
 #pragma unroll
     for (int d = GS_WAVE / 2; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
     if (lane == 0) a.smax[S] = m;
     if (S == 0 && lane == 0 && a.ext_count) *a.ext_count = 0u;
-    if (in) {
-        a.tile_nopen[t] = k;
-        a.tile_ext[t] = make_uint2(run, k < nseg ? cr.x + k * L2_SEG : GS_CONT_NONE);
-    }
 }
 
 // tile ranges = exclusive scan of the tile counts in tile order (one workgroup); completed tiles get an empty range
@@ -490,17 +505,16 @@ __global__ __launch_bounds__(1024) void l2_ranges_kernel(const uint32_t *__restr
     }
 }
 
-// One wave per tile ROW of the super-tile (8 waves, 8 tiles each).  A wave first compacts the segment's entries to those
+// One wave per tile ROW of the super-tile (SB waves, SB tiles each).  A wave first compacts the segment's entries to those
 // that touch its row (about half at C3) through a small LDS ring, and runs the per-tile ballots only on full batches of
-// 64 compacted entries: 64 x entries tests become ~ 8 x entries (row filter) + 8 x 0.47 x entries x 8 (tile tests).
-#define L2W_THREADS 512
+// 64 compacted entries: SB^2 x entries tests become ~ SB x entries (row filter) + SB x 0.47 x entries x SB (tile tests).
 #define RING 128
 // cur[k]: byte offset of tile k's cursor from `out` (WIDE: entry index, for lists beyond 4 GB)
-template <bool WIDE>
-__device__ __forceinline__ void emit_batch(uint32_t id, uint32_t m8, uint32_t (&cur)[SB], uint32_t *__restrict__ out) {
+template <bool WIDE, int SB>
+__device__ __forceinline__ void emit_batch(uint32_t id, uint32_t mrow, uint32_t (&cur)[SB], uint32_t *__restrict__ out) {
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
-        const bool hit = (m8 & (1u << k)) != 0u;
+        const bool hit = (mrow & (1u << k)) != 0u;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (WIDE) { if (hit) out[(size_t)cur[k] + rank] = id; cur[k] += (uint32_t)__popcll(bal); }
@@ -510,35 +524,36 @@ __device__ __forceinline__ void emit_batch(uint32_t id, uint32_t m8, uint32_t (&
         }
     }
 }
-template <bool WIDE>
-__global__ __launch_bounds__(L2W_THREADS) void l2_write_kernel(GsBin3Args a) {
+template <bool WIDE, int SBS>
+__global__ __launch_bounds__(GS_WAVE << SBS) void l2_write_kernel(GsBin3Args a) {
+    constexpr int SB = 1 << SBS, NT = GS_WAVE * SB;
     __shared__ uint32_t sid[L2_SEG];
-    __shared__ uint8_t scol[L2_SEG];                        // column bits of the entry inside the super-tile
-    __shared__ uint8_t srow[L2_SEG];                        // row bits
-    __shared__ uint32_t ring_id[L2W_THREADS / GS_WAVE][RING], ring_m[L2W_THREADS / GS_WAVE][RING];
-    __shared__ uint32_t sh[12];
-    __shared__ uint32_t sdead[2];
+    __shared__ uint16_t scol[L2_SEG];                       // column bits of the entry inside the super-tile
+    __shared__ uint16_t srow[L2_SEG];                       // row bits
+    __shared__ uint32_t ring_id[SB][RING], ring_m[SB][RING];
+    __shared__ uint32_t sh[NT / GS_WAVE + 4];               // (find_work: the waves' sums + the work item)
+    __shared__ uint32_t sdead[SB * SB / 32];
     int S; uint32_t e0, e1, w0;
     if (lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;
-    if (!find_work<L2W_THREADS>(a, sh, S, e0, e1, w0)) return;
+    if (!find_work<NT>(a, sh, S, e0, e1, w0)) return;
     const uint32_t kseg = blockIdx.x - w0;                  // this work item's segment of the super-tile's list
     if (a.tile_nopen && kseg >= a.smax[S]) return;          // capped lists: no tile of the super-tile takes entries this deep
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ox = (S % a.sgx) * SB, oy = (S / a.sgx) * SB;
     const int cnt = (int)(e1 - e0);
-    constexpr int ITEMS = L2_SEG / L2W_THREADS;
+    constexpr int ITEMS = L2_SEG / NT;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
-        const int i = tid + k * L2W_THREADS;
+        const int i = tid + k * NT;
         if (i < cnt) {
             const uint32_t lr = a.clr[e0 + i];
-            const int lx0 = lr & 7, lx1 = (lr >> 3) & 7, ly0 = (lr >> 6) & 7, ly1 = (lr >> 9) & 7;
+            const int lx0 = lr & (SB - 1), lx1 = (lr >> SBS) & (SB - 1), ly0 = (lr >> (2 * SBS)) & (SB - 1), ly1 = (lr >> (3 * SBS)) & (SB - 1);
             sid[i] = a.cids[e0 + i];
-            scol[i] = (uint8_t)((2u << lx1) - (1u << lx0));
-            srow[i] = (uint8_t)((2u << ly1) - (1u << ly0));
+            scol[i] = (uint16_t)((2u << lx1) - (1u << lx0));
+            srow[i] = (uint16_t)((2u << ly1) - (1u << ly0));
         }
     }
-    // cursors of the wave's eight tiles (row wv of the super-tile): range start + the hits of the earlier segments
+    // cursors of the wave's tiles (row wv of the super-tile): range start + the hits of the earlier segments
     uint32_t base = 0;
     if (lane < SB) {
         const int t = SB * wv + lane;
@@ -549,37 +564,39 @@ __global__ __launch_bounds__(L2W_THREADS) void l2_write_kernel(GsBin3Args a) {
             for (uint32_t w = w0; w < blockIdx.x; ++w) base += a.segcnt[(size_t)w * (SB * SB) + t];
         }
     }
-    if (wv == 0) {                                         // tiles outside the grid or completed in an earlier round take nothing
-        const int tx = ox + (lane & (SB - 1)), ty = oy + (lane >> SB_SHIFT);
+    if (wv < SB * SB / GS_WAVE) {                          // tiles outside the grid or completed in an earlier round take nothing
+        const int lt = wv * GS_WAVE + lane;                // local tile
+        const int tx = ox + (lt & (SB - 1)), ty = oy + (lt >> SBS);
         const bool dead = tx >= a.gx || ty >= a.gy || (a.done && a.done[ty * a.gx + tx]) ||
                           (a.tile_nopen && kseg >= a.tile_nopen[ty * a.gx + tx]);       // (|| short-circuits: tiles outside the grid are not looked up)
         const unsigned long long b = __ballot(dead);
-        if (lane == 0) { sdead[0] = (uint32_t)b; sdead[1] = (uint32_t)(b >> 32); }
+        if (lane == 0) { sdead[2 * wv] = (uint32_t)b; sdead[2 * wv + 1] = (uint32_t)(b >> 32); }
     }
     uint32_t cur[SB];
 #pragma unroll
     for (int k = 0; k < SB; ++k) cur[k] = __builtin_amdgcn_readlane(WIDE ? base : base << 2, k);
     __syncthreads();
-    const uint32_t live8 = ~((wv < 4 ? sdead[0] : sdead[1]) >> ((wv & 3) * SB)) & 0xFFu;     // live tiles of this wave's row
+    // live tiles of this wave's row: bits wv * SB .. wv * SB + SB - 1 of the dead mask
+    const uint32_t liverow = ~(sdead[(wv * SB) >> 5] >> ((wv * SB) & 31)) & ((1u << SB) - 1u);
     uint32_t *__restrict__ out = a.ids_out;
     uint32_t *rid = ring_id[wv], *rm = ring_m[wv];
     uint32_t fill = 0;
-    if (live8)
+    if (liverow)
     for (int b = 0; b < cnt; b += GS_WAVE) {
         const int i = b + lane;
-        uint32_t m8 = 0, id = 0;
-        if (i < cnt && ((srow[i] >> wv) & 1u)) { m8 = scol[i] & live8; id = sid[i]; }
-        const bool touch = m8 != 0u;
+        uint32_t mrow = 0, id = 0;
+        if (i < cnt && ((srow[i] >> wv) & 1u)) { mrow = scol[i] & liverow; id = sid[i]; }
+        const bool touch = mrow != 0u;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(touch);
         if (bal == 0ull) continue;
         const uint32_t pos = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (touch) { rid[pos] = id; rm[pos] = m8; }
+        if (touch) { rid[pos] = id; rm[pos] = mrow; }
         fill += (uint32_t)__popcll(bal);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (fill >= GS_WAVE) {                              // uniform
             const uint32_t bid = rid[lane], bm = rm[lane];
             const uint32_t tid2 = rid[GS_WAVE + lane], tm2 = rm[GS_WAVE + lane];
-            emit_batch<WIDE>(bid, bm, cur, out);
+            emit_batch<WIDE, SB>(bid, bm, cur, out);
             fill -= GS_WAVE;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if ((uint32_t)lane < fill) { rid[lane] = tid2; rm[lane] = tm2; }
@@ -589,22 +606,28 @@ __global__ __launch_bounds__(L2W_THREADS) void l2_write_kernel(GsBin3Args a) {
     if (fill) {
         uint32_t bid = 0, bm = 0;
         if ((uint32_t)lane < fill) { bid = rid[lane]; bm = rm[lane]; }
-        emit_batch<WIDE>(bid, bm, cur, out);
+        emit_batch<WIDE, SB>(bid, bm, cur, out);
     }
 }
 
 // sdone[S] = 1 when every tile of super-tile S that lies inside the grid completed in an earlier round
+template <int SBS>
 __global__ __launch_bounds__(L2_THREADS) void super_done_kernel(const uint8_t *__restrict__ done, int gx, int gy, int sgx, int ns, uint8_t *__restrict__ sdone) {
+    constexpr int SB = 1 << SBS;
     const int lane = threadIdx.x & 63, S = blockIdx.x * (L2_THREADS / GS_WAVE) + (threadIdx.x >> 6);
     if (S >= ns) return;
-    const int tx = (S % sgx) * SB + (lane & (SB - 1)), ty = (S / sgx) * SB + (lane >> SB_SHIFT);
-    const bool dead = tx >= gx || ty >= gy || done[ty * gx + tx];
-    const unsigned long long b = __ballot(dead);
+    bool all = true;
+    for (int lt = lane; lt < SB * SB; lt += GS_WAVE) {
+        const int tx = (S % sgx) * SB + (lt & (SB - 1)), ty = (S / sgx) * SB + (lt >> SBS);
+        all = all && (tx >= gx || ty >= gy || done[ty * gx + tx]);
+    }
+    const unsigned long long b = __ballot(all);
     if (lane == 0) sdone[S] = b == ~0ull ? 1 : 0;
 }
-hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, uint8_t *sdone, hipStream_t s) {
+hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, int sbs, uint8_t *sdone, hipStream_t s) {
     const int ns = sgx * sgy, per = L2_THREADS / GS_WAVE;
-    hipLaunchKernelGGL(super_done_kernel, dim3((ns + per - 1) / per), dim3(L2_THREADS), 0, s, done, gx, gy, sgx, ns, sdone);
+    if (sbs == 4) hipLaunchKernelGGL(super_done_kernel<4>, dim3((ns + per - 1) / per), dim3(L2_THREADS), 0, s, done, gx, gy, sgx, ns, sdone);
+    else hipLaunchKernelGGL(super_done_kernel<3>, dim3((ns + per - 1) / per), dim3(L2_THREADS), 0, s, done, gx, gy, sgx, ns, sdone);
     return hipGetLastError();
 }
 
@@ -612,6 +635,7 @@ hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, in
 static L1Args l1_args(const GsBin3L1 &b) {
     L1Args a{};
     a.rect = b.rect; a.perm = b.perm; a.sdone = b.sdone; a.n = b.n; a.n_slab = b.n_slab; a.sgx = b.sgx; a.ns = b.ns;
+    a.sbs = b.sbs == 4 ? 4 : 3;
     a.G = gs_bin3_group(b.ns);
     a.nwg = (int)((b.n_slab + a.G - 1) / a.G); a.nwg_all = (int)((b.n + a.G - 1) / a.G);
     a.rect_sorted = reinterpret_cast<uint2 *>(b.rect_sorted); a.table = b.table; a.row_total = b.row_total;
@@ -655,14 +679,23 @@ hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s) {
     if (a.max_work <= 0) return hipSuccess;
     GsBin3Args b = a;
     if (!b.cap_src || !b.tile_nopen || !b.smax || !b.tile_ext || b.done) { b.cap_src = nullptr; b.tile_nopen = nullptr; b.smax = nullptr; b.tile_ext = nullptr; }
-    hipLaunchKernelGGL(l2_count_kernel, dim3(b.max_work), dim3(L2_THREADS), 0, s, b);
-    if (b.cap_src) hipLaunchKernelGGL(l2_cap_kernel, dim3(b.ns), dim3(GS_WAVE), 0, s, b);
+    if (b.sbs == 4) hipLaunchKernelGGL(l2_count_kernel<4>, dim3(b.max_work), dim3(L2_THREADS), 0, s, b);
+    else hipLaunchKernelGGL(l2_count_kernel<3>, dim3(b.max_work), dim3(L2_THREADS), 0, s, b);
+    if (b.cap_src) {
+        if (b.sbs == 4) hipLaunchKernelGGL(l2_cap_kernel<4>, dim3(b.ns), dim3(GS_WAVE), 0, s, b);
+        else hipLaunchKernelGGL(l2_cap_kernel<3>, dim3(b.ns), dim3(GS_WAVE), 0, s, b);
+    }
     hipLaunchKernelGGL(l2_ranges_kernel, dim3(1), dim3(1024), 0, s, b.tilecnt, b.gx * b.gy, b.done, b.ranges, b.totals, b.cap_coarse, b.cap_fine, b.tile_ext);
     return gs_bin3_write_lists(b, s);
 }
 hipError_t gs_bin3_write_lists(const GsBin3Args &a, hipStream_t s) {
     if (a.max_work <= 0) return hipSuccess;
-    if (a.wide) hipLaunchKernelGGL(l2_write_kernel<true>, dim3(a.max_work), dim3(L2W_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(l2_write_kernel<false>, dim3(a.max_work), dim3(L2W_THREADS), 0, s, a);
+    if (a.sbs == 4) {
+        if (a.wide) hipLaunchKernelGGL((l2_write_kernel<true, 4>), dim3(a.max_work), dim3(GS_WAVE << 4), 0, s, a);
+        else hipLaunchKernelGGL((l2_write_kernel<false, 4>), dim3(a.max_work), dim3(GS_WAVE << 4), 0, s, a);
+    } else {
+        if (a.wide) hipLaunchKernelGGL((l2_write_kernel<true, 3>), dim3(a.max_work), dim3(GS_WAVE << 3), 0, s, a);
+        else hipLaunchKernelGGL((l2_write_kernel<false, 3>), dim3(a.max_work), dim3(GS_WAVE << 3), 0, s, a);
+    }
     return hipGetLastError();
 }

@@ -171,6 +171,7 @@ struct GsBin3L1 {
     const uint8_t *sdone;      // per super-tile: completed in an earlier round (null: none)
     int64_t n, n_slab;         // positions whose instances are summed (totals[2]) / positions listed by this round
     int sgx, ns;
+    int sbs;                   // log2 of the super-tile edge in tiles: 3 (8 x 8 tiles) or 4 (16 x 16: grids whose 8 x 8 super-tiles are too many)
     uint32_t *rect_sorted;     // 2 x n_slab words: rectangles in list order
     uint32_t *table;           // gs_bin3_table_words(n_slab, ns)
     uint32_t *row_total;       // ns
@@ -193,13 +194,14 @@ struct GsBin3L1 {
 struct GsBin3Args {
     const uint32_t *cranges;   // 2 x ns: [start, end) of every super-tile's list inside cids
     const uint32_t *cids;      // gaussian ids in (super-tile, list order)
-    const uint16_t *clr;       // the entries' rectangles clipped to their super-tile (lx0 | lx1 << 3 | ly0 << 6 | ly1 << 9)
+    const uint16_t *clr;       // the entries' rectangles clipped to their super-tile (lx0 | lx1 << sbs | ly0 << 2 sbs | ly1 << 3 sbs)
     uint32_t *ranges;          // 2 x tiles: the tile ranges of this round (written here: exclusive scan of the tile counts)
     uint32_t *tilecnt;         // tiles: hits per tile, zero on entry
     const uint8_t *done;       // per tile: completed in an earlier round, takes no entries (null: none)
-    uint32_t *segcnt;          // [max_work][64] hits per (segment, local tile)
+    uint32_t *segcnt;          // [max_work][4^sbs] hits per (segment, local tile)
     uint32_t *ids_out;         // gaussian ids in (tile, list order)
     int gx, gy, sgx, ns;
+    int sbs;                   // log2 of the super-tile edge in tiles (3 or 4)
     int max_work;              // upper bound of the number of (super-tile, segment) work items
     int wide;                  // the lists reach beyond 4 GB from ids_out: 64-bit store addresses
     const uint32_t *totals;    // the round's totals (GsBin3L1.totals) and the capacities they are checked against
@@ -219,7 +221,7 @@ struct GsBin3Args {
 // entries kept for a tile whose slot history walked w: a quarter more, and never less than two batches
 __host__ __device__ inline uint32_t gs_list_cap(uint32_t w) { const uint32_t c = w + (w >> 2) + 128u; return c < w ? 0xFFFFFFFFu : c; }
 int gs_bin3_seg();             // L2_SEG: coarse entries per level-2 work item
-int gs_bin3_sb_shift();
+int gs_bin3_sb_shift(int gx, int gy, int force);       // 3 or 4 (force: 3 / 4 = that edge whatever the grid, tests; else by the grid)
 bool gs_bin3_supported(int ns);
 int64_t gs_bin3_max_work(int64_t coarse_instances, int ns);
 size_t gs_bin3_table_words(int64_t n_slab, int ns);
@@ -228,9 +230,9 @@ hipError_t gs_bin3_l1_count(const GsBin3L1 &b, hipStream_t s);
 hipError_t gs_bin3_l1_scatter(const GsBin3L1 &b, hipStream_t s);
 hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s);
 hipError_t gs_bin3_write_lists(const GsBin3Args &a, hipStream_t s);      // the write pass alone (counts and ranges of the frame still valid)
-hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, uint8_t *sdone, hipStream_t s);
+hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, int sbs, uint8_t *sdone, hipStream_t s);
 
-#define GS_TILE_CLOCK_WORDS 14
+#define GS_TILE_CLOCK_WORDS 15
 #define GS_MAX_ROUNDS 4   // binning rounds (depth slabs) of one frame
 #define GS_G2D_STRIDE 16   // floats (or fixed-point words) per gaussian row of the composite backward's sums: ten used, padded to ONE
                            // 64-byte sector so that the 9-lane atomic of a (tile, splat) entry is a single memory-side request
@@ -279,7 +281,7 @@ struct GsCompositeArgs {
     const uint32_t *cranges, *cids;
     const uint16_t *clr;
     uint32_t *ids_w;           // == ids, writable
-    int sgx;
+    int sgx, sbs;              // super-tile grid width, log2 of the super-tile edge in tiles
     uint32_t *ext_count;       // segments appended by the forward's waves (one atomic per extension: the rare path), may be null
 };
 // the written entries of capped lists, summed over the tiles: out[0] = sum ext[t].x

@@ -46,6 +46,12 @@
 #ifndef GS_FWD_MINW
 #define GS_FWD_MINW 5               // __launch_bounds__ waves/SIMD of the forward (89 VGPRs)
 #endif
+#ifndef GS_LIVE_RECT
+#define GS_LIVE_RECT 1              // no-op test against the rectangle of the pixels still taking entries (0: against the whole tile; A/B builds)
+#endif
+#ifndef GS_FWD_PACK
+#define GS_FWD_PACK 1               // forward: pack the live pixels into one or two slots once they fit (0: A/B builds)
+#endif
 #ifndef GS_FWD_UNROLL
 #define GS_FWD_UNROLL 2             // entries interleaved in the forward's per-entry loop
 #endif
@@ -117,8 +123,11 @@ __device__ __forceinline__ bool rect_can_contribute(float A, float B, float C, f
 // lanes hold in slot p) can reach alpha >= 2^-27 somewhere.  The backward skips the dead strips of an entry with wave-uniform
 // branches: at C3 24 % of the strips of the evaluated entries are dead.  `keep` is the same tile-level test in both kernels, so
 // forward and backward evaluate the same entries.
+// (qx0 .. qx1) x (qy0 .. qy1): the pixels the entry is tested against -- the tile, or a rectangle inside it that holds every pixel
+// still taking entries
 template <bool STRIPS>
-__device__ __forceinline__ void stage_record(const float4 &n0, const float4 &n1, const float4 &n3, const int tx0, const int ty0, bool &keep, uint32_t &strips) {
+__device__ __forceinline__ void stage_record(const float4 &n0, const float4 &n1, const float4 &n3, const int qx0, const int qx1, const int qy0, const int qy1,
+                                             const int ty0, bool &keep, uint32_t &strips) {
     // payload quads (gs_common.h): n0 = {mu_x, mu_y, log2 sig (capped below 0), x_lo}, n1 = {k i0, k (i1+i2), k i3, x_hi}, n2 = {r, g, b, y_lo},
     // n3 = {y_hi, sig, box x, box y}: n0..n2 and n3.x go to LDS as they are; this is only the no-op test.
     // log2(sig) arrives capped three ulps below 0 (gs_preprocess.hip), so alpha = exp2(pw + l2s) < 1 strictly (pw <= 0: the conic
@@ -130,8 +139,8 @@ __device__ __forceinline__ void stage_record(const float4 &n0, const float4 &n1,
     const float l2s = n0.z;
     const float A = n1.x, B = n1.y, C = n1.z;
     const bool concave = A < 0.0f && C < 0.0f && 4.0f * A * C - B * B > 0.0f;
-    const float rx0 = (float)max(tx0, xmin) - n0.x, rx1 = (float)min(tx0 + GS_TILE - 1, xmax) - n0.x;
-    const float ry0 = (float)max(ty0, ymin) - n0.y, ry1 = (float)min(ty0 + GS_TILE - 1, ymax) - n0.y;
+    const float rx0 = (float)max(qx0, xmin) - n0.x, rx1 = (float)min(qx1, xmax) - n0.x;
+    const float ry0 = (float)max(qy0, ymin) - n0.y, ry1 = (float)min(qy1, ymax) - n0.y;
     const float hBrA = 0.5f * B * fast_rcp(A), hBrC = 0.5f * B * fast_rcp(C);
     keep = !empty && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, ry0, ry1);
     strips = 0xFu;
@@ -139,7 +148,7 @@ __device__ __forceinline__ void stage_record(const float4 &n0, const float4 &n1,
         strips = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const float sy0 = (float)max(ty0 + 4 * p, ymin) - n0.y, sy1 = (float)min(ty0 + 4 * p + 3, ymax) - n0.y;
+            const float sy0 = (float)max(max(ty0 + 4 * p, qy0), ymin) - n0.y, sy1 = (float)min(min(ty0 + 4 * p + 3, qy1), ymax) - n0.y;
             if (keep && rect_can_contribute(A, B, C, hBrA, hBrC, concave, l2s, rx0, rx1, sy0, sy1)) strips |= 1u << p;
         }
     }
@@ -152,6 +161,17 @@ __device__ __forceinline__ void stage_record(const float4 &n0, const float4 &n1,
 __device__ __forceinline__ void first_use_here(float4 &a, float4 &b, float4 &c, float4 &d) {
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w),
                       "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w), "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // kept-entry slot of this lane inside the wave's keep mask
@@ -177,8 +197,10 @@ __device__ __forceinline__ Entry load_entry(const float4 *sp, const float *syhi,
 __device__ __forceinline__ uint32_t extend_tile_list(const GsCompositeArgs &a, const int tile, uint32_t &cont, uint32_t s1) {
     const int lane = threadIdx.x;
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int S = (ty >> 3) * a.sgx + (tx >> 3);
-    const uint32_t lx = (uint32_t)(tx & 7), ly = (uint32_t)(ty & 7);
+    const int sbs = a.sbs;
+    const uint32_t sm = (1u << sbs) - 1u;
+    const int S = (ty >> sbs) * a.sgx + (tx >> sbs);
+    const uint32_t lx = (uint32_t)tx & sm, ly = (uint32_t)ty & sm;
     const uint32_t c1 = a.cranges[2 * S + 1];
     const uint32_t seg = (uint32_t)gs_bin3_seg_const();
     const uint32_t e_end = min(cont + seg, c1);
@@ -188,7 +210,7 @@ __device__ __forceinline__ uint32_t extend_tile_list(const GsCompositeArgs &a, c
         uint32_t id = 0;
         if (e < e_end) {
             const uint32_t lr = a.clr[e];
-            hit = (lr & 7u) <= lx && lx <= ((lr >> 3) & 7u) && ((lr >> 6) & 7u) <= ly && ly <= ((lr >> 9) & 7u);
+            hit = (lr & sm) <= lx && lx <= ((lr >> sbs) & sm) && ((lr >> (2 * sbs)) & sm) <= ly && ly <= ((lr >> (3 * sbs)) & sm);
             id = a.cids[e];
         }
         const uint64_t bal = __ballot(hit);
@@ -208,6 +230,15 @@ template <bool EARLY, bool CULL, bool CLK, bool SLAB>
 // CLK: per-tile debug clocks (gs_debug_tile_clock); a separate instantiation so that the production kernel carries none of it.
 // (Skipping the dead 16 x 4 strips of an entry with wave-uniform branches, as the backward does, was measured on the forward
 // too: 0.352 vs 0.357 ms at C3 -- its per-strip work is a 12-instruction dependent chain, the branches cost what they save.)
+//
+// PACKING THE LIVE PIXELS (round 4; single-round frames with the early-out).  A frozen pixel takes no further entry, but its lane
+// slot is executed as long as the tile walks: measured at C3 (profiles/r04c_tile_tail_C3.json), 21 % of the evaluated entries are
+// composited while 64 or fewer of the tile's 256 pixels are live, another 11 % with 128 or fewer.  At a batch boundary where the live
+// pixels fit two slots (or one) the wave writes the frozen pixels' final colour and transmittance to memory, moves the live ones --
+// {x, y, C, T}, through the staging buffer in LDS, in slot-then-lane order -- into slots 0 .. K-1 and runs the rest of the list with
+// K = 2 or 1 slots per entry instead of 4.  A packed slot carries its own x (the shared per-lane column is gone), so a slot costs
+// 18 VALU instructions instead of 12 + 6 shared: K = 2 is 36 against 54, K = 1 is 18.  Every pixel sees the same entries in the same
+// order with the same arithmetic, so the image and the transmittance are bit-identical to the unpacked walk.
 __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
@@ -218,7 +249,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     uint32_t cont = GS_CONT_NONE;                                  // capped lists: where the unwritten rest of the list starts in the coarse list
     const bool capped = !SLAB && EARLY && a.tile_ext != nullptr;
     if (capped) { const uint2 ex = a.tile_ext[tile]; s1 = s0 + ex.x; cont = ex.y; }
-    const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);     // first pixel of the tile (1-based)
+    const int ty0 = py0 - (lane >> 4);                             // first pixel row of the tile (1-based)
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
 
@@ -231,25 +262,45 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     if (SLAB && a.resume && a.tile_done[tile]) return;
     const uint32_t gp0 = SLAB && a.tile_pos ? a.tile_pos[tile] : 0u;
     const size_t plane = (size_t)a.W * a.H;
-    float Cr[4], Cg[4], Cb[4], T[4], Tdead[4], fy[4];
+    // (a frozen pixel's transmittance is final: it goes to memory when the pixel freezes, not at the end of the tile)
+    float Cr[4], Cg[4], Cb[4], T[4], fy[4];
     bool dead[4];
     uint32_t walked = 0, evaluated = 0;
+    constexpr bool PACK = GS_FWD_PACK && EARLY && !SLAB;
+    int K = 4;                                                          // slots per entry: 4 = the tile's pixels in place; 2 / 1 = live pixels packed
+    // packed: slots 2 and 3 hold no pixel, and fy[2], fy[3] hold the x of the pixels in slots 0 and 1 (0 = the slot is empty)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         Cr[p] = Cg[p] = Cb[p] = 0.0f;
         fy[p] = (float)(py0 + 4 * p);
         const bool in = (px <= a.W && py0 + 4 * p <= a.H);
         T[p] = in ? 1.0f : 0.0f;
-        Tdead[p] = 0.0f; dead[p] = !in;
+        dead[p] = !in;
         if (SLAB && a.resume && in) {
             const size_t o = (size_t)(px - 1) + (size_t)a.W * (py0 + 4 * p - 1);
             Cr[p] = a.image[o]; Cg[p] = a.image[o + plane]; Cb[p] = a.image[o + 2 * plane];
-            const float t = a.trans[o];
             dead[p] = ((a.tile_dead[4 * (size_t)tile + p] >> lane) & 1ull) != 0ull;
-            Tdead[p] = dead[p] ? t : 0.0f;
-            T[p] = dead[p] ? 0.0f : t;
+            T[p] = dead[p] ? 0.0f : a.trans[o];                           // (a frozen pixel's transmittance stays where the round that froze it put it)
         }
     }
+    // The no-op test of an entry (stage_record) runs against the rectangle that holds every pixel STILL TAKING ENTRIES, not against the
+    // whole tile: an entry that can only reach frozen pixels (or pixels outside a ragged image edge) is as much a no-op as one that
+    // reaches none.  Refreshed at the batch boundaries where pixels froze; forward and backward freeze the same pixels at the same
+    // boundaries, so both evaluate the same entries (C3: 6.8 % fewer than with the tile's rectangle, profiles/r04e_tile_tail_C3.json).
+    int qx0, qx1, qy0, qy1;
+    auto live_rect = [&]() {
+        int lx0 = 1 << 20, lx1 = -1, ly0 = 1 << 20, ly1 = -1;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!dead[p]) {
+                const int x = (!PACK || K == 4) ? px : (int)fy[2 + (p & 1)], y = (int)fy[p];
+                lx0 = min(lx0, x); lx1 = max(lx1, x); ly0 = min(ly0, y); ly1 = max(ly1, y);
+            }
+        }
+        qx0 = wave_min_i32(lx0); qx1 = wave_max_i32(lx1); qy0 = wave_min_i32(ly0); qy1 = wave_max_i32(ly1);
+        if (!GS_LIVE_RECT) { qx0 = px - (lane & 15); qx1 = qx0 + GS_TILE - 1; qy0 = ty0; qy1 = ty0 + GS_TILE - 1; }
+    };
+    live_rect();
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     uint32_t pos = s0 + lane;
@@ -270,6 +321,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     // live pixel / 4)); pixels moved inside their COLUMN (K = ceil(fullest column / 4))
     uint32_t clk_hist[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     int clk_k[3] = {4, 4, 4};
+    uint32_t clk_bbkeep = 0;                                            // ... and the entries the no-op test would keep against the whole tile
     if (CLK) t_mark = __builtin_amdgcn_s_memtime();
     for (;;) {                                                          // (capped lists: once more per segment the wave appends itself)
     bool stopped = false;
@@ -282,13 +334,63 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         const uint32_t phase = gp & (CB - 1);
         const int cnt = (int)min((uint32_t)CB - phase, s1 - base);      // batches end at multiples of CB of the WHOLE list
         if (EARLY && phase == 0) {
-            bool live = false;
+            bool live = false, froze = false;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                if (!dead[p] && T[p] < a.t_min) { dead[p] = true; Tdead[p] = T[p]; T[p] = 0.0f; }
+                if (!dead[p] && T[p] < a.t_min) {                        // frozen from here on: its transmittance is final
+                    const float x = (!PACK || K == 4) ? fx : fy[2 + (p & 1)];
+                    if (a.trans) a.trans[(size_t)((int)x - 1) + (size_t)a.W * ((int)fy[p] - 1)] = T[p];
+                    dead[p] = true; T[p] = 0.0f; froze = true;
+                }
                 live = live || !dead[p];
             }
             if (__ballot(live) == 0ull) { stopped = true; break; }
+            if (__ballot(froze) != 0ull) live_rect();
+            if (PACK && K > 1) {
+                uint64_t lm[4];
+                uint32_t nlive = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { lm[p] = __ballot(!dead[p]); nlive += (uint32_t)__popcll(lm[p]); }
+                const int Kn = (int)((nlive + 63u) >> 6);
+                if (Kn <= 2 && Kn < K) {
+                    // (1) the pixels that are dropped are final: their colour goes to memory now (their transmittance went when they froze)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float x = K == 4 ? fx : fy[2 + (p & 1)];
+                        const bool mine = K == 4 ? (px <= a.W && py0 + 4 * p <= a.H) : (p < 2 && x > 0.5f);
+                        if (mine && dead[p] && a.image) {
+                            const size_t o = (size_t)((int)x - 1) + (size_t)a.W * ((int)fy[p] - 1);
+                            a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p];
+                        }
+                    }
+                    // (2) live pixels -> ranks in slot-then-lane order -> six planes of 128 floats in the staging buffer -> slots 0 .. Kn-1
+                    float *buf = reinterpret_cast<float *>(sp);
+                    __syncthreads();
+                    uint32_t rb = 0;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        if (!dead[p]) {
+                            const uint32_t r = rb + (uint32_t)slot_of(lm[p]);
+                            buf[r] = K == 4 ? fx : fy[2 + (p & 1)]; buf[128 + r] = fy[p];
+                            buf[256 + r] = Cr[p]; buf[384 + r] = Cg[p]; buf[512 + r] = Cb[p]; buf[640 + r] = T[p];
+                        }
+                        rb += (uint32_t)__popcll(lm[p]);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t idx = (uint32_t)(q * 64 + lane);
+                        const bool has = idx < nlive;
+                        fy[2 + q] = has ? buf[idx] : 0.0f;
+                        fy[q] = has ? buf[128 + idx] : 0.0f;
+                        Cr[q] = has ? buf[256 + idx] : 0.0f; Cg[q] = has ? buf[384 + idx] : 0.0f; Cb[q] = has ? buf[512 + idx] : 0.0f;
+                        T[q] = has ? buf[640 + idx] : 0.0f;
+                        dead[q] = !has; dead[2 + q] = true;
+                        T[2 + q] = 0.0f;
+                    }
+                    K = Kn;
+                }
+            }
         }
         if (CLK && (phase == 0 || base == s0)) {                         // debug: live pixels / strips with a live pixel in this batch
             clk_live = 0; clk_strips = 0;
@@ -306,13 +408,18 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         }
         uint32_t strips;
         bool keep;
-        stage_record<false>(n0, n1, n3, tx0, ty0, keep, strips);
+        stage_record<false>(n0, n1, n3, qx0, qx1, qy0, qy1, ty0, keep, strips);
         int slot = lane, nk = cnt;
         if (!CULL) keep = true;
         if (CULL) {                                                     // compact the batch to the entries that can matter
             keep = keep && lane < cnt;
             const uint64_t m = __ballot(keep);
             slot = slot_of(m); nk = __popcll(m);
+        }
+        if (CLK && CULL) {                                              // debug: what the tile's own rectangle would have kept
+            bool k2; uint32_t st2;
+            stage_record<false>(n0, n1, n3, px - (lane & 15), px - (lane & 15) + GS_TILE - 1, ty0, ty0 + GS_TILE - 1, ty0, k2, st2);
+            clk_bbkeep += (uint32_t)__popcll(__ballot(k2 && lane < cnt));
         }
         __syncthreads();                                                // one wave: orders LDS reads/writes only
         if (keep) {
@@ -328,30 +435,53 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             if (base < s1 && pos2 < s1) id2 = a.ids[pos2];
         }
         if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
+// one pixel slot p of one entry (A0, B0: the column terms of the slot's x)
+#define GS_FWD_PIXEL(e, A0, B0, p) do {                                               \
+            const float dY = fy[p] - (e).q0.y;                                              \
+            const float ey = dY - __builtin_amdgcn_fmed3f(dY, (e).q2.w, (e).yhi);           \
+            const float pw = fmaf(dY, fmaf((e).q1.z, dY, (B0)), (A0));                      \
+            const float w = fast_exp2(fmaf(nbig, fabsf(ey), pw)) * T[p];                    \
+            Cr[p] = fmaf((e).q2.x, w, Cr[p]);                                               \
+            Cg[p] = fmaf((e).q2.y, w, Cg[p]);                                               \
+            Cb[p] = fmaf((e).q2.z, w, Cb[p]);                                               \
+            T[p] = T[p] - w;                                                                \
+        } while (0)
+// the column terms of an entry for a pixel column x
+#define GS_FWD_COLUMN(e, XCOL, A0, B0)                                                        \
+            const float dX##A0 = (XCOL) - (e).q0.x;                                           \
+            const float ex##A0 = dX##A0 - __builtin_amdgcn_fmed3f(dX##A0, (e).q0.w, (e).q1.w);   /* 0 inside the box columns */ \
+            const float A0 = fmaf(nbig, fabsf(ex##A0), fmaf((e).q1.x * dX##A0, dX##A0, (e).q0.z)); /* k i0 dX^2 + log2 sig - penalty */ \
+            const float B0 = (e).q1.y * dX##A0
+        if (!PACK || K == 4) {
 #pragma clang loop unroll_count(kFwdUnroll)
-        for (int k = 0; k < nk; ++k) {
-            const Entry e = load_entry(sp, syhi, k);
-            const float dX = fx - e.q0.x;
-            const float ex = dX - __builtin_amdgcn_fmed3f(dX, e.q0.w, e.q1.w);            // 0 inside the box columns
-            const float A0 = fmaf(nbig, fabsf(ex), fmaf(e.q1.x * dX, dX, e.q0.z));  // k i0 dX^2 + log2 sig - penalty
-            const float B0 = e.q1.y * dX;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float dY = fy[p] - e.q0.y;
-                const float ey = dY - __builtin_amdgcn_fmed3f(dY, e.q2.w, e.yhi);
-                const float pw = fmaf(dY, fmaf(e.q1.z, dY, B0), A0);
-                const float w = fast_exp2(fmaf(nbig, fabsf(ey), pw)) * T[p];
-                Cr[p] = fmaf(e.q2.x, w, Cr[p]);
-                Cg[p] = fmaf(e.q2.y, w, Cg[p]);
-                Cb[p] = fmaf(e.q2.z, w, Cb[p]);
-                T[p] = T[p] - w;
+            for (int k = 0; k < nk; ++k) {
+                const Entry e = load_entry(sp, syhi, k);
+                GS_FWD_COLUMN(e, fx, A0, B0);
+                GS_FWD_PIXEL(e, A0, B0, 0); GS_FWD_PIXEL(e, A0, B0, 1); GS_FWD_PIXEL(e, A0, B0, 2); GS_FWD_PIXEL(e, A0, B0, 3);
+            }
+        } else if (K == 2) {                                            // packed: every slot has its own column
+#pragma clang loop unroll_count(kFwdUnroll)
+            for (int k = 0; k < nk; ++k) {
+                const Entry e = load_entry(sp, syhi, k);
+                GS_FWD_COLUMN(e, fy[2], A0, B0);
+                GS_FWD_COLUMN(e, fy[3], A1, B1);
+                GS_FWD_PIXEL(e, A0, B0, 0); GS_FWD_PIXEL(e, A1, B1, 1);
+            }
+        } else {
+#pragma clang loop unroll_count(4)
+            for (int k = 0; k < nk; ++k) {
+                const Entry e = load_entry(sp, syhi, k);
+                GS_FWD_COLUMN(e, fy[2], A0, B0);
+                GS_FWD_PIXEL(e, A0, B0, 0);
             }
         }
+#undef GS_FWD_PIXEL
+#undef GS_FWD_COLUMN
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
         first_use_here(n0, n1, n2, n3);
         if (CLK) {
             const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t;
-            clk_exec += 4ull * (uint32_t)nk; clk_ideal += (unsigned long long)nk * ((clk_live + 63u) >> 6);
+            clk_exec += (unsigned long long)K * (uint32_t)nk; clk_ideal += (unsigned long long)nk * ((clk_live + 63u) >> 6);
             clk_alive += (unsigned long long)nk * clk_strips; clk_pix += (unsigned long long)nk * clk_live;
             for (int w = 0; w < 3; ++w) if (clk_k[w] >= 1 && clk_k[w] <= 4) clk_hist[w][clk_k[w] - 1] += (uint32_t)nk;
         }
@@ -381,14 +511,23 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         if (SLAB && a.tile_done) a.tile_done[tile] = all_dead ? 1 : 0;
         if (SLAB && a.tile_pos) a.tile_pos[tile] = gp0 + (s1 - s0);
     }
-    if (px <= a.W) {
+    if (PACK && K < 4) {                                                // packed: the pixels still held, wherever they belong
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (fy[2 + q] > 0.5f) {
+                const size_t o = (size_t)((int)fy[2 + q] - 1) + (size_t)a.W * ((int)fy[q] - 1);
+                if (a.image) { a.image[o] = Cr[q]; a.image[o + plane] = Cg[q]; a.image[o + 2 * plane] = Cb[q]; }
+                if (a.trans && !dead[q]) a.trans[o] = T[q];
+            }
+        }
+    } else if (px <= a.W) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int py = py0 + 4 * p;
             if (py <= a.H) {
                 const size_t o = (size_t)(px - 1) + (size_t)a.W * (py - 1);
                 if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p]; }
-                if (a.trans) a.trans[o] = (EARLY && dead[p]) ? Tdead[p] : T[p];
+                if (a.trans && !(EARLY && dead[p])) a.trans[o] = T[p];
             }
         }
     }
@@ -398,6 +537,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         c[3] = ((unsigned long long)walked << 32) | evaluated;
         c[4] = t_loop; c[5] = t_stage;
         c[6] = (clk_exec << 32) | (clk_ideal & 0xFFFFFFFFull); c[7] = (clk_alive << 32) | (clk_pix & 0xFFFFFFFFull);
+        c[14] = clk_bbkeep;
         for (int w = 0; w < 3; ++w) {
             c[8 + 2 * w] = ((unsigned long long)clk_hist[w][0] << 32) | clk_hist[w][1];
             c[9 + 2 * w] = ((unsigned long long)clk_hist[w][2] << 32) | clk_hist[w][3];
@@ -496,7 +636,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
     const float fx = (float)px;
     const size_t plane = (size_t)a.W * a.H;
-    const int tx0 = px - (lane & 15), ty0 = py0 - (lane >> 4);
+    const int ty0 = py0 - (lane >> 4);
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
     // transposed reduction: lane (c, s) = (rl >> 2, rl & 3) sums quarter s of component c; lanes >= 36 mirror lanes 0..27
@@ -522,6 +662,19 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         S[p] = in ? (a.image[o] * dCr[p] + a.image[o + plane] * dCg[p] + a.image[o + 2 * plane] * dCb[p]) : 0.0f;
         dead[p] = !in;
     }
+    // the rectangle of the pixels still taking entries: the no-op test runs against it, exactly as in the forward (same pixels frozen at
+    // the same batch boundaries, so the same entries are evaluated)
+    int qx0, qx1, qy0, qy1;
+    auto live_rect = [&]() {
+        int lx0 = 1 << 20, lx1 = -1, ly0 = 1 << 20, ly1 = -1;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!dead[p]) { lx0 = min(lx0, px); lx1 = max(lx1, px); ly0 = min(ly0, py0 + 4 * p); ly1 = max(ly1, py0 + 4 * p); }
+        }
+        qx0 = wave_min_i32(lx0); qx1 = wave_max_i32(lx1); qy0 = wave_min_i32(ly0); qy1 = wave_max_i32(ly1);
+        if (!GS_LIVE_RECT) { qx0 = px - (lane & 15); qx1 = qx0 + GS_TILE - 1; qy0 = ty0; qy1 = ty0 + GS_TILE - 1; }
+    };
+    live_rect();
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     uint32_t nid = 0;
@@ -560,15 +713,16 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         const uint32_t phase = gp & (CB - 1);
         const int cnt = (int)min((uint32_t)CB - phase, s1 - base);
         if (EARLY && phase == 0) {
-            bool live = false;
+            bool live = false, froze = false;
             alive = 0;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                if (!dead[p] && T[p] < a.t_min) { dead[p] = true; T[p] = 0.0f; S[p] = 0.0f; }
+                if (!dead[p] && T[p] < a.t_min) { dead[p] = true; T[p] = 0.0f; S[p] = 0.0f; froze = true; }
                 live = live || !dead[p];
                 if (__ballot(!dead[p]) != 0ull) alive |= 1u << p;           // strip p still has a pixel that takes entries
             }
             if (alive == 0u) { stop = true; break; }
+            if (__ballot(froze) != 0ull) live_rect();
         }
         if (CLK && (phase == 0 || gp == 0)) {
             clk_live = 0; clk_strips = 0;
@@ -577,7 +731,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         }
         uint32_t strips;
         bool keep;
-        stage_record<CULL>(n0, n1, n3, tx0, ty0, keep, strips);
+        stage_record<CULL>(n0, n1, n3, qx0, qx1, qy0, qy1, ty0, keep, strips);
         if (CULL && EARLY) strips &= alive;                                 // a strip of frozen pixels (T = S = 0) adds exact zeros
         int slot = lane, nk = cnt;
         if (!CULL) keep = true;

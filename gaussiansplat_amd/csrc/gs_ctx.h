@@ -116,7 +116,7 @@ struct gs_ctx {
     uint32_t *perm_all = nullptr;            // the whole depth order (perm_ptr)
     // ---- two-level binning (gs_bin3.hip): lists per super-tile of 8 x 8 tiles, then per tile
     bool two_level = false;
-    int sgx = 0, sgy = 0;
+    int sgx = 0, sgy = 0, sbs = 3;           // super-tile grid and log2 of the super-tile edge in tiles (3, or 4 on 4K-class grids)
     int64_t coarse_listed = 0;               // coarse instances of the current round
     DevBuf rect_sorted, l1_table, l1_rows, l1_partials, cids, clr, cranges, segcnt, sdone, tilecnt;
     uint32_t *bin_totals() { return counters.as<uint32_t>() + 32; }

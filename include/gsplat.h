@@ -145,6 +145,9 @@ typedef struct {
 } gs_config;
 #define GS_DEBUG_WIDE_CURSORS 1   /* two-level binning: 64-bit list cursors although the lists fit 32-bit byte offsets (tests)    */
 #define GS_DEBUG_ALWAYS_ORDER 2    /* longest-first launch orders (and their side stream) also on grids with fewer tiles than wave slots (tests) */
+#define GS_DEBUG_SUPER16 8          /* two-level binning with super-tiles of 16 x 16 tiles whatever the grid (default: on grids whose 8 x 8 super-tiles
+                                      would be more than 256, i.e. 4K-class images); GS_DEBUG_SUPER8 16: 8 x 8 whatever the grid (tests) */
+#define GS_DEBUG_SUPER8 16
 #define GS_DEBUG_TINY_CAPS 4       /* capped lists with the minimum cap on every tile, history or not: every tile that walks more than its
                                       first segment extends its list in the composite kernel (tests)                               */
 
@@ -369,11 +372,12 @@ int gs_get_work_counters_ex(gs_ctx *ctx, int64_t out[4]);
 int gs_debug_time_composite(gs_ctx *ctx, int which, int variant, int reps, float *mean_ms);
 
 /* Profiling aid: one launch of the composite forward (which=0) or backward (which=1) kernel of the current frame with
- * per-tile clocks.  out (HOST): 14 x gx*gy uint64 per tile {start, end (100 MHz s_memrealtime ticks), HW_ID | XCC_ID << 32,
+ * per-tile clocks.  out (HOST): 15 x gx*gy uint64 per tile {start, end (100 MHz s_memrealtime ticks), HW_ID | XCC_ID << 32,
  * walked << 32 | evaluated, shader cycles inside the per-entry loops, shader cycles outside them (staging a batch and waiting
  * for its gathers), per-entry strip slots executed << 32 | the slots needed if the tile's live pixels were packed 64 to a slot,
  * strips holding a live pixel << 32 | live pixels (the last four summed over the evaluated entries), and (forward) six words: the
- * evaluated entries by the number of 64-lane slots they would need with live pixels packed anywhere / by whole rows / inside columns}.
+ * evaluated entries by the number of 64-lane slots they would need with live pixels packed anywhere / by whole rows / inside columns,
+ * and the entries that would survive the no-op test against the rectangle of the live pixels instead of the whole tile}.
  * tools/tile_tail.py turns it into the occupancy-over-time, tail and frozen-pixel summaries under profiles/. */
 int gs_debug_tile_clock(gs_ctx *ctx, int which, int variant, uint64_t *out);
 

@@ -6,7 +6,8 @@ on the cases its structure makes special:
     direct-write path; super-tile lists far longer than one level-2 segment;
   * grids whose last super-tile row / column is ragged (gx, gy not multiples of 8) and grids smaller than one super-tile;
   * fewer list positions than one level-1 workgroup, a single gaussian, gaussians without any tile;
-  * a 4K-class grid (510 super-tiles: 512 positions per level-1 workgroup instead of 1024).
+  * a 4K-class grid (super-tiles of 16 x 16 tiles by default there; 8 x 8 forced: 510 super-tiles, 512 positions per level-1
+    workgroup), an 8K grid, and super-tiles of 16 x 16 tiles forced on the small grids.
 Lists are compared bit for bit, for the depth and the index order, and with the generate-in-pass radix path (bin_path 2).
 """
 import numpy as np
@@ -33,6 +34,7 @@ def _check_lists(O, B, sc, cam, T, P, ocam, W, H, deg, order, bin_path=0, **kw):
     return n_inst
 
 
+@pytest.mark.parametrize("super16", [False, True])
 @pytest.mark.parametrize("order", [1, 0])
 @pytest.mark.parametrize("n,W,H,grow", [
     (3000, 640, 400, 3.2),       # footprints of hundreds of pixels: most gaussians span many super-tiles (staging overflow, long lists)
@@ -41,11 +43,12 @@ def _check_lists(O, B, sc, cam, T, P, ocam, W, H, deg, order, bin_path=0, **kw):
     (1, 333, 222, 3.0),          # one gaussian
     (65, 2040, 72, 2.5),         # 128 x 5 tiles: one row of super-tiles
 ])
-def test_big_footprints_and_ragged_grids(oracle, n, W, H, grow, order):
+def test_big_footprints_and_ragged_grids(oracle, n, W, H, grow, order, super16):
+    """super16: super-tiles of 16 x 16 tiles (what 4K-class grids take by themselves) forced on these small grids"""
     from gaussiansplat_amd import backend as B
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, 1, 4000 + n)
     sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(grow)).astype(np.float32)        # log-scales: exp(grow) times larger
-    ni = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 1, order)
+    ni = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 1, order, debug_flags=B.GS_DEBUG_SUPER16 if super16 else 0)
     if n >= 1500:
         assert ni > 20 * n                                                                     # the footprints really are large
 
@@ -65,17 +68,20 @@ def test_gaussians_without_tiles_and_duplicates(oracle):
         a = sc[k].copy(); a[1::2] = a[1]; sc[k] = a
     sc["scales"] = (sc["scales"] + np.float32(2.0)).astype(np.float32)
     _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
+    _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, debug_flags=B.GS_DEBUG_SUPER16)
 
 
 def test_4k_grid_small_scene(oracle):
-    """3840 x 2160: 240 x 135 tiles = 30 x 17 super-tiles (510): the level-1 workgroups take 512 positions."""
+    """3840 x 2160: 240 x 135 tiles.  By default super-tiles of 16 x 16 tiles (15 x 9 = 135 of them: 8 x 8 would be 30 x 17 =
+    510, and level 1 costs per (chunk, super-tile)); GS_DEBUG_SUPER8 forces the 510 (512 positions per level-1 workgroup)."""
     from gaussiansplat_amd import backend as B
     n, W, H = 20_000, 3840, 2160
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, 0, 77)
     sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(1.0)).astype(np.float32)
     a = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
     b = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, bin_path=2)
-    assert a == b
+    c = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, debug_flags=B.GS_DEBUG_SUPER8)
+    assert a == b == c
 
 
 def test_8k_grid_and_wide_cursors(oracle):
@@ -88,6 +94,7 @@ def test_8k_grid_and_wide_cursors(oracle):
     sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(2.0)).astype(np.float32)
     a = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1)
     b = _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, debug_flags=B.GS_DEBUG_WIDE_CURSORS)
+    assert a == _check_lists(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, debug_flags=B.GS_DEBUG_WIDE_CURSORS | B.GS_DEBUG_SUPER8)   # 2040 super-tiles of 8 x 8
     n2, W2, H2 = 5_000, 640, 480
     sc2, cam2, T2, P2, ocam2 = scene_and_cameras(n2, W2, H2, 0, 79)
     sc2 = dict(sc2); sc2["scales"] = (sc2["scales"] + np.float32(1.5)).astype(np.float32)

@@ -125,8 +125,9 @@ def test_camera_jump_under_a_reused_slot_extends_lists_in_the_kernel():
     ctx.close(); plain.close()
 
 
-@pytest.mark.parametrize("n,W,H,deg,grow", [(120_000, 648, 470, 2, 1.0), (40_000, 256, 208, 3, 0.3), (300, 96, 64, 0, 0.0)])
-def test_minimum_caps_everywhere(oracle, n, W, H, deg, grow):
+@pytest.mark.parametrize("n,W,H,deg,grow,super16", [(120_000, 648, 470, 2, 1.0, False), (120_000, 648, 470, 2, 1.0, True), (40_000, 256, 208, 3, 0.3, False),
+                                                    (300, 96, 64, 0, 0.0, False)])
+def test_minimum_caps_everywhere(oracle, n, W, H, deg, grow, super16):
     """GS_DEBUG_TINY_CAPS: every tile's list is written up to its first segment(s) only; every tile that walks further extends
     its list -- also the tiles that never saturate, which end up appending their whole list.  Bits as with full lists, and vs
     the oracle within the usual bars."""
@@ -137,7 +138,7 @@ def test_minimum_caps_everywhere(oracle, n, W, H, deg, grow):
     for det in (True, False):
         plain = hip_context(sc, cam, T, P, W, H, deg, deterministic=det, list_cap=1, slab_mode=0)
         ref = _frame(plain, dC, deg); plain.close()
-        ctx = hip_context(sc, cam, T, P, W, H, deg, deterministic=det, slab_mode=0, debug_flags=B.GS_DEBUG_TINY_CAPS)
+        ctx = hip_context(sc, cam, T, P, W, H, deg, deterministic=det, slab_mode=0, debug_flags=B.GS_DEBUG_TINY_CAPS | (B.GS_DEBUG_SUPER16 if super16 else 0))
         for rep in range(2):
             f = _frame(ctx, dC, deg)
             assert f["st"]["capped"]

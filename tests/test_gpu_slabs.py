@@ -132,3 +132,23 @@ def test_slab_resume_with_negative_transmittance():
         assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2], equal_nan=True)
         for k in GRADS:
             assert np.array_equal(r[3][k], res[0][3][k], equal_nan=True), k
+
+
+def test_forced_slabs_with_super_tiles_of_16(oracle):
+    """The slab rounds on the two-level path with super-tiles of 16 x 16 tiles (the default of 4K-class grids, forced here):
+    completed super-tiles (super_done_kernel<4>) and completed tiles drop out of the later rounds; bits as with one round."""
+    from gaussiansplat_amd import backend as B, synthetic
+    n, W, H, deg = 9000, 600, 392, 1                                         # 38 x 25 tiles: 3 x 2 super-tiles of 16, ragged
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 23)
+    sc["scales"] = sc["scales"] + np.float32(1.3)
+    dC = synthetic.make_dC(W, H, 23)
+    c0 = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-4, deterministic=True, slab_mode=0)
+    r0 = _frame(c0, dC, deg); c0.close()
+    for flags in (B.GS_DEBUG_SUPER16, 0):
+        c1 = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-4, deterministic=True, slab_mode=1, slab_fractions=(0.12, 0.4), debug_flags=flags)
+        r1 = _frame(c1, dC, deg); c1.close()
+        assert r1[0] == 3
+        assert np.array_equal(r0[1], r1[1]) and np.array_equal(r0[2], r1[2])
+        assert r1[4]["walked_bwd"] == r1[4]["walked_fwd"] and r1[4]["evaluated_fwd"] == r0[4]["evaluated_fwd"] == r1[4]["evaluated_bwd"]
+        for k in GRADS:
+            assert np.array_equal(r0[3][k], r1[3][k]), k

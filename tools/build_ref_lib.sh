@@ -10,7 +10,7 @@ for f in $(git ls-tree --name-only $REV gaussiansplat_amd/csrc/); do git show $R
 git show $REV:include/gsplat.h > $D/x/include/gsplat.h
 cd $D/x/y/csrc
 for f in gs_preprocess gs_preprocess2d; do /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -ffp-contract=off -c $f.hip -o $f.o & done
-for f in gs_preprocess_bwd gs_sort gs_bin2 gs_bin3 gs_composite gs_loss gs_api; do /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -c $f.hip -o $f.o & done
+for f in $(ls *.hip | sed 's/\.hip$//' | grep -v '^gs_preprocess$\|^gs_preprocess2d$'); do /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -c $f.hip -o $f.o & done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../../../../../gaussiansplat_amd/lib_ref/libgsplat_hip.so *.o -ldl
 echo built gaussiansplat_amd/lib_ref/libgsplat_hip.so from $REV

@@ -97,6 +97,8 @@ def analyse(clk):
                 tot = max(sum(h), 1.0)
                 frozen["entries_share_by_slots_1_to_4_" + name] = [round(x / tot, 4) for x in h]
                 frozen["mean_slots_" + name] = sum((k + 1) * x for k, x in enumerate(h)) / tot
+        if clk.shape[1] > 14 and clk[ran, 14].sum() > 0:
+            frozen["evaluated_if_culled_against_live_rectangle_over_evaluated"] = float(clk[ran, 14].astype(np.float64).sum() / evs)
     # least squares: tile duration ~ a * walked + b * evaluated + c  (what a launch order should sort by)
     A = np.stack([walked.astype(np.float64), evaluated.astype(np.float64), np.ones(len(dur))], 1)
     coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
