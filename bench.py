@@ -38,19 +38,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
-def algorithmic_bytes(stage: str, N: int, I: int, I1: int, Iw_f: int, Iw_b: int, P: int, Tn: int, K: int) -> float:
+def algorithmic_bytes(stage: str, N: int, I: int, I1: int, Iw_f: int, Iw_b: int, P: int, Tn: int, K: int, I_listed: int | None = None) -> float:
     """Algorithmic HBM bytes of one launch of a stage.  SURVEY.md section 8(d) figures for the per-gaussian and the composite
     stages (I = tile instances, Iw = list entries actually walked).  For the binning the survey prices the reference-style
     pipeline (12 I key build + 24 I sort + 8 I ranges); the two-level binning that replaced it has less to move, and its own
     minimum is used so that the fractions cannot exceed 1: per gaussian the rectangle in and out of depth order, per coarse
-    instance I1 (gaussian x super-tile of 8x8 tiles) 6 B written once and read twice, per instance the 4-byte id."""
+    instance I1 (gaussian x super-tile of 8x8 or 16x16 tiles) 6 B written once and read twice, per LISTED instance the 4-byte id
+    (I_listed < I when the lists are capped, gs_config.list_cap: the ids nobody walks are not written)."""
     per_g_params = 4 * (3 + 3 + 4 + 1 + 3 * K)
+    if I_listed is None:
+        I_listed = I
     return {
         "preprocess": (per_g_params + 48) * N,
         "depth_sort": 16 * N,                       # one read + one write of the 8-byte (depth|id) pair
         "count_scan": 20 * N,                       # level-1 histogram: perm 4 + rectangle 8 read, rectangle in list order 8 written
         "emit": 12 * I,
-        "tile_sort": 8 * N + 18 * I1 + 4 * I + 8 * Tn,   # level-1 scatter + level 2 (counts, ranges, lists)
+        "tile_sort": 8 * N + 18 * I1 + 4 * I_listed + 8 * Tn,   # level-1 scatter + level 2 (counts, ranges, lists)
         "ranges": 8 * I + 8 * Tn,
         "composite_fwd": 40 * Iw_f + 16 * P,
         "composite_bwd": 40 * Iw_b + 20 * P + 36 * Iw_b,
@@ -177,6 +180,7 @@ def main():
     ap.add_argument("--schedule", type=int, default=0, help="gs_config.schedule (0 = library default = 3; 1 = tile order; 4 = forward by the previous frame when its slot has no history)")
     ap.add_argument("--no-view-slots", action="store_true", help="do not name view slots (the forward then launches in tile order)")
     ap.add_argument("--list-cap", type=int, default=0, help="gs_config.list_cap: 0 automatic (tile lists written as far as the view slot's previous frame walked them), 1 never, 2 also on small grids")
+    ap.add_argument("--debug-flags", type=int, default=0, help="gs_config.debug_flags (A/B runs: 16 = super-tiles of 8 x 8 tiles on every grid, 8 = of 16 x 16)")
     ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
     ap.add_argument("--settle-frames", type=int, default=24, help="untimed frames per rank the timed pass's renderer runs BEFORE its W warm-up "
                     "steps (0: none; the same count on every rank).  A fresh renderer's first ~20 frames run up to 4 %% slower than its "
@@ -273,7 +277,7 @@ def main():
     def make(t_min, profile_stages):
         return R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene, device=local, order=args.order, t_min=t_min,
                              profile_stages=profile_stages, alpha_cull=not args.no_cull, rank_mode=args.rank_mode, schedule=args.schedule,
-                             list_cap=args.list_cap)
+                             list_cap=args.list_cap, debug_flags=args.debug_flags)
 
     sync_mode = [args.grad_sync]                                                # the exchange `step` uses (N > 1)
 
@@ -448,7 +452,7 @@ def main():
         P, Tn, K = W * H, gx * gy, (deg + 1) ** 2
         early = args.t_min > 0
         pmc, pmc_src = _pmc_summary(args.config) if (abs(args.t_min - 1e-5) < 1e-12 or args.t_min == 0.0) else (None, None)
-        by = algorithmic_bytes(dom, n, I, I1, wf, wb, P, Tn, K)
+        by = algorithmic_bytes(dom, n, I, I1, wf, wb, P, Tn, K, ls["listed"])
         ach = by / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         dom_pmc = _pmc_entry(pmc, dom, early)
         dom_valu = valu_view(dom_pmc, dom_ms, pmc_src)
@@ -458,7 +462,7 @@ def main():
         for st, ms in stage_ms.items():
             if ms <= 0:
                 continue
-            b = algorithmic_bytes(st, n, I, I1, wf, wb, P, Tn, K)
+            b = algorithmic_bytes(st, n, I, I1, wf, wb, P, Tn, K, ls["listed"])
             e = {"algorithmic_bytes": b, "ms": round(ms, 5), "achieved_GBs": round(b / (ms * 1e-3) / 1e9, 1), "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             v = valu_view(_pmc_entry(pmc, st, early), ms, pmc_src)
             if v:

@@ -261,7 +261,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     // frozen is marked done and takes no further instances.
     if (SLAB && a.resume && a.tile_done[tile]) return;
     const uint32_t gp0 = SLAB && a.tile_pos ? a.tile_pos[tile] : 0u;
-    const size_t plane = (size_t)a.W * a.H;
+    const uint32_t plane = (uint32_t)a.W * (uint32_t)a.H;           // pixel indices fit 32 bits: W, H <= 32767 (gs_set_camera), 3 W H < 2^32
     // (a frozen pixel's transmittance is final: it goes to memory when the pixel freezes, not at the end of the tile)
     float Cr[4], Cg[4], Cb[4], T[4], fy[4];
     bool dead[4];
@@ -277,8 +277,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         T[p] = in ? 1.0f : 0.0f;
         dead[p] = !in;
         if (SLAB && a.resume && in) {
-            const size_t o = (size_t)(px - 1) + (size_t)a.W * (py0 + 4 * p - 1);
-            Cr[p] = a.image[o]; Cg[p] = a.image[o + plane]; Cb[p] = a.image[o + 2 * plane];
+            const uint32_t o = (uint32_t)(px - 1) + (uint32_t)a.W * (uint32_t)(py0 + 4 * p - 1);
+            Cr[p] = a.image[o]; Cg[p] = a.image[o + plane]; Cb[p] = a.image[o + 2u * plane];
             dead[p] = ((a.tile_dead[4 * (size_t)tile + p] >> lane) & 1ull) != 0ull;
             T[p] = dead[p] ? 0.0f : a.trans[o];                           // (a frozen pixel's transmittance stays where the round that froze it put it)
         }
@@ -293,12 +293,12 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (!dead[p]) {
-                const int x = (!PACK || K == 4) ? px : (int)fy[2 + (p & 1)], y = (int)fy[p];
+                const int x = (int)((!PACK || K == 4) ? fx : fy[2 + (p & 1)]), y = (int)fy[p];
                 lx0 = min(lx0, x); lx1 = max(lx1, x); ly0 = min(ly0, y); ly1 = max(ly1, y);
             }
         }
         qx0 = wave_min_i32(lx0); qx1 = wave_max_i32(lx1); qy0 = wave_min_i32(ly0); qy1 = wave_max_i32(ly1);
-        if (!GS_LIVE_RECT) { qx0 = px - (lane & 15); qx1 = qx0 + GS_TILE - 1; qy0 = ty0; qy1 = ty0 + GS_TILE - 1; }
+        if (!GS_LIVE_RECT) { qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = qx0 + GS_TILE - 1; qy0 = ty0; qy1 = ty0 + GS_TILE - 1; }
     };
     live_rect();
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
@@ -339,7 +339,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             for (int p = 0; p < 4; ++p) {
                 if (!dead[p] && T[p] < a.t_min) {                        // frozen from here on: its transmittance is final
                     const float x = (!PACK || K == 4) ? fx : fy[2 + (p & 1)];
-                    if (a.trans) a.trans[(size_t)((int)x - 1) + (size_t)a.W * ((int)fy[p] - 1)] = T[p];
+                    if (a.trans) a.trans[(uint32_t)((int)x - 1) + (uint32_t)a.W * (uint32_t)((int)fy[p] - 1)] = T[p];
                     dead[p] = true; T[p] = 0.0f; froze = true;
                 }
                 live = live || !dead[p];
@@ -359,8 +359,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
                         const float x = K == 4 ? fx : fy[2 + (p & 1)];
                         const bool mine = K == 4 ? (px <= a.W && py0 + 4 * p <= a.H) : (p < 2 && x > 0.5f);
                         if (mine && dead[p] && a.image) {
-                            const size_t o = (size_t)((int)x - 1) + (size_t)a.W * ((int)fy[p] - 1);
-                            a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p];
+                            const uint32_t o = (uint32_t)((int)x - 1) + (uint32_t)a.W * (uint32_t)((int)fy[p] - 1);
+                            a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2u * plane] = Cb[p];
                         }
                     }
                     // (2) live pixels -> ranks in slot-then-lane order -> six planes of 128 floats in the staging buffer -> slots 0 .. Kn-1
@@ -515,8 +515,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             if (fy[2 + q] > 0.5f) {
-                const size_t o = (size_t)((int)fy[2 + q] - 1) + (size_t)a.W * ((int)fy[q] - 1);
-                if (a.image) { a.image[o] = Cr[q]; a.image[o + plane] = Cg[q]; a.image[o + 2 * plane] = Cb[q]; }
+                const uint32_t o = (uint32_t)((int)fy[2 + q] - 1) + (uint32_t)a.W * (uint32_t)((int)fy[q] - 1);
+                if (a.image) { a.image[o] = Cr[q]; a.image[o + plane] = Cg[q]; a.image[o + 2u * plane] = Cb[q]; }
                 if (a.trans && !dead[q]) a.trans[o] = T[q];
             }
         }
@@ -525,8 +525,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         for (int p = 0; p < 4; ++p) {
             const int py = py0 + 4 * p;
             if (py <= a.H) {
-                const size_t o = (size_t)(px - 1) + (size_t)a.W * (py - 1);
-                if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2 * plane] = Cb[p]; }
+                const uint32_t o = (uint32_t)(px - 1) + (uint32_t)a.W * (uint32_t)(py - 1);
+                if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2u * plane] = Cb[p]; }
                 if (a.trans && !(EARLY && dead[p])) a.trans[o] = T[p];
             }
         }
@@ -649,6 +649,9 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
     bool dead[4];
     uint32_t walked = 0, evaluated = 0;
+    // (Packing the live pixels into one slot once 64 or fewer are left -- what the forward does -- was built for this kernel too and
+    // measured equal to slower, same box: the per-splat reduction, which packing does not shorten, is too large a share of an entry, and
+    // the packed loop cost the kernel 18 spilled registers: profiles/r04g_ab_backward_packing.log.)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int py = py0 + 4 * p;
@@ -669,10 +672,10 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         int lx0 = 1 << 20, lx1 = -1, ly0 = 1 << 20, ly1 = -1;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            if (!dead[p]) { lx0 = min(lx0, px); lx1 = max(lx1, px); ly0 = min(ly0, py0 + 4 * p); ly1 = max(ly1, py0 + 4 * p); }
+            if (!dead[p]) { const int x = (int)fx, y = (int)fy[p]; lx0 = min(lx0, x); lx1 = max(lx1, x); ly0 = min(ly0, y); ly1 = max(ly1, y); }
         }
         qx0 = wave_min_i32(lx0); qx1 = wave_max_i32(lx1); qy0 = wave_min_i32(ly0); qy1 = wave_max_i32(ly1);
-        if (!GS_LIVE_RECT) { qx0 = px - (lane & 15); qx1 = qx0 + GS_TILE - 1; qy0 = ty0; qy1 = ty0 + GS_TILE - 1; }
+        if (!GS_LIVE_RECT) { qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = qx0 + GS_TILE - 1; qy0 = ty0; qy1 = ty0 + GS_TILE - 1; }
     };
     live_rect();
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
