@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="view batches: one renderer, one stream (default: the views of a rank alternate between "
                     "--pipeline-depth renderers / streams over the same model, so the lists of view k+1 are built beside the composite kernels of view k)")
     ap.add_argument("--pipeline-depth", type=int, default=3, help="view batches: views of a rank in flight at once (renderers / streams over the same model; 3: + 2 % over 2 at C4 on one GPU, 4 and 5 no better)")
+    ap.add_argument("--own-renderer-in-flight", action="store_true", help="A/B: the pipelined view batches use the rank's own renderer + depth-1 new ones instead of depth new ones (measured slower: distributed.HipViewRenderer)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
     if args.config is None:
@@ -286,7 +287,7 @@ def main():
     def step(r, k):
         """one step = one view batch: this rank's views one after the other (gradients accumulate), then the exchange"""
         batch = batches[k % len(batches)]
-        hv = r.__dict__.setdefault("_bench_hv", D.HipViewRenderer(r, args.pipeline_depth))            # (cycle r <-> hv: collected by gc below)
+        hv = r.__dict__.setdefault("_bench_hv", D.HipViewRenderer(r, args.pipeline_depth, args.own_renderer_in_flight))   # (cycle r <-> hv: collected by gc below)
         D.multi_view_step(hv, [cams[v] for v in batch], [dCs[v] for v in batch], sync=sync_mode[0], overlap=not args.no_overlap,
                           pipeline=not args.no_pipeline, exchange=exchange_on[0])
 

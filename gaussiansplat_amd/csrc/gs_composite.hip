@@ -300,7 +300,11 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         qx0 = wave_min_i32(lx0); qx1 = wave_max_i32(lx1); qy0 = wave_min_i32(ly0); qy1 = wave_max_i32(ly1);
         if (!GS_LIVE_RECT) { qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = qx0 + GS_TILE - 1; qy0 = ty0; qy1 = ty0 + GS_TILE - 1; }
     };
-    live_rect();
+    {   // at the start every pixel inside the image is live: the tile's rectangle clipped to the image (no reduction needed), unless a
+        // slab round resumes with frozen pixels
+        qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = min(qx0 + GS_TILE - 1, a.W); qy0 = ty0; qy1 = min(ty0 + GS_TILE - 1, a.H);
+        if (SLAB && a.resume) live_rect();
+    }
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     uint32_t pos = s0 + lane;
@@ -345,8 +349,9 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
                 live = live || !dead[p];
             }
             if (__ballot(live) == 0ull) { stopped = true; break; }
-            if (__ballot(froze) != 0ull) live_rect();
-            if (PACK && K > 1) {
+            const bool anyfroze = __ballot(froze) != 0ull;                // (nothing froze: rectangle and live count are what they were)
+            if (anyfroze) live_rect();
+            if (PACK && K > 1 && anyfroze) {
                 uint64_t lm[4];
                 uint32_t nlive = 0;
 #pragma unroll
@@ -677,7 +682,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         qx0 = wave_min_i32(lx0); qx1 = wave_max_i32(lx1); qy0 = wave_min_i32(ly0); qy1 = wave_max_i32(ly1);
         if (!GS_LIVE_RECT) { qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = qx0 + GS_TILE - 1; qy0 = ty0; qy1 = ty0 + GS_TILE - 1; }
     };
-    live_rect();
+    qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = min(qx0 + GS_TILE - 1, a.W); qy0 = ty0; qy1 = min(ty0 + GS_TILE - 1, a.H);   // every pixel inside the image is live
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     uint32_t nid = 0;

@@ -129,8 +129,13 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
 class HipViewRenderer:
     """Adapter of a GaussianRenderer3D (HIP path) to the ViewRenderer protocol."""
 
-    def __init__(self, renderer, pipeline_depth: int = 3):
+    def __init__(self, renderer, pipeline_depth: int = 3, own_renderer_in_flight: bool = False):
         self.r = renderer
+        # True: the rank's own renderer is one of the `pipeline_depth` in flight (one ctx less).  Measured SLOWER on MI355X with the
+        # runtime's default of four hardware queues (8-view batch, one GPU, same box: 9.8 ms against 9.0 ms with `pipeline_depth` new
+        # renderers; the relation flips with GPU_MAX_HW_QUEUES=8 -- it is a matter of which HSA queue each stream lands on, which
+        # neither torch nor HIP lets a host choose; profiles/r04i_c4_twins.log), so the default keeps the own renderer out of it.
+        self.own_renderer_in_flight = own_renderer_in_flight
         self.last_ctx = renderer.ctx            # the ctx that rendered the most recent view (introspection: counters, instance counts)
         self.pipeline_depth = max(2, int(pipeline_depth))      # views in flight in render_views_pipelined
 
@@ -162,18 +167,18 @@ class HipViewRenderer:
     # ---- several views of one rank on `pipeline_depth` streams (multi_view_step(pipeline=True))
     def _twins(self):
         """`pipeline_depth` renderers in flight over the SAME parameter tensors and the SAME flat gradient buffer (borrowed device
-        pointers: no copy of the model, no gradient buffer of their own): the rank's own renderer is the first, the others are
-        twins with their own ctx -- i.e. their own per-view scratch (payload rows, depth order, tile lists, image; 288 GB of HBM
-        hold many) -- created from a copy of the WHOLE gs_config, so that every view takes the same code paths.  Each has its
-        own HIP stream."""
+        pointers: no copy of the model, no gradient buffer of their own): twins of the rank's renderer with their own ctx -- i.e.
+        their own per-view scratch (payload rows, depth order, tile lists, image; 288 GB of HBM hold many) -- created from a copy of
+        the WHOLE gs_config, so that every view takes the same code paths.  Each has its own HIP stream.  (own_renderer_in_flight:
+        the rank's own renderer is the first of them.)"""
         if getattr(self, "_tw", None) is None:
             import torch
             from . import renderer as R
             r = self.r
             H, W = r.transmittance.shape
             dev = r.imageData.device
-            tw = [(r, torch.cuda.Stream(device=dev))]
-            for _ in range(self.pipeline_depth - 1):
+            tw = [(r, torch.cuda.Stream(device=dev))] if self.own_renderer_in_flight else []
+            for _ in range(self.pipeline_depth - len(tw)):
                 t = R.GaussianRenderer3D(r.splatData, (W, H), r.sh_degree, device=dev.index or 0, share_grads_with=r, cfg=r.ctx.cfg)
                 tw.append((t, torch.cuda.Stream(device=dev)))
             self._tw = tw
