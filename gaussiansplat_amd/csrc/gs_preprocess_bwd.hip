@@ -50,8 +50,24 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
     constexpr int K = (DEG + 1) * (DEG + 1);
     constexpr int ROW = 3 * K + 1;
     extern __shared__ __attribute__((aligned(16))) float tile[];       // [256][ROW]
+    // Untouched gaussians.  With the transmittance early-out most gaussians of a dense view are never composited (C3: 63 %, C5: 90 %,
+    // tools/touched_rows.py): their colour gradient d rgb is exactly zero, hence d shs = basis * 0 and the colour -> direction term are
+    // exactly zero.  When ACCUMULATING (views after the first of a batch) their SH rows (192 B at degree 3) are not loaded and their
+    // d_shs rows neither read nor written: C4 on one GPU 8.85 -> 8.71 ms per 8 views, same box.  When OVERWRITING the zeros have to be
+    // written anyway and making the SH loads wait for the gradient row costs what the skipped loads save (C3 1.316 vs 1.324 ms):
+    // there the rows are loaded unconditionally, as before (profiles/r04j_ab_untouched_rows.log).
+    constexpr bool SKIP = !OVERWRITE;
+    __shared__ uint8_t srow_live[256];
     const int64_t gb = (int64_t)blockIdx.x * blockDim.x;
     const int nb = (int)min((int64_t)blockDim.x, a.n - gb);
+    float g2[10];
+    if (SKIP) {
+        const int64_t g0 = gb + threadIdx.x;
+        bool lv = false;
+        if (g0 < a.n) { load_g2(a, g0, g2); lv = g2[0] != 0.0f || g2[1] != 0.0f || g2[2] != 0.0f; }
+        srow_live[threadIdx.x] = lv ? 1 : 0;
+        __syncthreads();
+    }
     // 3K is a multiple of 4 only for K = 4, 16 ... : use 16-byte global accesses when it is
     constexpr bool VEC = (3 * K) % 4 == 0;
     const bool vec_in = VEC && (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0;
@@ -59,19 +75,19 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
     if (vec_in) {
         const float4 *src = reinterpret_cast<const float4 *>(a.shs + gb * 3 * K);       // gb*3K*4 B is 16-B aligned (gb % 256 == 0)
         for (int i4 = threadIdx.x; i4 < nb * (3 * K / 4); i4 += blockDim.x) {
-            const float4 v = src[i4];
-            float *d = tile + ((i4 * 4) / (3 * K)) * ROW + (i4 * 4) % (3 * K);
+            const int row = (i4 * 4) / (3 * K);
+            const float4 v = (!SKIP || srow_live[row]) ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float *d = tile + row * ROW + (i4 * 4) % (3 * K);
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
     } else {
         for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x)
-            tile[(idx / (3 * K)) * ROW + idx % (3 * K)] = a.shs[gb * 3 * K + idx];
+            tile[(idx / (3 * K)) * ROW + idx % (3 * K)] = (!SKIP || srow_live[idx / (3 * K)]) ? a.shs[gb * 3 * K + idx] : 0.0f;
     }
     __syncthreads();
     const int64_t g = gb + threadIdx.x;
     if (g < a.n) {
-        float g2[10];
-        load_g2(a, g, g2);
+        if (!SKIP) load_g2(a, g, g2);
         // a gaussian no pixel touched (off screen, or skipped by the composite because its per-view payload is not finite:
         // tz == 0, exp(scale) overflow, singular covariance) has an all-zero row: its gradient is exactly zero, and the
         // recomputed direction may be NaN, so zeros are substituted for the basis instead of forming 0 * NaN
@@ -134,7 +150,9 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
         if (vec_out) {
             float4 *dst = reinterpret_cast<float4 *>(a.d_shs + gb * 3 * K);
             for (int i4 = threadIdx.x; i4 < nb * (3 * K / 4); i4 += blockDim.x) {
-                const float *t = tile + ((i4 * 4) / (3 * K)) * ROW + (i4 * 4) % (3 * K);
+                const int row = (i4 * 4) / (3 * K);
+                if (!OVERWRITE && !srow_live[row]) continue;             // + 0 (or a step of 0): the row stays as it is
+                const float *t = tile + row * ROW + (i4 * 4) % (3 * K);
                 float4 v = make_float4(t[0], t[1], t[2], t[3]);
                 if (!OVERWRITE) {
                     const float4 o = dst[i4];
@@ -145,6 +163,7 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
             }
         } else {
             for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x) {
+                if (!OVERWRITE && !srow_live[idx / (3 * K)]) continue;
                 const float v = tile[(idx / (3 * K)) * ROW + idx % (3 * K)];
                 if (OVERWRITE) a.d_shs[gb * 3 * K + idx] = v;
                 else if (a.sgd_scale != 0.0f) a.d_shs[gb * 3 * K + idx] = fmaf(a.sgd_scale, v, a.d_shs[gb * 3 * K + idx]);
@@ -172,6 +191,13 @@ __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a,
     float g2f[10];
     load_g2(a, g, g2f);                                  // colour gradient + raw moments (gs_common.h: gs_g2d_to_grads)
     const float *T = cam.T, *P = cam.P;
+    if (!OVERWRITE) {   // untouched by the view (see gs_sh_bwd_kernel): a gradient of exactly zero is added to nothing -- the model is not read
+        const float4 dpc0 = reinterpret_cast<const float4 *>(a.dpc)[g];
+        bool touched = dpc0.x != 0.0f || dpc0.y != 0.0f || dpc0.z != 0.0f;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) touched = touched || g2f[i] != 0.0f;
+        if (!touched) return;
+    }
 
     // ---- forward recompute (same formulas as gs_preprocess.hip)
     const double m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
