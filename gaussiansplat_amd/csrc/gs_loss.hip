@@ -56,13 +56,15 @@ __device__ __forceinline__ float block_sum_256(float v, float *sm) {
 template <int NT> struct HaloIt { static constexpr int n = (LHY * LPITCH + NT - 1) / NT; };     // halo elements per thread and plane
 template <int NT>
 __device__ __forceinline__ void halo_fetch(float (&v)[HaloIt<NT>::n], const float *__restrict__ plane, int W, int H, int x0, int y0) {
+    int hy = (int)threadIdx.x / LPITCH, hx = (int)threadIdx.x - hy * LPITCH;          // element i = thread + NT k: one division, then steps
 #pragma unroll
     for (int k = 0; k < HaloIt<NT>::n; ++k) {
-        const int i = (int)threadIdx.x + NT * k;
-        const int hy = i / LPITCH, hx = i - hy * LPITCH, gx = x0 + hx - LP, gy = y0 + hy - LP;
+        const int gx = x0 + hx - LP, gy = y0 + hy - LP;
         const bool in = hx < LHX && gx >= 0 && gx < W && gy >= 0 && gy < H;          // (hy >= LHY: gy may still be inside; never stored)
         const float t = plane[(uint32_t)(min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1))];   // uniform base + 32-bit lane offset
         v[k] = in ? t : 0.0f;
+        hx += NT % LPITCH; hy += NT / LPITCH;
+        if (hx >= LPITCH) { hx -= LPITCH; hy += 1; }
     }
 }
 template <int NT>
@@ -96,9 +98,10 @@ __device__ __forceinline__ void fold_cols(float (&acc)[NO], const float (&F)[NF]
 // Tile of a workgroup.  The dispatcher deals workgroups to the 8 XCDs round-robin (block b runs on XCD b % 8), each XCD with its own
 // L2; in plain grid order the eight tiles around a tile sit on eight different XCDs and every one fetches the shared halo from memory
 // itself.  Here XCD x works through the x-th eighth of the tiles in row-major order, so the tiles in flight on an XCD are neighbours
-// (stats 109 -> 105 us, grad 72 -> 68 us at 1920x1080x3).  (Persistent workgroups that fetch the next tile's halo into registers before
-// the stencil of the current one were measured too: slower, 111 / 77 us -- the 16 / 24 registers held across the stencil cost a wave
-// per SIMD; profiles/r04m_loss_persistent.log.)
+// (stats 109 -> 105 us, grad 72 -> 68 us at 1920x1080x3).  (Persistent workgroups that fetch the next tile's halo before the stencil of
+// the current one were measured too, into registers and by LDS-DMA into a second pair of buffers: 111 / 114 us for the stats kernel
+// against 105 -- the kernel is bound by its 2700 VALU instructions per wave, not by the fetch; profiles/r04m_loss_persistent.log,
+// r04n_loss_lds_dma.log.)
 struct LossTile { int x0, y0, c; };
 __device__ __forceinline__ bool loss_tile(const GsLossArgs &a, LossTile &t) {
     const int gx = (a.W + LTX - 1) / LTX, gy = (a.H + LTY - 1) / LTY, T = gx * gy * a.C;
