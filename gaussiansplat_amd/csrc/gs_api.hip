@@ -59,6 +59,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (c0.debug_flags & ~(GS_DEBUG_WIDE_CURSORS | GS_DEBUG_ALWAYS_ORDER | GS_DEBUG_TINY_CAPS | GS_DEBUG_SUPER16 | GS_DEBUG_SUPER8)) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown debug_flags");
     if (c0.depth_sort < 0 || c0.depth_sort > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: depth_sort must be 0, 1 or 2");
     if (c0.list_cap < 0 || c0.list_cap > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: list_cap must be 0, 1 or 2");
+    if (c0.tile_parts != 0 && c0.tile_parts != 1 && c0.tile_parts != 2 && c0.tile_parts != 4) return fail(nullptr, GS_ERR_INVALID, "gs_create: tile_parts must be 0, 1, 2 or 4");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

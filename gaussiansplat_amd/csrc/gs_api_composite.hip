@@ -63,6 +63,15 @@ int gs_set_view_slot(gs_ctx *c, int32_t slot) {
     return GS_OK;
 }
 
+// waves per tile of this frame's composite launches (gs_config.tile_parts)
+static int composite_parts(const gs_ctx *c) {
+    const int want = c->cfg.tile_parts;
+    if (want == 1 || !(c->cfg.t_min > 0.0f) || c->n_rounds > 1 || c->frame_capped) return 1;
+    if (want == 2 || want == 4) return want;
+    const long long ntiles = (long long)c->gx * c->gy, slots = 5120;       // 256 CUs x 4 SIMDs x five waves (GS_FWD_MINW, GS_BWD_MINW)
+    return 4 * ntiles <= slots ? 4 : 2 * ntiles <= slots ? 2 : 1;
+}
+
 // the composite launch of round r of the frame (r = 0 unless the frame is binned in depth slabs)
 static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     const int R = c->n_rounds;
@@ -76,6 +85,7 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.resume = r > 0; a.final_round = r == R - 1;
     a.tile_work = c->tile_work.as<uint32_t>(); a.tile_walked = const_cast<uint32_t *>(c->last_walked);
     a.tile_order = order; a.order_len = order ? gs_lpt_order_len(c->gx, c->gy) : 0;
+    a.parts = c->frame_parts;
     if (c->frame_capped && R == 1) {                                        // capped lists: the wave extends its tile's list when it must
         a.tile_ext = c->tile_ext.as<uint2>(); a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>();
         a.ids_w = c->ids.as<uint32_t>(); a.sgx = c->sgx; a.sbs = c->sbs; a.ext_count = c->ext_count();
@@ -114,6 +124,7 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
         HIPCHK(c, c->tile_dead.ensure(sizeof(unsigned long long) * 4 * (ntiles ? ntiles : 1)));
         HIPCHK(c, hipMemsetAsync(c->tile_pos.p, 0, sizeof(uint32_t) * ntiles, c->stream));
     }
+    c->frame_parts = composite_parts(c);
     const uint32_t *order = forward_order(c);
     if (c->order_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0)); c->order_pending = false; }     // the order kernel in flight reads tile_work
     for (int r = 0; r < R; ++r) {
@@ -198,6 +209,7 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
     a.walked = nullptr; a.tile_walked = c->tile_walked_b.as<uint32_t>(); a.tile_work = c->tile_work_b.as<uint32_t>();
     if (c->frame_capped && c->n_rounds == 1) a.tile_ext = c->tile_ext.as<uint2>();      // the lists end where gs_bin / the forward stopped writing them
     a.cull = c->cfg.alpha_cull != 0;
+    a.parts = c->frame_parts;                                              // as the frame's forward
     if (!params_only) {
         c->last_dC = dC_dev;
         // zero fill of the gradient rows (64 B per gaussian), in line: on a side stream beside the forward composite it cost more than

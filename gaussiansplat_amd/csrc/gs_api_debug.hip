@@ -277,6 +277,12 @@ int gs_get_list_stats(gs_ctx *c, int64_t out[3]) {
     return GS_OK;
 }
 
+int gs_get_tile_parts(gs_ctx *c) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_tile_parts: gs_forward first");
+    return c->frame_parts;
+}
+
 int gs_get_work_counters_ex(gs_ctx *c, int64_t out[4]) {
     if (!c || !out) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_work_counters_ex: gs_forward first");

@@ -283,6 +283,10 @@ struct GsCompositeArgs {
     uint32_t *ids_w;           // == ids, writable
     int sgx, sbs;              // super-tile grid width, log2 of the super-tile edge in tiles
     uint32_t *ext_count;       // segments appended by the forward's waves (one atomic per extension: the rare path), may be null
+    // small grids: 1, 2 or 4 waves (workgroups) per tile, each owning 4, 2 or 1 of the tile's four 16 x 4 pixel strips and walking the
+    // tile's list on its own (gs_config.tile_parts; single-round frames with the early-out and full lists only).  Block b of the launch
+    // is part b / len of tile (order[]) b % len, len = the launch length of one part.
+    int parts;
 };
 // the written entries of capped lists, summed over the tiles: out[0] = sum ext[t].x
 hipError_t gs_launch_sum_listed(const uint2 *ext, int n, unsigned long long *out, hipStream_t s);

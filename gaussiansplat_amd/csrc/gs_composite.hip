@@ -71,14 +71,21 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 
 // The tile of this workgroup: its own index, or -- plain launch over a launch order (gs_config.schedule 3 / 4) -- order[blockIdx]
 // (holes of the order: GS_LPT_NONE).  -1: nothing to do.
-__device__ __forceinline__ int tile_of_block(const GsCompositeArgs &a, int ntiles) {
+__device__ __forceinline__ int tile_of_block(const GsCompositeArgs &a, int ntiles, int &part) {
+    const int len = (a.tile_order && a.order_len > 0) ? a.order_len : ((ntiles + 7) / 8) * 8;   // composite_grid(): blocks of one part
+    int b = (int)blockIdx.x;
+    part = 0;
+    if (a.parts > 1) { part = b / len; b -= part * len; if (part >= a.parts) return -1; }   // the parts of a tile: same XCD (len % 8 == 0)
     if (a.tile_order) {
-        if ((int)blockIdx.x >= (a.order_len > 0 ? a.order_len : ntiles)) return -1;
-        const uint32_t t = a.tile_order[blockIdx.x];
+        if (b >= (a.order_len > 0 ? a.order_len : ntiles)) return -1;
+        const uint32_t t = a.tile_order[b];
         return t < (uint32_t)ntiles ? (int)t : -1;
     }
-    const int tile = (int)blockIdx.x;
-    return tile < ntiles ? tile : -1;
+    return b < ntiles ? b : -1;
+}
+// the pixel strips (slots) part `part` of a tile owns: all four, a pair, or one
+__device__ __forceinline__ uint32_t strips_of_part(const GsCompositeArgs &a, int part) {
+    return a.parts == 4 ? (1u << part) : a.parts == 2 ? (3u << (2 * part)) : 0xFu;
 }
 
 __device__ __forceinline__ unsigned long long wave_hw_id() {
@@ -239,7 +246,7 @@ template <bool EARLY, bool CULL, bool CLK, bool SLAB>
 // K = 2 or 1 slots per entry instead of 4.  A packed slot carries its own x (the shared per-lane column is gone), so a slot costs
 // 18 VALU instructions instead of 12 + 6 shared: K = 2 is 36 against 54, K = 1 is 18.  Every pixel sees the same entries in the same
 // order with the same arithmetic, so the image and the transmittance are bit-identical to the unpacked walk.
-__device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, const float nbig) {
+__device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, const int part, float4 *sp, float *syhi, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
@@ -267,13 +274,15 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     bool dead[4];
     uint32_t walked = 0, evaluated = 0;
     constexpr bool PACK = GS_FWD_PACK && EARLY && !SLAB;
+    const uint32_t own = (EARLY && !SLAB) ? strips_of_part(a, part) : 0xFu;   // tile_parts > 1: the strips this wave composites
+    bool first_pack = PACK && a.parts > 1;                              // ... packed into K = 2 / 1 slots at the first batch
     int K = 4;                                                          // slots per entry: 4 = the tile's pixels in place; 2 / 1 = live pixels packed
     // packed: slots 2 and 3 hold no pixel, and fy[2], fy[3] hold the x of the pixels in slots 0 and 1 (0 = the slot is empty)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         Cr[p] = Cg[p] = Cb[p] = 0.0f;
         fy[p] = (float)(py0 + 4 * p);
-        const bool in = (px <= a.W && py0 + 4 * p <= a.H);
+        const bool in = (px <= a.W && py0 + 4 * p <= a.H) && ((own >> p) & 1u);   // (a strip of another part: no pixel of this wave)
         T[p] = in ? 1.0f : 0.0f;
         dead[p] = !in;
         if (SLAB && a.resume && in) {
@@ -302,7 +311,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     };
     {   // at the start every pixel inside the image is live: the tile's rectangle clipped to the image (no reduction needed), unless a
         // slab round resumes with frozen pixels
-        qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = min(qx0 + GS_TILE - 1, a.W); qy0 = ty0; qy1 = min(ty0 + GS_TILE - 1, a.H);
+        qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = min(qx0 + GS_TILE - 1, a.W);
+        qy0 = ty0 + 4 * (int)__builtin_ctz(own); qy1 = min(ty0 + 4 * (31 - (int)__builtin_clz(own)) + 3, a.H);
         if (SLAB && a.resume) live_rect();
     }
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
@@ -351,7 +361,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             if (__ballot(live) == 0ull) { stopped = true; break; }
             const bool anyfroze = __ballot(froze) != 0ull;                // (nothing froze: rectangle and live count are what they were)
             if (anyfroze) live_rect();
-            if (PACK && K > 1 && anyfroze) {
+            if (PACK && K > 1 && (anyfroze || first_pack)) {
+                first_pack = false;
                 uint64_t lm[4];
                 uint32_t nlive = 0;
 #pragma unroll
@@ -362,7 +373,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const float x = K == 4 ? fx : fy[2 + (p & 1)];
-                        const bool mine = K == 4 ? (px <= a.W && py0 + 4 * p <= a.H) : (p < 2 && x > 0.5f);
+                        const bool mine = K == 4 ? (px <= a.W && py0 + 4 * p <= a.H && ((own >> p) & 1u)) : (p < 2 && x > 0.5f);
                         if (mine && dead[p] && a.image) {
                             const uint32_t o = (uint32_t)((int)x - 1) + (uint32_t)a.W * (uint32_t)((int)fy[p] - 1);
                             a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2u * plane] = Cb[p];
@@ -509,7 +520,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             if (lane == 0) a.tile_dead[4 * (size_t)tile + p] = m;
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && part == 0) {                                       // (tile_parts > 1: the counters of a tile are those of its first part)
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
         if (a.tile_work) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + evaluated : evaluated;
         if (a.tile_walked) a.tile_walked[tile] = SLAB && a.resume ? a.tile_walked[tile] + walked : walked;
@@ -529,7 +540,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int py = py0 + 4 * p;
-            if (py <= a.H) {
+            if (py <= a.H && ((own >> p) & 1u)) {
                 const uint32_t o = (uint32_t)(px - 1) + (uint32_t)a.W * (uint32_t)(py - 1);
                 if (a.image) { a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2u * plane] = Cb[p]; }
                 if (a.trans && !(EARLY && dead[p])) a.trans[o] = T[p];
@@ -557,8 +568,9 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     if (a.zero_words && blockIdx.x == 0 && threadIdx.x < 2) a.zero_words[threadIdx.x] = 0ull;
-    const int tile = tile_of_block(a, ntiles);
-    if (tile >= 0) forward_tile<EARLY, CULL, CLK, SLAB>(a, tile, sp, syhi, nbig);
+    int part;
+    const int tile = tile_of_block(a, ntiles, part);
+    if (tile >= 0) forward_tile<EARLY, CULL, CLK, SLAB>(a, tile, part, sp, syhi, nbig);
 }
 
 // ---------------------------------------------------------------- wave64 reduction of the nine per-splat sums
@@ -634,7 +646,7 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
 }
 
 template <bool EARLY, bool DET, bool CULL, bool CLK>
-__device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, float4 *sp, float *syhi, uint32_t *sid, uint32_t *sstrip,
+__device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, const int part, float4 *sp, float *syhi, uint32_t *sid, uint32_t *sstrip,
                                               float *red, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
@@ -654,13 +666,14 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
     bool dead[4];
     uint32_t walked = 0, evaluated = 0;
+    const uint32_t own = EARLY ? strips_of_part(a, part) : 0xFu;          // tile_parts > 1 (frames with the early-out): the strips this wave differentiates
     // (Packing the live pixels into one slot once 64 or fewer are left -- what the forward does -- was built for this kernel too and
     // measured equal to slower, same box: the per-splat reduction, which packing does not shorten, is too large a share of an entry, and
     // the packed loop cost the kernel 18 spilled registers: profiles/r04g_ab_backward_packing.log.)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int py = py0 + 4 * p;
-        const bool in = (px <= a.W && py <= a.H);
+        const bool in = (px <= a.W && py <= a.H) && ((own >> p) & 1u);
         const size_t o = in ? (size_t)(px - 1) + (size_t)a.W * (py - 1) : 0;
         fy[p] = (float)py;
         dCr[p] = in ? a.dC[o] : 0.0f;
@@ -682,7 +695,8 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         qx0 = wave_min_i32(lx0); qx1 = wave_max_i32(lx1); qy0 = wave_min_i32(ly0); qy1 = wave_max_i32(ly1);
         if (!GS_LIVE_RECT) { qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = qx0 + GS_TILE - 1; qy0 = ty0; qy1 = ty0 + GS_TILE - 1; }
     };
-    qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = min(qx0 + GS_TILE - 1, a.W); qy0 = ty0; qy1 = min(ty0 + GS_TILE - 1, a.H);   // every pixel inside the image is live
+    qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = min(qx0 + GS_TILE - 1, a.W);   // every pixel of the part's strips inside the image is live
+    qy0 = ty0 + 4 * (int)__builtin_ctz(own); qy1 = min(ty0 + 4 * (31 - (int)__builtin_clz(own)) + 3, a.H);
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     uint32_t nid = 0;
@@ -699,7 +713,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     // The tile's list is the concatenation of its segments, one per binning round of the frame (one segment unless the
     // frame was binned in depth slabs); batches end at multiples of CB of the WHOLE list, as in the forward.
     uint32_t gp = 0;
-    uint32_t alive = 0xFu;                                                // strips with a live pixel (refreshed at every batch boundary)
+    uint32_t alive = own;                                                 // strips with a live pixel (refreshed at every batch boundary)
     bool stop = false;
     unsigned long long t_loop = 0, t_stage = 0, t_mark = 0;               // debug clocks (a.tile_clock)
     unsigned long long clk_exec = 0, clk_ideal = 0, clk_alive = 0, clk_pix = 0;   // (see the forward)
@@ -799,9 +813,11 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         }
     }
     }
-    if (lane == 0 && a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
-    if (lane == 0 && a.tile_walked) a.tile_walked[tile] = walked;
-    if (lane == 0 && a.tile_work) a.tile_work[tile] = evaluated;
+    if (lane == 0 && part == 0) {                                         // (tile_parts > 1: the counters of a tile are those of its first part)
+        if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
+        if (a.tile_walked) a.tile_walked[tile] = walked;
+        if (a.tile_work) a.tile_work[tile] = evaluated;
+    }
     if (CLK && a.tile_clock && lane == 0) {
         unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)tile;
         c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
@@ -820,8 +836,9 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     __shared__ __attribute__((aligned(16))) float red[RED_FLOATS];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
-    const int tile = tile_of_block(a, ntiles);
-    if (tile >= 0) backward_tile<EARLY, DET, CULL, CLK>(a, tile, sp, syhi, sid, sstrip, red, nbig);
+    int part;
+    const int tile = tile_of_block(a, ntiles, part);
+    if (tile >= 0) backward_tile<EARLY, DET, CULL, CLK>(a, tile, part, sp, syhi, sid, sstrip, red, nbig);
 }
 
 // Longest-first order for a PLAIN launch (gs_config.schedule 3 / 4).  The dispatcher hands workgroups out in blockIdx order,
@@ -1028,9 +1045,9 @@ hipError_t gs_launch_clock_probe(unsigned long long *out, hipStream_t s) {
     return hipGetLastError();
 }
 
-static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {
-    if (a.tile_order && a.order_len > 0) return dim3((unsigned)a.order_len);
-    return dim3(((ntiles + 7) / 8) * 8);
+static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {           // (tile_of_block computes the same length of one part)
+    const int len = (a.tile_order && a.order_len > 0) ? a.order_len : ((ntiles + 7) / 8) * 8;
+    return dim3((unsigned)(len * (a.parts > 1 ? a.parts : 1)));
 }
 
 // variant (debug launches, gs_debug_time_composite / gs_debug_tile_clock): tens digit 1 = tile order instead of the frame's launch order
@@ -1046,6 +1063,7 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
+    if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.tile_pos || a.tile_clock)) return hipErrorInvalidValue;
     if (a.tile_ext && (gs_bin3_seg() != L2_SEG || !early || !a.cranges || !a.cids || !a.clr || !a.ids_w || a.tile_pos)) return hipErrorInvalidValue;
     if (a.tile_pos) {                                                     // a round of a slab frame (t_min > 0 by construction: plan_rounds)
         if (!early || a.tile_clock) return hipErrorInvalidValue;
@@ -1076,6 +1094,7 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const bool early = a.t_min > 0.0f;
     const dim3 grid = composite_grid(a, ntiles), block(64);
+    if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.nseg > 1 || a.tile_clock)) return hipErrorInvalidValue;
 #define GS_B2(E, D) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, true>), grid, block, 0, s, a); \
                          else hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, false>), grid, block, 0, s, a); } while (0)
 #define GS_B(E) do { if (a.g2d_fixed) GS_B2(E, true); else GS_B2(E, false); } while (0)

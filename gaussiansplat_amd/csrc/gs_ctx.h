@@ -90,6 +90,7 @@ struct gs_ctx {
     const uint32_t *last_walked = nullptr;   // per-tile walked counts of the most recent forward (the slot's array, or tile_walked)
     // ---- capped lists (gs_config.list_cap): this frame's tile lists were written only as far as the slot's history says they are walked
     bool frame_capped = false;
+    int frame_parts = 1;                   // waves per tile of the frame's composite launches (gs_config.tile_parts; decided by gs_forward)
     const uint32_t *cap_src = nullptr;       // the history the caps of this frame come from (null: none)
     DevBuf tile_nopen, smax, tile_ext, zero_tiles;
     GsBin3Args last_l2{};                    // the level-2 arguments of the frame's lists (gs_get_array writes the capped rest with them)

@@ -48,7 +48,7 @@ extern "C" {
  *    instead of running with shifted fields); schedule 0 now means "library default"; view slots (gs_set_view_slot);
  *    speculative binning (no host wait inside gs_bin); GS_BWD_PARAMS_SH / _GEOM; 64-byte payload and gradient rows.
  * 3: gs_config.list_cap (capped tile lists from the view slot's history; a former reserved word, sizeof unchanged); 4096 view
- *    slots; gs_get_list_stats. */
+ *    slots; gs_get_list_stats.  (gs_config.tile_parts, a later reserved word: 0 = the library's choice, as reserved words must be.) */
 #define GS_ABI_VERSION 3
 
 typedef enum {
@@ -141,7 +141,17 @@ typedef struct {
                                  than 5120 tiles (measured: at 28 % walked the shorter write pass only pays for the extra cap pass).
                                  1 never; 2 also on small grids (tests).  GS_ARR_TILE_RANGES is always the full ranges; asking for
                                  GS_ARR_SORTED_IDS / _KEYS of a capped frame first writes the unwritten rest.                   */
-    int32_t reserved[4];      /* sizeof(gs_config) == 96                                                                       */
+    int32_t tile_parts;       /* waves per tile on small grids (speed only).  The reference runs one 16 x 16 thread block per tile
+                                 (splat.jl:224-231, threads = (16, 16)); here one wave64 composites a tile, four pixels per lane in four
+                                 16 x 4 strips.  A grid with fewer tiles than the chip has wave slots (256 CUs x 4 SIMDs x 5) leaves
+                                 slots idle and every wave runs alone on its SIMD; then 2 or 4 waves share a tile, each owning two
+                                 strips or one and walking the tile's list on its own (forward and backward alike; the entries a
+                                 wave evaluates are tested against ITS pixels, so pixels may differ from the one-wave result by
+                                 contributions below 2^-27 -- the no-op rule of alpha_cull).  0 (default) automatic: 4 when
+                                 4 x tiles fit the wave slots, else 2 when 2 x tiles fit, else 1; 1, 2, 4: as given.  Always 1 for
+                                 frames without the early-out (t_min = 0), frames binned in depth slabs and capped lists.
+                                 With more than one part the per-tile work counters are those of the tile's first part.          */
+    int32_t reserved[3];      /* sizeof(gs_config) == 96                                                                       */
 } gs_config;
 #define GS_DEBUG_WIDE_CURSORS 1   /* two-level binning: 64-bit list cursors although the lists fit 32-bit byte offsets (tests)    */
 #define GS_DEBUG_ALWAYS_ORDER 2    /* longest-first launch orders (and their side stream) also on grids with fewer tiles than wave slots (tests) */
@@ -361,6 +371,10 @@ int gs_get_work_counters(gs_ctx *ctx, int64_t *walked_fwd, int64_t *walked_bwd);
  * capped, gs_config.list_cap; includes what composite waves appended), list segments appended by composite waves (0 when the
  * slot's history covered the frame), 1 if the frame's lists were capped else 0}.  Call after gs_forward; synchronises. */
 int gs_get_list_stats(gs_ctx *ctx, int64_t out[3]);
+
+/* Waves per tile (1, 2 or 4) of the last frame's composite launches (gs_config.tile_parts); negative: error.  Call after gs_forward.
+ * No counterpart in the reference (one thread block per tile, splat.jl:224-231). */
+int gs_get_tile_parts(gs_ctx *ctx);
 
 /* out = {walked_fwd, walked_bwd, evaluated_fwd, evaluated_bwd}: `evaluated` counts the walked entries that
  * survived the alpha_cull no-op test and were evaluated per pixel (== walked when alpha_cull == 0). */

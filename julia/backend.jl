@@ -39,7 +39,8 @@ mutable struct GsConfig                      # must mirror gs_config (96 bytes)
     debug_flags::Int32
     depth_sort::Int32
     list_cap::Int32                          # capped tile lists: 0 automatic, 1 never, 2 also on small grids
-    reserved::NTuple{4, Int32}
+    tile_parts::Int32                        # waves per tile on small grids: 0 automatic, 1, 2, 4
+    reserved::NTuple{3, Int32}
 end
 
 struct GsGrads                               # gs_grads: device pointers, may be C_NULL
@@ -65,7 +66,7 @@ function check(r::HipRenderer, rc::Cint)
 end
 
 function defaultConfig()
-    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, 0, 0, ntuple(_ -> Int32(0), 4))
+    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, 0, 0, 0, ntuple(_ -> Int32(0), 3))
     ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
     # a library built from another header would read this struct with shifted fields: refuse it here, loudly
     (hip_abiVersion() == GS_ABI_VERSION && cfg.abi_version == GS_ABI_VERSION && cfg.struct_size == sizeof(GsConfig)) ||
@@ -235,6 +236,9 @@ function hip_listStats(r::HipRenderer)
     check(r, ccall((:gs_get_list_stats, libgs), Cint, (Ptr{Cvoid}, Ptr{Int64}), r.ctx, out))
     return out
 end
+
+# waves per tile (1, 2, 4) of the last frame's composite launches (GsConfig.tile_parts)
+hip_tileParts(r::HipRenderer) = ccall((:gs_get_tile_parts, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 
 # renderer scratch arrays (gs_array ids of include/gsplat.h; e.g. 11 = sortIdxs, 12 = tile ranges, 13 = sorted ids) into a host array
 function hip_getArray!(r::HipRenderer, which::Integer, dst::Array)
