@@ -381,6 +381,7 @@ def main():
     I1 = lctx.num_coarse_instances
     wc = lctx.work_counters_ex()
     ls = lctx.list_stats()
+    tile_parts = lctx.tile_parts_of_frame()                                      # waves per tile of the composite launches (gs_config.tile_parts)
     wf, wb = wc["walked_fwd"], wc["walked_bwd"]
     value = views_per_step * n * args.steps / dt / 1e6
     nranks = dist.get_world_size() if world > 1 else 1
@@ -504,7 +505,7 @@ def main():
                        "view_slots": not args.no_view_slots,
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
                        "instances": I, "coarse_instances": I1, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
-                       "list_cap": args.list_cap, "lists_capped": ls["capped"], "listed_entries": ls["listed"], "list_segments_appended_by_waves": ls["extended_segments"],
+                       "list_cap": args.list_cap, "tile_parts": tile_parts, "lists_capped": ls["capped"], "listed_entries": ls["listed"], "list_segments_appended_by_waves": ls["extended_segments"],
                        "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "counters_of": "the last view rendered",
                        "seed": seed},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
