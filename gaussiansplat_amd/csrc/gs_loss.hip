@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256, 3) void ssim_stats_kernel(GsLossArgs a) {
     }
 }
 
-// NO outputs per thread (consecutive pixels of one row): 64 / NO x 16 threads per 64 x 16 tile.  The kernel is bound by the LDS reads of
-// its three planes, and a thread's NO + 10 window columns come out of (NO + 12) / 4 16-byte reads per row: 6 floats read per output
-// and plane row at NO = 4, 2.5 at NO = 8 (and the row folds are shared by eight outputs instead of four).
+// NO outputs per thread (consecutive pixels of one row): 64 / NO x 16 threads per 64 x 16 tile.  A thread's NO + 10 window columns come
+// out of (NO + 12) / 4 16-byte LDS reads per row: 6 floats read per output and plane row at NO = 4, 2.5 at NO = 8 -- measured equal
+// (68 vs 74 us at 1920x1080x3): what NO = 8 saves in LDS traffic it loses in occupancy (141 VGPRs, three waves per SIMD against five).
 #ifndef LOSS_GRAD_MINW
-#define LOSS_GRAD_MINW 3                 // waves per SIMD the kernel is built for (LDS: 23.9 KB per workgroup -> 6 workgroups of 2 waves per CU)
+#define LOSS_GRAD_MINW 3                 // waves per SIMD the kernel is built for at least (NO = 4 needs 92 VGPRs: five)
 #endif
 #ifndef LOSS_GRAD_NO
 #define LOSS_GRAD_NO 4
