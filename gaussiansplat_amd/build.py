@@ -31,7 +31,9 @@ SOURCES = {
     "gs_sort.hip": [],
     "gs_bin2.hip": [],
     "gs_bin3.hip": [],
-    "gs_composite.hip": [],
+    # no SLP vectoriser: a v_pk_*_f32 issues at the cost of two plain operations on gfx950, and forming the pairs costs moves
+    # (C3 1.328 -> 1.294 ms, C5 4.38 -> 4.26, same box, profiles/r04q_ab_no_slp.log; round 2's kernels had measured the opposite)
+    "gs_composite.hip": ["-fno-slp-vectorize"],
     # the SLP vectoriser turns the stencil into v_pk_* (no faster than two plain ops on gfx950) plus 270 register moves per loop body
     "gs_loss.hip": ["-fno-slp-vectorize"],
     "gs_api.hip": [],
@@ -91,4 +93,4 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", defines=())
 if __name__ == "__main__":
     tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else ""
     print(build(force="--force" in sys.argv, verbose=True, tag=tag,
-                defines=[a for a in sys.argv[1:] if a.startswith("-D")]))
+                defines=[a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-f")]))

@@ -102,7 +102,7 @@ def main():
     src = os.path.join(ROOT, "gaussiansplat_amd", "csrc", "gs_composite.hip")
     with tempfile.TemporaryDirectory() as td:
         s_path = os.path.join(td, "c.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", s_path, src] + os.environ.get("LOOP_COST_FLAGS", "").split(),
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", s_path, src] + os.environ.get("LOOP_COST_FLAGS", "").split(),
                        check=True, capture_output=True)
         asm = open(s_path).read()
     names = re.findall(r"^(_Z20composite_(?:fwd|bwd)_kernel\S*?):", asm, re.M)
