@@ -93,4 +93,4 @@ def build(force: bool = False, verbose: bool = False, tag: str = "", defines=())
 if __name__ == "__main__":
     tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else ""
     print(build(force="--force" in sys.argv, verbose=True, tag=tag,
-                defines=[a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-f")]))
+                defines=[a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-f") or a.startswith("-mllvm") or a.startswith("-amdgpu")]))

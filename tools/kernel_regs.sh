@@ -1,8 +1,10 @@
 #!/bin/bash
 # VGPRs / spills / occupancy of every kernel of one translation unit (hipcc's kernel-resource-usage remarks).
 # usage: tools/kernel_regs.sh gs_composite.hip [extra -D flags]
-src=gaussiansplat_amd/csrc/$1; shift
-/opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function -fno-slp-vectorize "$@" -c "$src" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 |
+src=gaussiansplat_amd/csrc/$1
+case "$1" in gs_composite.hip|gs_loss.hip) noslp=-fno-slp-vectorize;; *) noslp=;; esac   # as gaussiansplat_amd/build.py compiles them
+shift
+/opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function $noslp "$@" -c "$src" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 |
 python3 -c '
 import re, sys
 cur = None; rows = {}
