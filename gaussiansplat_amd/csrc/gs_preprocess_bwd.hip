@@ -11,10 +11,11 @@
 //
 // Two kernels, one thread per gaussian, no atomics (each thread owns its rows); HBM-bound:
 //   gs_sh_bwd_kernel    d rgb -> d shs, plus d rgb / d(clip position) handed to the second kernel
-//                       (16 B/gaussian).  The SH rows (3K floats = 192 B at degree 3, thread-strided in
-//                       HBM) go through an LDS tile [256][3K+1]: coalesced block loads, conflict-free
-//                       per-thread rows (odd stride), gradients written back into the same tile and
-//                       stored/added to d_shs with coalesced accesses.
+//                       (16 B/gaussian).  The SH gradients (3K floats = 192 B at degree 3, thread-strided in
+//                       HBM) go through an LDS tile [256][3K+1]: conflict-free per-thread rows (odd stride),
+//                       stored/added to d_shs with coalesced accesses.  The SH coefficients themselves are not
+//                       read: the colour's dependence on the view direction comes as the 3 x 3 Jacobian the
+//                       frame's preprocess wrote (GsPreprocessArgs.shjac, 48 B/gaussian).
 //   gs_geom_bwd_kernel  d{mu', invCov2d, sig} -> d{means, scales, quaternions, opacities}.  The chain (3x3 / 2x3 / 2x2
 //                       products, the 2x2 inverse and the quaternion terms) is evaluated in fp64 from the fp32 inputs:
 //                       in fp32 its cancellations put the quaternion gradient at 2e-4 .. 2e-3 relative L2 of the fp64
@@ -52,10 +53,8 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
     extern __shared__ __attribute__((aligned(16))) float tile[];       // [256][ROW]
     // Untouched gaussians.  With the transmittance early-out most gaussians of a dense view are never composited (C3: 63 %, C5: 90 %,
     // tools/touched_rows.py): their colour gradient d rgb is exactly zero, hence d shs = basis * 0 and the colour -> direction term are
-    // exactly zero.  When ACCUMULATING (views after the first of a batch) their SH rows (192 B at degree 3) are not loaded and their
-    // d_shs rows neither read nor written: C4 on one GPU 8.85 -> 8.71 ms per 8 views, same box.  When OVERWRITING the zeros have to be
-    // written anyway and making the SH loads wait for the gradient row costs what the skipped loads save (C3 1.316 vs 1.324 ms):
-    // there the rows are loaded unconditionally, as before (profiles/r04j_ab_untouched_rows.log).
+    // exactly zero.  When ACCUMULATING (views after the first of a batch) their d_shs rows are neither read nor written: C4 on one GPU
+    // 8.85 -> 8.71 ms per 8 views, same box (profiles/r04j_ab_untouched_rows.log).  When OVERWRITING the zeros have to be written.
     constexpr bool SKIP = !OVERWRITE;
     __shared__ uint8_t srow_live[256];
     const int64_t gb = (int64_t)blockIdx.x * blockDim.x;
@@ -70,21 +69,7 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
     }
     // 3K is a multiple of 4 only for K = 4, 16 ... : use 16-byte global accesses when it is
     constexpr bool VEC = (3 * K) % 4 == 0;
-    const bool vec_in = VEC && (reinterpret_cast<uintptr_t>(a.shs) & 15) == 0;
     const bool vec_out = VEC && (reinterpret_cast<uintptr_t>(a.d_shs) & 15) == 0;   // e.g. a flat buffer slice at 44 n bytes
-    if (vec_in) {
-        const float4 *src = reinterpret_cast<const float4 *>(a.shs + gb * 3 * K);       // gb*3K*4 B is 16-B aligned (gb % 256 == 0)
-        for (int i4 = threadIdx.x; i4 < nb * (3 * K / 4); i4 += blockDim.x) {
-            const int row = (i4 * 4) / (3 * K);
-            const float4 v = (!SKIP || srow_live[row]) ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            float *d = tile + row * ROW + (i4 * 4) % (3 * K);
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-    } else {
-        for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x)
-            tile[(idx / (3 * K)) * ROW + idx % (3 * K)] = (!SKIP || srow_live[idx / (3 * K)]) ? a.shs[gb * 3 * K + idx] : 0.0f;
-    }
-    __syncthreads();
     const int64_t g = gb + threadIdx.x;
     if (g < a.n) {
         if (!SKIP) load_g2(a, g, g2);
@@ -106,7 +91,7 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
         const float v2 = p[2] - (cam.lookAt[2] - cam.eye[2]);
         const float inrm = live ? rsqrtf(v0 * v0 + v1 * v1 + v2 * v2) : 0.0f;
         const float X = live ? v0 * inrm : 0.0f, Y = live ? v1 * inrm : 0.0f, Z = live ? v2 * inrm : 0.0f;
-        float bs[K], cs[K];
+        float bs[K];
         bs[0] = SH_C0;
         if constexpr (DEG >= 1) { bs[1] = -Y * SH_C1; bs[2] = Z * SH_C1; bs[3] = -X * SH_C1; }
         if constexpr (DEG >= 2) {
@@ -121,25 +106,18 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
         float *sh = tile + threadIdx.x * ROW;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            cs[k] = grgb[0] * sh[3 * k] + grgb[1] * sh[3 * k + 1] + grgb[2] * sh[3 * k + 2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) sh[c + 3 * k] = bs[k] * grgb[c];   // the tile now carries d L / d sh
+            for (int c = 0; c < 3; ++c) sh[c + 3 * k] = bs[k] * grgb[c];   // the tile carries d L / d sh (stored coalesced below)
         }
+        // d L / d dir through the colour: sum_c d rgb_c * (d rgb_c / d dir), the Jacobian the frame's preprocess wrote while it had
+        // the SH row in registers (gs_preprocess.hip: sh_jacobian_row) -- this kernel used to read the 3K coefficients a second time
         float ddir[3] = {0.0f, 0.0f, 0.0f};
-        if constexpr (DEG >= 1) { ddir[0] += -SH_C1 * cs[3]; ddir[1] += -SH_C1 * cs[1]; ddir[2] += SH_C1 * cs[2]; }
-        if constexpr (DEG >= 2) {
-            ddir[0] += bC2[0] * Y * cs[4] - 2 * bC2[2] * X * cs[6] + bC2[3] * Z * cs[7] + 2 * bC2[4] * X * cs[8];
-            ddir[1] += bC2[0] * X * cs[4] + bC2[1] * Z * cs[5] - 2 * bC2[2] * Y * cs[6] - 2 * bC2[4] * Y * cs[8];
-            ddir[2] += bC2[1] * Y * cs[5] + 4 * bC2[2] * Z * cs[6] + bC2[3] * X * cs[7];
-        }
-        if constexpr (DEG >= 3) {
-            const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
-            ddir[0] += 6 * bC3[0] * xy * cs[9] + bC3[1] * yz * cs[10] - 2 * bC3[2] * xy * cs[11] - 6 * bC3[3] * xz * cs[12]
-                       + bC3[4] * (4 * zz - 3 * xx - yy) * cs[13] + 2 * bC3[5] * xz * cs[14] + bC3[6] * (3 * xx - 3 * yy) * cs[15];
-            ddir[1] += bC3[0] * (3 * xx - 3 * yy) * cs[9] + bC3[1] * xz * cs[10] + bC3[2] * (4 * zz - xx - 3 * yy) * cs[11]
-                       - 6 * bC3[3] * yz * cs[12] - 2 * bC3[4] * xy * cs[13] - 2 * bC3[5] * yz * cs[14] - 6 * bC3[6] * xy * cs[15];
-            ddir[2] += bC3[1] * xy * cs[10] + 8 * bC3[2] * yz * cs[11] + bC3[3] * (6 * zz - 3 * xx - 3 * yy) * cs[12]
-                       + 8 * bC3[4] * xz * cs[13] + bC3[5] * (xx - yy) * cs[14];
+        if (live) {
+            const float4 *Jp = reinterpret_cast<const float4 *>(a.shjac) + 3 * g;
+            const float4 J0 = Jp[0], J1 = Jp[1], J2 = Jp[2];
+            ddir[0] = grgb[0] * J0.x + grgb[1] * J1.x + grgb[2] * J2.x;
+            ddir[1] = grgb[0] * J0.y + grgb[1] * J1.y + grgb[2] * J2.y;
+            ddir[2] = grgb[0] * J0.z + grgb[1] * J1.z + grgb[2] * J2.z;
         }
         const float dd = X * ddir[0] + Y * ddir[1] + Z * ddir[2];
         // d L / d tps[1:3] through the colour (dir = normalize(tps[1:3] - (lookAt - eye)))
