@@ -141,6 +141,19 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, 
     const float m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
     float ts[4], tps[4];
     project_mean(cam, m1, m2, m3, ts, tps);
+
+    // ---- sh2color, splat.jl:180-193 (degrees 2,3: build extension, same accumulation order).  First: the SH row (48 registers at
+    // degree 3) is dead before the covariance chain starts
+    float x, y, z;
+    view_direction(cam, tps, x, y, z);
+    const float *sh = a.shs + (int64_t)3 * K * g;
+    float sc[3], Jc[3][3], rgb[3];
+    if (a.shjac) {                                                       // gradients are wanted (GsPreprocessArgs.shjac): same colour sums
+        sh_color<DEG, true>(x, y, z, sh, sc, Jc);
+        store_sh_jacobian(a.shjac, g, Jc);
+    } else sh_color<DEG, false>(x, y, z, sh, sc, Jc);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = (float)((double)sc[c] + 0.5);    // :192
     const double cx = cam.W / 2.0, cy = cam.H / 2.0;                  // forward.jl:58-59 (Float64)
     const float wf = (float)cam.W, hf = (float)cam.H;
     const float mux = (float)((double)((wf * tps[0] / tps[3] + 1.0f) / 2.0f) + cx);   // projection.jl:88
@@ -234,17 +247,6 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, 
     const float bymin = (float)gs_jlmax(1.0, floor(-r + (double)muy));
     const float bymax = (float)gs_jlmin((double)cam.H, ceil(r + (double)muy));
 
-    // ---- sh2color, splat.jl:180-193 (degrees 2,3: build extension, same accumulation order)
-    float x, y, z;
-    view_direction(cam, tps, x, y, z);
-    const float *sh = a.shs + (int64_t)3 * K * g;
-    float sc[3], Jc[3][3], rgb[3];
-    if (a.shjac) {                                                       // gradients are wanted (GsPreprocessArgs.shjac): same colour sums
-        sh_color<DEG, true>(x, y, z, sh, sc, Jc);
-        store_sh_jacobian(a.shjac, g, Jc);
-    } else sh_color<DEG, false>(x, y, z, sh, sc, Jc);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rgb[c] = (float)((double)sc[c] + 0.5);    // :192
     // ---- cusigmoid, splat.jl:175-178
     const float ez = gs_expf(a.opac[g]);
     float sg = ez / (1.0f + ez);
