@@ -335,6 +335,7 @@ hipError_t gs_launch_sh_from_views(int64_t n, int sh_degree, const float *means,
 // dL/dM = 1/2 [Sxx Sxy; Sxy Syy].  In place: row becomes [dr dg db dsig dmx dmy d00 d01 d10 d11].
 template <typename R>
 __host__ __device__ inline void gs_g2d_to_grads(R (&g2)[10], R sig, R i0, R mc, R i3) {   // g2: the ten used words of a row
+#pragma clang fp contract(off)   // (called from two kernels that must produce the same bits: gs_geom_bwd_body.inc)
     const R S0 = g2[3], Sx = g2[4], Sy = g2[5], Sxx = g2[6], Sxy = g2[7], Syy = g2[9];
     g2[3] = sig > R(0) ? -S0 / sig : R(0);
     g2[4] = -(i0 * Sx + mc * Sy);

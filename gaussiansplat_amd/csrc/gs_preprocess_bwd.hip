@@ -46,8 +46,23 @@ __device__ __forceinline__ void load_g2(const GsPreprocessBwdArgs &a, int64_t g,
     }
 }
 
-template <int DEG, bool OVERWRITE>
+// old + v as one rounded add that the compiler may not fuse with the products v came from: the accumulating and the
+// overwriting instantiation must produce the SAME v (accumulating eight views == the sum of eight single-view gradients)
+__device__ __forceinline__ float add_exact(float old, float v) {
+#pragma clang fp contract(off)
+    return old + v;
+}
+// accumulate, or (sgd_scale != 0) apply the step: the same fma gs_sgd_step would do on the stored float gradient
+__device__ __forceinline__ float acc_or_step(float old, float v, float sgd_scale) {
+    return sgd_scale != 0.0f ? fmaf(sgd_scale, v, old) : add_exact(old, v);
+}
+
+// FUSED: the geometry chain of the gaussian follows in the same thread (gs_backward's usual case: both phases) -- its row of 2-D gradients
+// and its mean are read once, d L / d tps stays in registers, one launch less.  The two-kernel form remains for callers that run the
+// phases apart (a multi-GPU host starts the exchange of the SH gradients between them).
+template <int DEG, bool OVERWRITE, bool FUSED>
 __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
+#pragma clang fp contract(off)   // the fused and the two-kernel form must produce the same bits: no context-dependent fma formation
     constexpr int K = (DEG + 1) * (DEG + 1);
     constexpr int ROW = 3 * K + 1;
     extern __shared__ __attribute__((aligned(16))) float tile[];       // [256][ROW]
@@ -121,7 +136,15 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
         }
         const float dd = X * ddir[0] + Y * ddir[1] + Z * ddir[2];
         // d L / d tps[1:3] through the colour (dir = normalize(tps[1:3] - (lookAt - eye)))
-        reinterpret_cast<float4 *>(a.dpc)[g] = make_float4((ddir[0] - X * dd) * inrm, (ddir[1] - Y * dd) * inrm, (ddir[2] - Z * dd) * inrm, 0.0f);
+        const float4 dpc_sh = make_float4((ddir[0] - X * dd) * inrm, (ddir[1] - Y * dd) * inrm, (ddir[2] - Z * dd) * inrm, 0.0f);
+        if (FUSED) {
+            const float (&g2f)[10] = g2;
+#define GS_GEOM_DPC dpc_sh
+            do {
+#include "gs_geom_bwd_body.inc"
+            } while (0);
+#undef GS_GEOM_DPC
+        } else reinterpret_cast<float4 *>(a.dpc)[g] = dpc_sh;
     }
     __syncthreads();
     if (a.d_shs) {
@@ -151,183 +174,17 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
     }
 }
 
-// old + v as one rounded add that the compiler may not fuse with the products v came from: the accumulating and the
-// overwriting instantiation must produce the SAME v (accumulating eight views == the sum of eight single-view gradients)
-__device__ __forceinline__ float add_exact(float old, float v) {
-#pragma clang fp contract(off)
-    return old + v;
-}
-// accumulate, or (sgd_scale != 0) apply the step: the same fma gs_sgd_step would do on the stored float gradient
-__device__ __forceinline__ float acc_or_step(float old, float v, float sgd_scale) {
-    return sgd_scale != 0.0f ? fmaf(sgd_scale, v, old) : add_exact(old, v);
-}
-
 template <bool OVERWRITE>
 __global__ __launch_bounds__(256) void gs_geom_bwd_kernel(GsPreprocessBwdArgs a, GsCamera cam) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n) return;
     float g2f[10];
     load_g2(a, g, g2f);                                  // colour gradient + raw moments (gs_common.h: gs_g2d_to_grads)
-    const float *T = cam.T, *P = cam.P;
-    if (!OVERWRITE) {   // untouched by the view (see gs_sh_bwd_kernel): a gradient of exactly zero is added to nothing -- the model is not read
-        const float4 dpc0 = reinterpret_cast<const float4 *>(a.dpc)[g];
-        bool touched = dpc0.x != 0.0f || dpc0.y != 0.0f || dpc0.z != 0.0f;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) touched = touched || g2f[i] != 0.0f;
-        if (!touched) return;
-    }
-
-    // ---- forward recompute (same formulas as gs_preprocess.hip)
-    const double m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
-    double t[4], p[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = T[i] * m1 + T[i + 4] * m2 + T[i + 8] * m3 + T[i + 12];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = P[i] * t[0] + P[i + 4] * t[1] + P[i + 8] * t[2] + P[i + 12] * t[3];
-    const float4 dpc = reinterpret_cast<const float4 *>(a.dpc)[g];
-    // all-zero moments and colour path: the forward skipped this gaussian (payload not finite) or no pixel touched it.
-    // Its gradient is exactly zero; the recomputed J, cov, M below may hold Inf/NaN (tz == 0, exp overflow, singular
-    // covariance), and 0 * NaN must not reach the parameter gradients.
-    bool live = dpc.x != 0.0 || dpc.y != 0.0 || dpc.z != 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) live = live || g2f[i] != 0.0;
-    double g2[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) g2[i] = (double)g2f[i];
-    double dt[4] = {0, 0, 0, 0}, dp[4] = {dpc.x, dpc.y, dpc.z, 0.0};
-    const double tx = t[0], ty = t[1], tz = t[2], fx = cam.fx, fy = cam.fy;
-    const double itz = 1.0 / tz, itz2 = itz * itz;
-    const double J[2][3] = {{fx * itz, 0.0, -fx * tx * itz2}, {0.0, fy * itz, -fy * ty * itz2}};
-    const double w = a.quats[4 * g], x = a.quats[4 * g + 1], y = a.quats[4 * g + 2], z = a.quats[4 * g + 3];
-    const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
-                           {2 * (x * y + w * z), 1 - 2 * (x * x - z * z), 2 * (y * z - w * x)},
-                           {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
-    const double e[3] = {exp((double)a.scales[3 * g]), exp((double)a.scales[3 * g + 1]), exp((double)a.scales[3 * g + 2])};
-    double Wm[3][3], Sg[3][3], A[2][3], ASg[2][3], cov[2][2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Wm[i][j] = R[i][j] * e[j];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Sg[i][j] = Wm[i][0] * Wm[j][0] + Wm[i][1] * Wm[j][1] + Wm[i][2] * Wm[j][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) A[i][j] = J[i][0] * R[0][j] + J[i][1] * R[1][j] + J[i][2] * R[2][j];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) ASg[i][j] = A[i][0] * Sg[0][j] + A[i][1] * Sg[1][j] + A[i][2] * Sg[2][j];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) cov[i][j] = ASg[i][0] * A[j][0] + ASg[i][1] * A[j][1] + ASg[i][2] * A[j][2] + 0.3;
-    const double idet = 1.0 / (cov[0][0] * cov[1][1] - cov[0][1] * cov[1][0]);
-    const double M[2][2] = {{cov[1][1] * idet, -cov[0][1] * idet}, {-cov[1][0] * idet, cov[0][0] * idet}};
-    const double ez = exp((double)a.opac[g]);
-    const double sg = ez / (1.0 + ez);
-    gs_g2d_to_grads(g2, sg, M[0][0], 0.5 * (M[0][1] + M[1][0]), M[1][1]);
-    const double gsig = g2[3], gmx = g2[4], gmy = g2[5];
-    const double G[2][2] = {{g2[6], g2[7]}, {g2[8], g2[9]}};           // G[r][c] = dL/dM[r][c]
-
-    // ---- M = cov^-1  =>  dcov = -M^T G M^T
-    double t1[2][2], dcov[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) t1[i][j] = M[0][i] * G[0][j] + M[1][i] * G[1][j];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dcov[i][j] = -(t1[i][0] * M[j][0] + t1[i][1] * M[j][1]);
-    // ---- cov = A Sg A^T (+0.3): dA = (dcov + dcov^T) A Sg ; dSg = A^T dcov A
-    const double off = dcov[0][1] + dcov[1][0];
-    const double ds2[2][2] = {{2 * dcov[0][0], off}, {off, 2 * dcov[1][1]}};
-    double dA[2][3], dSg[3][3], dJ[2][3], dR[3][3], dWm[3][3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dA[i][j] = ds2[i][0] * ASg[0][j] + ds2[i][1] * ASg[1][j];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            dSg[i][j] = A[0][i] * (dcov[0][0] * A[0][j] + dcov[0][1] * A[1][j]) + A[1][i] * (dcov[1][0] * A[0][j] + dcov[1][1] * A[1][j]);
-    // ---- A = J R
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dJ[i][j] = dA[i][0] * R[j][0] + dA[i][1] * R[j][1] + dA[i][2] * R[j][2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dR[i][j] = J[0][i] * dA[0][j] + J[1][i] * dA[1][j];
-    // ---- Sg = Wm Wm^T, Wm = R diag(e)
-    double de[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s += (dSg[i][k] + dSg[k][i]) * Wm[k][j];
-            dWm[i][j] = s;
-            dR[i][j] += s * e[j];
-            de[j] += R[i][j] * s;
-        }
-    // ---- R(q), with the reference's R22
-    double dw = 0, dx = 0, dy = 0, dz = 0;
-    dy += -4 * y * dR[0][0]; dz += -4 * z * dR[0][0];
-    dx += 2 * y * dR[1][0]; dy += 2 * x * dR[1][0]; dw += 2 * z * dR[1][0]; dz += 2 * w * dR[1][0];
-    dx += 2 * z * dR[2][0]; dz += 2 * x * dR[2][0]; dw += -2 * y * dR[2][0]; dy += -2 * w * dR[2][0];
-    dx += 2 * y * dR[0][1]; dy += 2 * x * dR[0][1]; dw += -2 * z * dR[0][1]; dz += -2 * w * dR[0][1];
-    dx += -4 * x * dR[1][1]; dz += 4 * z * dR[1][1];
-    dy += 2 * z * dR[2][1]; dz += 2 * y * dR[2][1]; dw += 2 * x * dR[2][1]; dx += 2 * w * dR[2][1];
-    dx += 2 * z * dR[0][2]; dz += 2 * x * dR[0][2]; dw += 2 * y * dR[0][2]; dy += 2 * w * dR[0][2];
-    dy += 2 * z * dR[1][2]; dz += 2 * y * dR[1][2]; dw += -2 * x * dR[1][2]; dx += -2 * w * dR[1][2];
-    dx += -4 * x * dR[2][2]; dy += -4 * y * dR[2][2];
-    // ---- J(t)
-    const double itz3 = itz2 * itz;
-    dt[0] += dJ[0][2] * (-fx * itz2);
-    dt[1] += dJ[1][2] * (-fy * itz2);
-    dt[2] += dJ[0][0] * (-fx * itz2) + dJ[1][1] * (-fy * itz2) + dJ[0][2] * (2 * fx * tx * itz3) + dJ[1][2] * (2 * fy * ty * itz3);
-    // ---- mu(p): mu = (W p0/p3 + 1)/2 + W/2
-    const double ip3 = 1.0 / p[3];
-    const double Wd = (double)cam.W, Hd = (double)cam.H;
-    dp[0] += gmx * 0.5 * Wd * ip3;
-    dp[1] += gmy * 0.5 * Hd * ip3;
-    dp[3] += -(gmx * 0.5 * Wd * p[0] + gmy * 0.5 * Hd * p[1]) * ip3 * ip3;
-    // ---- p = P t ; t = T [m;1]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dt[j] += P[i + 4 * j] * dp[i];
-    if (a.d_means) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float v = live ? (float)(T[4 * j] * dt[0] + T[1 + 4 * j] * dt[1] + T[2 + 4 * j] * dt[2] + T[3 + 4 * j] * dt[3]) : 0.0f;
-            if (OVERWRITE) a.d_means[3 * g + j] = v; else a.d_means[3 * g + j] = acc_or_step(a.d_means[3 * g + j], v, a.sgd_scale);
-        }
-    }
-    if (a.d_scales) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float v = live ? (float)(de[j] * e[j]) : 0.0f;
-            if (OVERWRITE) a.d_scales[3 * g + j] = v; else a.d_scales[3 * g + j] = acc_or_step(a.d_scales[3 * g + j], v, a.sgd_scale);
-        }
-    }
-    if (a.d_quats) {
-        float4 *q = reinterpret_cast<float4 *>(a.d_quats) + g;
-        float4 o = OVERWRITE ? make_float4(0.f, 0.f, 0.f, 0.f) : *q;
-        if (live) { o.x = acc_or_step(o.x, (float)dw, a.sgd_scale); o.y = acc_or_step(o.y, (float)dx, a.sgd_scale); o.z = acc_or_step(o.z, (float)dy, a.sgd_scale); o.w = acc_or_step(o.w, (float)dz, a.sgd_scale); }
-        *q = o;
-    }
-    if (a.d_opac) {
-        const float v = live ? (float)(gsig * sg * (1.0 - sg)) : 0.0f;
-        if (OVERWRITE) a.d_opac[g] = v; else a.d_opac[g] = acc_or_step(a.d_opac[g], v, a.sgd_scale);
-    }
+#define GS_GEOM_DPC (reinterpret_cast<const float4 *>(a.dpc)[g])
+    do {
+#include "gs_geom_bwd_body.inc"
+    } while (0);
+#undef GS_GEOM_DPC
 }
 
 // ---------------------------------------------------------------- colour-factored gradient exchange (multi-GPU)
@@ -434,8 +291,10 @@ hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera
     dim3 block(T), grid((unsigned)((a.n + T - 1) / T));
     const int K = (a.sh_degree + 1) * (a.sh_degree + 1);
     const size_t lds = sizeof(float) * T * (3 * K + 1);
-#define GS_SH(D) do { if (a.overwrite) hipLaunchKernelGGL((gs_sh_bwd_kernel<D, true>), grid, block, lds, s, a, cam); \
-                      else hipLaunchKernelGGL((gs_sh_bwd_kernel<D, false>), grid, block, lds, s, a, cam); } while (0)
+#define GS_SH2(D, F) do { if (a.overwrite) hipLaunchKernelGGL((gs_sh_bwd_kernel<D, true, F>), grid, block, lds, s, a, cam); \
+                         else hipLaunchKernelGGL((gs_sh_bwd_kernel<D, false, F>), grid, block, lds, s, a, cam); } while (0)
+#define GS_SH(D) do { if (fused) GS_SH2(D, true); else GS_SH2(D, false); } while (0)
+    const bool fused = (phases & 3) == 3;
     if (phases & 1)
     switch (a.sh_degree) {
         case 0: GS_SH(0); break;
@@ -445,7 +304,7 @@ hipError_t gs_launch_preprocess_bwd(const GsPreprocessBwdArgs &a, const GsCamera
         default: return hipErrorInvalidValue;
     }
     block = dim3(256); grid = dim3((unsigned)((a.n + 255) / 256));
-    if (phases & 2) {
+    if ((phases & 2) && !fused) {
         if (a.overwrite) hipLaunchKernelGGL(gs_geom_bwd_kernel<true>, grid, block, 0, s, a, cam);
         else hipLaunchKernelGGL(gs_geom_bwd_kernel<false>, grid, block, 0, s, a, cam);
     }
