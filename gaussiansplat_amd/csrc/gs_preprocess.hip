@@ -132,8 +132,11 @@ __global__ __launch_bounds__(256) void gs_sh_jacobian_kernel(GsPreprocessArgs a,
     store_sh_jacobian(a.shjac, g, J);
 }
 
+#ifndef GS_PRE_MINW
+#define GS_PRE_MINW 3                   // waves per SIMD the kernel is built for at least (degree 3 with the Jacobian: 131 VGPRs)
+#endif
 template <int DEG>
-__global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, GsCamera cam) {
+__global__ __launch_bounds__(256, GS_PRE_MINW) void gs_preprocess_kernel(GsPreprocessArgs a, GsCamera cam) {
     constexpr int K = (DEG + 1) * (DEG + 1);
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.n) return;
