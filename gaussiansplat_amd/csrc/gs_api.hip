@@ -101,7 +101,7 @@ int gs_destroy(gs_ctx *c) {
     comm_release(c);
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
-                      &c->counters, &c->grads_flat, &c->dpc, &c->shjac, &c->ids, &c->words, &c->cs, &c->diff,
+                      &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
                       &c->tile_work, &c->tile_clock,
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
                       &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->tilecnt,
@@ -273,10 +273,6 @@ int gs_preprocess(gs_ctx *c) {
     a.invcov = c->invcov.as<float>();
     a.depth_key = c->depth_key.as<uint32_t>();
     a.rect = c->rect.as<uint16_t>();
-    if (c->want_jac) {                                                      // gradients are wanted: d rgb / d dir while the SH row is in registers
-        HIPCHK(c, c->shjac.ensure(sizeof(float) * 12 * n1));
-        a.shjac = c->shjac.as<float>(); c->jac_frame = c->frame_id;
-    }
     c->range_valid = false;
     // the key range is folded only when this frame's depth sort can take the bucket path: while the classic sort runs (the 64-frame
     // fallback, N beyond the bucket path's limit) nothing would reset the accumulators and the atomics would be wasted

@@ -251,15 +251,6 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
     b.g2d = det ? nullptr : c->g2d.as<float>(); b.g2d_fixed = det ? c->g2d.as<long long>() : nullptr;
     HIPCHK(c, c->dpc.ensure(sizeof(float) * 4 * n1));
     b.dpc = c->dpc.as<float>();
-    if (c->jac_frame != c->frame_id) {                                      // the ctx's first backward (its preprocess did not know): the same
-        GsPreprocessArgs ja{};                                              // Jacobians, bit for bit, from a kernel of their own
-        ja.n = c->n; ja.sh_degree = c->sh_degree; ja.means = c->means; ja.shs = c->shs;
-        HIPCHK(c, c->shjac.ensure(sizeof(float) * 12 * n1));
-        ja.shjac = c->shjac.as<float>();
-        HIPCHK(c, gs_launch_sh_jacobian(ja, c->cam, c->stream));
-        c->jac_frame = c->frame_id; c->want_jac = true;
-    }
-    b.shjac = c->shjac.as<float>();
     b.overwrite = (flags & GS_BWD_OVERWRITE) ? 1 : 0;
     b.sgd_scale = sgd_scale;
     b.d_means = grads->d_means; b.d_scales = grads->d_scales; b.d_quats = grads->d_quats;

@@ -64,8 +64,6 @@ struct GsPreprocessArgs {
     uint32_t *depth_key;
     uint16_t *rect;       // 4 x n : x0 x1 y0 y1 (1-based inclusive, x0 == 0 -> no tile)
     GsDebugArrays dbg;
-    float *shjac;         // may be null: 12 x n, d rgb / d (view direction) as three 16-byte rows per gaussian (gs_preprocess.hip:
-                          // sh_jacobian_row) -- written once the ctx has seen a backward, read by gs_sh_bwd_kernel
     uint32_t *key_range;  // may be null: 64 minima + 64 maxima of the depth keys, GS_KEY_RANGE_STRIDE words apart (every wave folds its
                           // extremes into slot blockIdx % 64): the key range the two-step depth sort cuts into buckets (gs_sort.hip)
 };
@@ -73,8 +71,6 @@ struct GsPreprocessArgs {
 #define GS_KEY_RANGE_STRIDE 64
 // launchers (each enqueues on `stream`, returns hipGetLastError())
 hipError_t gs_launch_preprocess(const GsPreprocessArgs &a, const GsCamera &cam, hipStream_t stream);
-// a.shjac alone, bit for bit what gs_launch_preprocess writes there (reads a.means, a.shs)
-hipError_t gs_launch_sh_jacobian(const GsPreprocessArgs &a, const GsCamera &cam, hipStream_t stream);
 
 // 2-D image-fitting renderer (gs_preprocess2d.hip): SplatData2D, reference src/splat.jl:20-26
 struct GsPreprocess2DArgs {
@@ -312,7 +308,6 @@ struct GsPreprocessBwdArgs {
     int64_t n;
     int sh_degree;
     const float *means, *scales, *quats, *opac, *shs;
-    const float *shjac;           // 12 x n: d rgb / d (view direction) of this frame (GsPreprocessArgs.shjac)
     const float *g2d;
     const long long *g2d_fixed;   // non-null: read the 2-D gradients from the fixed-point buffer
     float *d_means, *d_scales, *d_quats, *d_opac, *d_shs;   // accumulate (+=) or overwrite; may be null

@@ -152,9 +152,6 @@ struct gs_ctx {
     int64_t ev_counted[GS_STAGE_COUNT] = {};               // last frame whose pair of this stage was added to ev_cnt
     DevBuf grads_flat;                       // gs_grads_alloc
     DevBuf dpc;                              // 4 x n scratch between the two backward kernels
-    DevBuf shjac;                            // 12 x n: d rgb / d (view direction) of the frame (GsPreprocessArgs.shjac)
-    bool want_jac = false;                   // the ctx has run a backward: gs_preprocess writes shjac from now on
-    int64_t jac_frame = -1;                  // frame_id whose Jacobians shjac holds
     DevBuf loss_maps, loss_acc, loss_in[2], loss_dc, view_cams;
     ncclComm_t comm = nullptr;
     int comm_ranks = 0;

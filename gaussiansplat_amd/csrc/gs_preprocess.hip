@@ -35,64 +35,16 @@ __device__ __forceinline__ uint32_t gs_pack_i16(float lo, float hi) {
     return ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16);
 }
 
-// sh2color (splat.jl:180-193) and, when gradients are wanted, d rgb_c / d dir_j (dir = the unit view direction): every coefficient
-// is loaded once and feeds its channel's colour sum -- in the reference's order, s = s + sh[c + 3 k] * bs[k], k ascending -- and the
-// three Jacobian sums J[c][j] = sum_k sh[c + 3 k] * d basis_k / d dir_j.  The backward needs sum_c dL/drgb_c J[c][j] (the colour's share
-// of dL/d position); written here, while the SH row passes through registers, it saves gs_sh_bwd_kernel the second read of the row
-// (192 of its 476 bytes per gaussian at degree 3).
-template <bool JAC, bool HX, bool HY, bool HZ>
-__device__ __forceinline__ void sh_term(const float *sh, const int k, const float b, const float dx, const float dy, const float dz,
-                                        float (&s)[3], float (&J)[3][3]) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v = sh[c + 3 * k];
-        s[c] = s[c] + v * b;
-        if (JAC) {
-            if (HX) J[c][0] = J[c][0] + v * dx;
-            if (HY) J[c][1] = J[c][1] + v * dy;
-            if (HZ) J[c][2] = J[c][2] + v * dz;
-        }
-    }
-}
-template <int DEG, bool JAC>
-__device__ __forceinline__ void sh_color(const float x, const float y, const float z, const float *sh, float (&s)[3], float (&J)[3][3]) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { s[c] = sh[c] * SH_C0; J[c][0] = J[c][1] = J[c][2] = 0.0f; }
-    if constexpr (DEG >= 1) {
-        sh_term<JAC, false, true, false>(sh, 1, -y * SH_C1, 0.0f, -SH_C1, 0.0f, s, J);
-        sh_term<JAC, false, false, true>(sh, 2, z * SH_C1, 0.0f, 0.0f, SH_C1, s, J);
-        sh_term<JAC, true, false, false>(sh, 3, -x * SH_C1, -SH_C1, 0.0f, 0.0f, s, J);
-    }
-    if constexpr (DEG >= 2) {
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        sh_term<JAC, true, true, false>(sh, 4, kC2[0] * xy, kC2[0] * y, kC2[0] * x, 0.0f, s, J);
-        sh_term<JAC, false, true, true>(sh, 5, kC2[1] * yz, 0.0f, kC2[1] * z, kC2[1] * y, s, J);
-        sh_term<JAC, true, true, true>(sh, 6, kC2[2] * ((2.0f * zz - xx) - yy), -2.0f * kC2[2] * x, -2.0f * kC2[2] * y, 4.0f * kC2[2] * z, s, J);
-        sh_term<JAC, true, false, true>(sh, 7, kC2[3] * xz, kC2[3] * z, 0.0f, kC2[3] * x, s, J);
-        sh_term<JAC, true, true, false>(sh, 8, kC2[4] * (xx - yy), 2.0f * kC2[4] * x, -2.0f * kC2[4] * y, 0.0f, s, J);
-        if constexpr (DEG >= 3) {
-            sh_term<JAC, true, true, false>(sh, 9, (kC3[0] * y) * (3.0f * xx - yy), 6.0f * kC3[0] * xy, kC3[0] * (3.0f * xx - 3.0f * yy), 0.0f, s, J);
-            sh_term<JAC, true, true, true>(sh, 10, (kC3[1] * xy) * z, kC3[1] * yz, kC3[1] * xz, kC3[1] * xy, s, J);
-            sh_term<JAC, true, true, true>(sh, 11, (kC3[2] * y) * ((4.0f * zz - xx) - yy), -2.0f * kC3[2] * xy, kC3[2] * (4.0f * zz - xx - 3.0f * yy),
-                                           8.0f * kC3[2] * yz, s, J);
-            sh_term<JAC, true, true, true>(sh, 12, (kC3[3] * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy), -6.0f * kC3[3] * xz, -6.0f * kC3[3] * yz,
-                                           kC3[3] * (6.0f * zz - 3.0f * xx - 3.0f * yy), s, J);
-            sh_term<JAC, true, true, true>(sh, 13, (kC3[4] * x) * ((4.0f * zz - xx) - yy), kC3[4] * (4.0f * zz - 3.0f * xx - yy), -2.0f * kC3[4] * xy,
-                                           8.0f * kC3[4] * xz, s, J);
-            sh_term<JAC, true, true, true>(sh, 14, (kC3[5] * z) * (xx - yy), 2.0f * kC3[5] * xz, -2.0f * kC3[5] * yz, kC3[5] * (xx - yy), s, J);
-            sh_term<JAC, true, true, false>(sh, 15, (kC3[6] * x) * (xx - 3.0f * yy), kC3[6] * (3.0f * xx - 3.0f * yy), -6.0f * kC3[6] * xy, 0.0f, s, J);
-        }
-    }
-}
-// the three rows of a gaussian, 16 bytes each: shjac[12 g + 4 c + j]
-__device__ __forceinline__ void store_sh_jacobian(float *shjac, int64_t g, const float (&J)[3][3]) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) reinterpret_cast<float4 *>(shjac)[3 * g + c] = make_float4(J[c][0], J[c][1], J[c][2], 0.0f);
-}
-// the clip-space position of a mean (frustumCulling, projection.jl:46-93) and the unit view direction of sh2color (splat.jl:180-189):
-// ONE copy of the statements, for gs_preprocess_kernel and for gs_sh_jacobian_kernel, which must produce the same bits
-__device__ __forceinline__ void project_mean(const GsCamera &cam, const float m1, const float m2, const float m3, float (&ts)[4], float (&tps)[4]) {
+template <int DEG>
+__global__ __launch_bounds__(256) void gs_preprocess_kernel(GsPreprocessArgs a, GsCamera cam) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n) return;
     const float *T = cam.T, *P = cam.P;
+
+    // ---- frustumCulling, projection.jl:46-93
+    const float m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
+    float ts[4], tps[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float s = T[i] * m1;
@@ -109,54 +61,6 @@ __device__ __forceinline__ void project_mean(const GsCamera &cam, const float m1
         s = s + P[i + 12] * ts[3];
         tps[i] = s;
     }
-}
-__device__ __forceinline__ void view_direction(const GsCamera &cam, const float (&tps)[4], float &x, float &y, float &z) {
-    const float d0 = tps[0] - (cam.lookAt[0] - cam.eye[0]);
-    const float d1 = tps[1] - (cam.lookAt[1] - cam.eye[1]);
-    const float d2 = tps[2] - (cam.lookAt[2] - cam.eye[2]);
-    const float nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
-    const float ninv = 1.0f / nrm;
-    x = ninv * d0; y = ninv * d1; z = ninv * d2;
-}
-// The Jacobians alone: the first backward of a ctx, whose preprocess did not know yet that gradients are wanted (later ones write them)
-template <int DEG>
-__global__ __launch_bounds__(256) void gs_sh_jacobian_kernel(GsPreprocessArgs a, GsCamera cam) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n) return;
-    float ts[4], tps[4], x, y, z;
-    project_mean(cam, a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2], ts, tps);
-    view_direction(cam, tps, x, y, z);
-    constexpr int K = (DEG + 1) * (DEG + 1);
-    float sc[3], J[3][3];
-    sh_color<DEG, true>(x, y, z, a.shs + (int64_t)3 * K * g, sc, J);
-    store_sh_jacobian(a.shjac, g, J);
-}
-
-#ifndef GS_PRE_MINW
-#define GS_PRE_MINW 3                   // waves per SIMD the kernel is built for at least (degree 3 with the Jacobian: 131 VGPRs)
-#endif
-template <int DEG>
-__global__ __launch_bounds__(256, GS_PRE_MINW) void gs_preprocess_kernel(GsPreprocessArgs a, GsCamera cam) {
-    constexpr int K = (DEG + 1) * (DEG + 1);
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n) return;
-    // ---- frustumCulling, projection.jl:46-93
-    const float m1 = a.means[3 * g], m2 = a.means[3 * g + 1], m3 = a.means[3 * g + 2];
-    float ts[4], tps[4];
-    project_mean(cam, m1, m2, m3, ts, tps);
-
-    // ---- sh2color, splat.jl:180-193 (degrees 2,3: build extension, same accumulation order).  First: the SH row (48 registers at
-    // degree 3) is dead before the covariance chain starts
-    float x, y, z;
-    view_direction(cam, tps, x, y, z);
-    const float *sh = a.shs + (int64_t)3 * K * g;
-    float sc[3], Jc[3][3], rgb[3];
-    if (a.shjac) {                                                       // gradients are wanted (GsPreprocessArgs.shjac): same colour sums
-        sh_color<DEG, true>(x, y, z, sh, sc, Jc);
-        store_sh_jacobian(a.shjac, g, Jc);
-    } else sh_color<DEG, false>(x, y, z, sh, sc, Jc);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rgb[c] = (float)((double)sc[c] + 0.5);    // :192
     const double cx = cam.W / 2.0, cy = cam.H / 2.0;                  // forward.jl:58-59 (Float64)
     const float wf = (float)cam.W, hf = (float)cam.H;
     const float mux = (float)((double)((wf * tps[0] / tps[3] + 1.0f) / 2.0f) + cx);   // projection.jl:88
@@ -250,6 +154,42 @@ __global__ __launch_bounds__(256, GS_PRE_MINW) void gs_preprocess_kernel(GsPrepr
     const float bymin = (float)gs_jlmax(1.0, floor(-r + (double)muy));
     const float bymax = (float)gs_jlmin((double)cam.H, ceil(r + (double)muy));
 
+    // ---- sh2color, splat.jl:180-193 (degrees 2,3: build extension, same accumulation order)
+    const float d0 = tps[0] - (cam.lookAt[0] - cam.eye[0]);
+    const float d1 = tps[1] - (cam.lookAt[1] - cam.eye[1]);
+    const float d2 = tps[2] - (cam.lookAt[2] - cam.eye[2]);
+    const float nrm = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+    const float ninv = 1.0f / nrm;
+    const float x = ninv * d0, y = ninv * d1, z = ninv * d2;
+    float bs[K];
+    bs[0] = SH_C0;
+    if constexpr (DEG >= 1) { bs[1] = -y * SH_C1; bs[2] = z * SH_C1; bs[3] = -x * SH_C1; }
+    if constexpr (DEG >= 2) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        bs[4] = kC2[0] * xy;
+        bs[5] = kC2[1] * yz;
+        bs[6] = kC2[2] * ((2.0f * zz - xx) - yy);
+        bs[7] = kC2[3] * xz;
+        bs[8] = kC2[4] * (xx - yy);
+        if constexpr (DEG >= 3) {
+            bs[9]  = (kC3[0] * y) * (3.0f * xx - yy);
+            bs[10] = (kC3[1] * xy) * z;
+            bs[11] = (kC3[2] * y) * ((4.0f * zz - xx) - yy);
+            bs[12] = (kC3[3] * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy);
+            bs[13] = (kC3[4] * x) * ((4.0f * zz - xx) - yy);
+            bs[14] = (kC3[5] * z) * (xx - yy);
+            bs[15] = (kC3[6] * x) * (xx - 3.0f * yy);
+        }
+    }
+    const float *sh = a.shs + (int64_t)3 * K * g;
+    float rgb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = sh[c] * bs[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) s = s + sh[c + 3 * k] * bs[k];
+        rgb[c] = (float)((double)s + 0.5);                            // :192
+    }
     // ---- cusigmoid, splat.jl:175-178
     const float ez = gs_expf(a.opac[g]);
     float sg = ez / (1.0f + ez);
@@ -325,20 +265,6 @@ __global__ __launch_bounds__(256, GS_PRE_MINW) void gs_preprocess_kernel(GsPrepr
         a.dbg.invcov[4 * g] = inv0; a.dbg.invcov[4 * g + 1] = inv1; a.dbg.invcov[4 * g + 2] = inv2; a.dbg.invcov[4 * g + 3] = inv3;
         a.dbg.bbs[4 * g] = bxmin; a.dbg.bbs[4 * g + 1] = bymin; a.dbg.bbs[4 * g + 2] = bxmax; a.dbg.bbs[4 * g + 3] = bymax;
     }
-}
-
-hipError_t gs_launch_sh_jacobian(const GsPreprocessArgs &a, const GsCamera &cam, hipStream_t stream) {
-    if (a.n <= 0) return hipSuccess;
-    if (!a.shjac) return hipErrorInvalidValue;
-    const dim3 block(256), grid((unsigned)((a.n + 255) / 256));
-    switch (a.sh_degree) {
-        case 0: hipLaunchKernelGGL(gs_sh_jacobian_kernel<0>, grid, block, 0, stream, a, cam); break;
-        case 1: hipLaunchKernelGGL(gs_sh_jacobian_kernel<1>, grid, block, 0, stream, a, cam); break;
-        case 2: hipLaunchKernelGGL(gs_sh_jacobian_kernel<2>, grid, block, 0, stream, a, cam); break;
-        case 3: hipLaunchKernelGGL(gs_sh_jacobian_kernel<3>, grid, block, 0, stream, a, cam); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
 }
 
 hipError_t gs_launch_preprocess(const GsPreprocessArgs &a, const GsCamera &cam, hipStream_t stream) {

@@ -13,9 +13,8 @@
 //   gs_sh_bwd_kernel    d rgb -> d shs, plus d rgb / d(clip position) handed to the second kernel
 //                       (16 B/gaussian).  The SH gradients (3K floats = 192 B at degree 3, thread-strided in
 //                       HBM) go through an LDS tile [256][3K+1]: conflict-free per-thread rows (odd stride),
-//                       stored/added to d_shs with coalesced accesses.  The SH coefficients themselves are not
-//                       read: the colour's dependence on the view direction comes as the 3 x 3 Jacobian the
-//                       frame's preprocess wrote (GsPreprocessArgs.shjac, 48 B/gaussian).
+//                       stored/added to d_shs with coalesced accesses.  The SH coefficients are read only for
+//                       gaussians a pixel touched, by their own thread (the colour's dependence on the view direction).
 //   gs_geom_bwd_kernel  d{mu', invCov2d, sig} -> d{means, scales, quaternions, opacities}.  The chain (3x3 / 2x3 / 2x2
 //                       products, the 2x2 inverse and the quaternion terms) is evaluated in fp64 from the fp32 inputs:
 //                       in fp32 its cancellations put the quaternion gradient at 2e-4 .. 2e-3 relative L2 of the fp64
@@ -124,15 +123,40 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
 #pragma unroll
             for (int c = 0; c < 3; ++c) sh[c + 3 * k] = bs[k] * grgb[c];   // the tile carries d L / d sh (stored coalesced below)
         }
-        // d L / d dir through the colour: sum_c d rgb_c * (d rgb_c / d dir), the Jacobian the frame's preprocess wrote while it had
-        // the SH row in registers (gs_preprocess.hip: sh_jacobian_row) -- this kernel used to read the 3K coefficients a second time
         float ddir[3] = {0.0f, 0.0f, 0.0f};
         if (live) {
-            const float4 *Jp = reinterpret_cast<const float4 *>(a.shjac) + 3 * g;
-            const float4 J0 = Jp[0], J1 = Jp[1], J2 = Jp[2];
-            ddir[0] = grgb[0] * J0.x + grgb[1] * J1.x + grgb[2] * J2.x;
-            ddir[1] = grgb[0] * J0.y + grgb[1] * J1.y + grgb[2] * J2.y;
-            ddir[2] = grgb[0] * J0.z + grgb[1] * J1.z + grgb[2] * J2.z;
+            // d L / d dir through the colour needs the coefficients: those of THIS gaussian, read by its own thread as twelve 16-byte
+            // loads, and only if a pixel touched it (37 % of the gaussians at C3, 10 % at C5) -- cs[k] = d rgb . sh[:, k], then the
+            // derivative polynomials of the basis.  (Until round 4 every row came in through the LDS tile, touched or not: 192 of the
+            // kernel's 476 bytes per gaussian.  A 3 x 3 Jacobian d rgb / d dir written by the preprocess instead was measured too: the
+            // backward 10 us faster than this, the preprocess 30 us slower -- 131 VGPRs, three waves per SIMD; profiles/r04s_ab_lazy_sh.log.)
+            const float4 *row = reinterpret_cast<const float4 *>(a.shs + (int64_t)3 * K * g);
+            float shv[3 * K];
+            if constexpr ((3 * K) % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < 3 * K / 4; ++q) { const float4 t4 = row[q]; shv[4 * q] = t4.x; shv[4 * q + 1] = t4.y; shv[4 * q + 2] = t4.z; shv[4 * q + 3] = t4.w; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3 * K; ++q) shv[q] = a.shs[(int64_t)3 * K * g + q];
+            }
+            float cs[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) cs[k] = grgb[0] * shv[3 * k] + grgb[1] * shv[3 * k + 1] + grgb[2] * shv[3 * k + 2];
+            if constexpr (DEG >= 1) { ddir[0] += -SH_C1 * cs[3]; ddir[1] += -SH_C1 * cs[1]; ddir[2] += SH_C1 * cs[2]; }
+            if constexpr (DEG >= 2) {
+                ddir[0] += bC2[0] * Y * cs[4] - 2 * bC2[2] * X * cs[6] + bC2[3] * Z * cs[7] + 2 * bC2[4] * X * cs[8];
+                ddir[1] += bC2[0] * X * cs[4] + bC2[1] * Z * cs[5] - 2 * bC2[2] * Y * cs[6] - 2 * bC2[4] * Y * cs[8];
+                ddir[2] += bC2[1] * Y * cs[5] + 4 * bC2[2] * Z * cs[6] + bC2[3] * X * cs[7];
+            }
+            if constexpr (DEG >= 3) {
+                const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+                ddir[0] += 6 * bC3[0] * xy * cs[9] + bC3[1] * yz * cs[10] - 2 * bC3[2] * xy * cs[11] - 6 * bC3[3] * xz * cs[12]
+                           + bC3[4] * (4 * zz - 3 * xx - yy) * cs[13] + 2 * bC3[5] * xz * cs[14] + bC3[6] * (3 * xx - 3 * yy) * cs[15];
+                ddir[1] += bC3[0] * (3 * xx - 3 * yy) * cs[9] + bC3[1] * xz * cs[10] + bC3[2] * (4 * zz - xx - 3 * yy) * cs[11]
+                           - 6 * bC3[3] * yz * cs[12] - 2 * bC3[4] * xy * cs[13] - 2 * bC3[5] * yz * cs[14] - 6 * bC3[6] * xy * cs[15];
+                ddir[2] += bC3[1] * xy * cs[10] + 8 * bC3[2] * yz * cs[11] + bC3[3] * (6 * zz - 3 * xx - 3 * yy) * cs[12]
+                           + 8 * bC3[4] * xz * cs[13] + bC3[5] * (xx - yy) * cs[14];
+            }
         }
         const float dd = X * ddir[0] + Y * ddir[1] + Z * ddir[2];
         // d L / d tps[1:3] through the colour (dir = normalize(tps[1:3] - (lookAt - eye)))
