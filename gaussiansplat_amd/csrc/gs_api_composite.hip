@@ -215,6 +215,8 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         // zero fill of the gradient rows (64 B per gaussian), in line: on a side stream beside the forward composite it cost more than
         // it hid (C3, same box, interleaved: 1.433 ms with the fill beside the forward, 1.412 ms in line -- its workgroups take wave slots
         // from the forward's tiles, and the two event hand-shakes per frame delay the depth sort's launches)
+        // (a fill with streaming stores, which would spare the caches 64 B per gaussian, was measured: the atomics of the composite backward then
+        // find their rows in memory instead of the cache, C3 + 1 %; profiles/r04t_ab_nontemporal.log)
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
         // launch order: the one the frame's forward used, or (no history) what the order kernel made of that forward
         if (lpt_schedule(c)) { a.tile_order = c->frame_order; a.order_len = c->frame_order ? gs_lpt_order_len(c->gx, c->gy) : 0; }

@@ -26,6 +26,9 @@
 #include "gs_common.h"
 #include <stdlib.h>
 
+#ifndef GS_NT_STORES
+#define GS_NT_STORES 2               // overwrite-mode gradient stores bypass the caches: 1 the SH gradients, 2 the geometry chain's too (0: A/B builds)
+#endif
 #define SH_C0 0.28209479177387814f
 #define SH_C1 0.48860251190291990f
 __constant__ float bC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
@@ -184,7 +187,15 @@ __global__ __launch_bounds__(256) void gs_sh_bwd_kernel(GsPreprocessBwdArgs a, G
                     if (a.sgd_scale != 0.0f) { v.x = fmaf(a.sgd_scale, v.x, o.x); v.y = fmaf(a.sgd_scale, v.y, o.y); v.z = fmaf(a.sgd_scale, v.z, o.z); v.w = fmaf(a.sgd_scale, v.w, o.w); }
                     else { v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
                 }
-                dst[i4] = v;
+                if (OVERWRITE && GS_NT_STORES) {
+                    // streamed past the caches: 192 B per gaussian that nothing on the GPU reads again this frame.  Stored normally they
+                    // pushed the model's SH rows out of the 256 MB infinity cache, and the next frame's preprocess fetched them from
+                    // HBM again (C3: preprocess 86 -> 73 us, same box, profiles/r04t_ab_nontemporal.log).  (Accumulating views read the
+                    // rows back: cached stores.)
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f vv = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<v4f *>(dst) + i4);
+                } else dst[i4] = v;
             }
         } else {
             for (int idx = threadIdx.x; idx < nb * 3 * K; idx += blockDim.x) {
