@@ -60,6 +60,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (c0.depth_sort < 0 || c0.depth_sort > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: depth_sort must be 0, 1 or 2");
     if (c0.list_cap < 0 || c0.list_cap > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: list_cap must be 0, 1 or 2");
     if (c0.tile_parts != 0 && c0.tile_parts != 1 && c0.tile_parts != 2 && c0.tile_parts != 4) return fail(nullptr, GS_ERR_INVALID, "gs_create: tile_parts must be 0, 1, 2 or 4");
+    if (c0.sched_rounds < 0 || c0.sched_rounds > GS_LPT_MAX_ROUNDS) return fail(nullptr, GS_ERR_INVALID, "gs_create: sched_rounds must be 0 .. 16");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -73,6 +74,11 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipSetDevice"); }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipStreamCreate"); }
     c->own_stream = true;
+    {   // wave slots of the composite kernels (their __launch_bounds__ ask for five waves per SIMD): what "the grid fills the chip" means
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->wave_slots = prop.multiProcessorCount * 4 * 5;
+        else (void)hipGetLastError();
+    }
     if ((e = hipHostMalloc((void **)&c->pinned, 512, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return hipfail(nullptr, e, "hipHostMalloc"); }
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
         for (int k = 0; k < 2; ++k)

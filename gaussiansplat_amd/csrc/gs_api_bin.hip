@@ -135,7 +135,7 @@ static int list_cap_source(gs_ctx *c, int rounds, const uint32_t **out) {
     }
     // Engages where it pays (measured, profiles/r04b_kernel_stats_*): the write pass is bound by its entries only when most of them
     // are never walked -- C5 (6 % walked): 591 -> 129 us; at C3 (28 % walked) the pass goes 45 -> 37 us and the cap pass costs that.
-    if (c->cfg.list_cap != 2 && (ntiles <= 5120 || !(c->walked_ratio >= 0.0 && c->walked_ratio < GS_LIST_CAP_MAX_RATIO))) return GS_OK;
+    if (c->cfg.list_cap != 2 && (ntiles <= c->wave_slots || !(c->walked_ratio >= 0.0 && c->walked_ratio < GS_LIST_CAP_MAX_RATIO))) return GS_OK;
     const int k = order_index(c);
     if (k == GS_MAX_VIEW_SLOTS && c->cfg.schedule != 4) return GS_OK;          // frames without a slot: history only under schedule 4
     if (c->slots[k].walked_grid != grid || !c->slots[k].walked.p) return GS_OK;

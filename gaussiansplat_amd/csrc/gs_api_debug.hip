@@ -175,7 +175,22 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     // variant tens digit (gs_composite.hip: apply_sched_variant): 0 the frame's own launch order (what production uses for the
     // backward and for the next forward of the slot), 1 tile order, 3 = 0 explicitly
     a.tile_order = lpt_schedule(c) ? c->frame_order : nullptr;
-    a.order_len = a.tile_order ? gs_lpt_order_len(c->gx, c->gy) : 0;
+    a.rounds = a.tile_order ? c->frame_rounds : 1;
+    a.order_len = a.tile_order ? gs_lpt_order_len(c->gx, c->gy, a.rounds) : 0;
+    a.parts = c->frame_parts;                                                // as the frame's own launches
+    if (c->dbg_win_len > 0) {                                                // gs_debug_set_window: a slice of the launch order
+        if (!a.tile_order || a.parts > 1 || a.rounds > 1)
+            return fail(c, GS_ERR_INVALID, "gs_debug_set_window: the frame has no one-tile-per-wave launch order (several waves per tile, or a static schedule: gs_config.sched_rounds = 1)");
+        if (c->dbg_win_start + c->dbg_win_len > a.order_len) return fail(c, GS_ERR_INVALID, "gs_debug_set_window: beyond the launch order");
+        a.tile_order += c->dbg_win_start; a.order_len = c->dbg_win_len;
+    }
+    return GS_OK;
+}
+
+int gs_debug_set_window(gs_ctx *c, int32_t start, int32_t len) {
+    if (!c) return GS_ERR_INVALID;
+    if (start < 0 || len < 0 || (start & 7) || (len & 7)) return fail(c, GS_ERR_INVALID, "gs_debug_set_window: start and len must be non-negative multiples of 8");
+    c->dbg_win_start = start; c->dbg_win_len = len;
     return GS_OK;
 }
 
@@ -281,6 +296,12 @@ int gs_get_tile_parts(gs_ctx *c) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_tile_parts: gs_forward first");
     return c->frame_parts;
+}
+
+int gs_get_sched_rounds(gs_ctx *c) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_sched_rounds: gs_forward first");
+    return c->frame_order ? c->frame_rounds : 1;
 }
 
 int gs_get_work_counters_ex(gs_ctx *c, int64_t out[4]) {

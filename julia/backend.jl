@@ -6,9 +6,19 @@
 # `pointer(A)` is passed unpermuted: means 3xN, scales 3xN, quaternions 4xN, opacities 1xN,
 # shs (3K)xN, image WxHx3, T/P 4x4.
 #
-# A maintainer adds `include("backend.jl")` to src/GaussianSplat.jl and replaces the CUDA.jl bodies
-# of preprocess / compactIdxs / forward / backward (src/forward.jl:35-198, src/backward.jl:3-38)
-# by the `hip_*` functions below.
+# A maintainer copies this file over the reference's empty src/backend.jl and adds ONE line, `include("backend.jl")`, at the
+# end of src/GaussianSplat.jl (after `include("projection.jl")`, i.e. after renderer.jl has pulled in splat.jl, forward.jl and
+# backward.jl).  The second half of this file then defines METHODS WITH THE REFERENCE'S OWN SIGNATURES on the reference's own types
+#   getRenderer(Val(GAUSSIAN_3D), path | nGaussians, imgSize, threads, blocks)      src/renderer.jl:119-186
+#   preprocess(renderer::GaussianRenderer3D)                                        src/forward.jl:35
+#   compactIdxs(renderer::GaussianRenderer3D, threads, blocks)                      src/forward.jl:118
+#   forward(renderer::GaussianRenderer3D, tps, threads, blocks)                     src/forward.jl:163
+#   backward(renderer::GaussianRenderer3D, ΔC)                                      src/backward.jl:3
+#   resetGrads(grads::SplatGrads3D)                                                 src/splat.jl:158-173
+# which replace the CUDA.jl bodies (later definitions of the same signature win), so src/examples/main.jl:14-34 runs unchanged:
+# the renderer's fields are host `Array`s (there is no CUDA.jl on this target) written in place, and the HipRenderer that holds the
+# resident model lives in a side table keyed by the renderer object.  The `hip_*` functions of module HipBackend remain the
+# explicit, allocation-free interface (device pointers, view slots, fused SGD, multi-GPU).
 
 module HipBackend
 
@@ -40,7 +50,8 @@ mutable struct GsConfig                      # must mirror gs_config (96 bytes)
     depth_sort::Int32
     list_cap::Int32                          # capped tile lists: 0 automatic, 1 never, 2 also on small grids
     tile_parts::Int32                        # waves per tile on small grids: 0 automatic, 1, 2, 4
-    reserved::NTuple{3, Int32}
+    sched_rounds::Int32                      # tiles per wave of the static schedule: 0 automatic, 1 never, 2 .. 16
+    reserved::NTuple{2, Int32}
 end
 
 struct GsGrads                               # gs_grads: device pointers, may be C_NULL
@@ -66,7 +77,7 @@ function check(r::HipRenderer, rc::Cint)
 end
 
 function defaultConfig()
-    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, 0, 0, 0, ntuple(_ -> Int32(0), 3))
+    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, 0, 0, 0, 0, ntuple(_ -> Int32(0), 2))
     ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
     # a library built from another header would read this struct with shifted fields: refuse it here, loudly
     (hip_abiVersion() == GS_ABI_VERSION && cfg.abi_version == GS_ABI_VERSION && cfg.struct_size == sizeof(GsConfig)) ||
@@ -240,6 +251,9 @@ end
 # waves per tile (1, 2, 4) of the last frame's composite launches (GsConfig.tile_parts)
 hip_tileParts(r::HipRenderer) = ccall((:gs_get_tile_parts, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 
+# tiles per wave of the last frame's composite launches (GsConfig.sched_rounds; 1 = one tile per wave)
+hip_schedRounds(r::HipRenderer) = ccall((:gs_get_sched_rounds, libgs), Cint, (Ptr{Cvoid},), r.ctx)
+
 # renderer scratch arrays (gs_array ids of include/gsplat.h; e.g. 11 = sortIdxs, 12 = tile ranges, 13 = sorted ids) into a host array
 function hip_getArray!(r::HipRenderer, which::Integer, dst::Array)
     check(r, ccall((:gs_get_array, libgs), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), r.ctx, which, dst, sizeof(dst)))
@@ -285,4 +299,140 @@ end
 
 hip_rankProbeResult(r::HipRenderer) = ccall((:gs_rank_probe_result, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 
+# profiling: the debug launches cover only order[start+1 : start+len] of the frame's launch order (0, 0: all of it)
+hip_debugSetWindow(r::HipRenderer, start::Integer, len::Integer) =
+    check(r, ccall((:gs_debug_set_window, libgs), Cint, (Ptr{Cvoid}, Int32, Int32), r.ctx, start, len))
+
 end # module
+
+# ======================================================================================================================
+# The reference's own API on the reference's own types (see the header of this file).  Only defined when this file is
+# included where those types exist, i.e. at the end of src/GaussianSplat.jl.
+# ======================================================================================================================
+if @isdefined(GaussianRenderer3D)
+
+using .HipBackend: HipRenderer, GsGrads, hip_getRenderer, hip_preprocess, hip_compactIdxs, hip_forward!, hip_initGrads,
+                   hip_readGrads!, hip_resetGrads!, hip_getArray!, defaultConfig
+
+# state the reference keeps in CuArrays hung off the renderer: here one HipRenderer (resident model, scratch, gradient buffer) per
+# reference renderer, dropped with it (weak keys; HipRenderer's finalizer calls gs_destroy)
+mutable struct HipSide
+    hr::HipRenderer
+    grads::Union{Nothing, GsGrads}
+    uploaded::Bool
+end
+const HIP_SIDE = WeakKeyDict{Any, HipSide}()
+# The reference uploads the model on every call (`|> CuArray`, src/forward.jl:63-69,169-170), so host-side edits of
+# renderer.splatData between frames (src/train.jl:42-46) are always seen.  true keeps that; false uploads once and relies on
+# hipModelChanged!(renderer) after an edit.
+const HIP_REUPLOAD_EVERY_FRAME = Ref(true)
+# true: preprocess / compactIdxs also fill the reference's scratch fields (positions, cov2ds, cov3ds, invCov2ds, bbs, sortIdxs)
+# and return the real tps (gs_config.export_debug: 124 more bytes per gaussian written per frame)
+const HIP_EXPORT_SCRATCH = Ref(false)
+
+hipModelChanged!(renderer::GaussianRenderer3D) = (haskey(HIP_SIDE, renderer) && (HIP_SIDE[renderer].uploaded = false); nothing)
+
+function hipSide(renderer::GaussianRenderer3D)
+    get!(HIP_SIDE, renderer) do
+        d = renderer.splatData
+        cfg = defaultConfig()
+        cfg.export_debug = HIP_EXPORT_SCRATCH[] ? 1 : 0
+        hr = hip_getRenderer(Matrix{Float32}(d.means), Matrix{Float32}(d.scales), Matrix{Float32}(d.quaternions),
+                             Matrix{Float32}(d.opacities), Matrix{Float32}(d.shs), size(renderer.imageData); cfg = cfg)
+        HipSide(hr, nothing, true)
+    end
+end
+
+# getRenderer (src/renderer.jl:119-149 from a gaussian count, :151-186 from a .ply): same fields, host arrays instead of CuArrays
+function hostRenderer3D(splatData::SplatData3D, imgSize::Tuple)
+    n = length(splatData.opacities)
+    feat = splatData.features === nothing ? nothing : zeros(Float32, size(splatData.features))
+    # by FIELD name (the reference's initGrads passes them in another order than SplatGrads3D declares, src/splat.jl:137-156)
+    grads = SplatGrads3D(zeros(Float32, size(splatData.means)), zeros(Float32, size(splatData.scales)), zeros(Float32, size(splatData.shs)),
+                         zeros(Float32, size(splatData.quaternions)), zeros(Float32, size(splatData.opacities)), feat)
+    return GaussianRenderer3D(splatData, grads, zeros(Float32, imgSize...), nothing, ones(Float32, imgSize[1:end-1]...),
+                              zeros(Float32, 2, 2, n), zeros(Float32, 3, 3, n), zeros(Float32, 2, 2, n), zeros(Float32, 2, 2, n),
+                              n, nothing, nothing, nothing)
+end
+getRenderer(rendererTypeVal::Val{GAUSSIAN_3D}, path::String, imgSize::Tuple, threads::Tuple, blocks::Tuple) =
+    hostRenderer3D(initData(Val(SPLAT3D), path), imgSize)
+function getRenderer(rendererTypeVal::Val{GAUSSIAN_3D}, nGaussians::Int, imgSize::Tuple, threads::Tuple, blocks::Tuple)
+    # initData(Val(SPLAT3D), n) (src/splat.jl:91-104) with host arrays
+    data = SplatData3D(rand(Float32, 3, nGaussians), rand(Float32, 3, nGaussians), rand(Float32, 9, nGaussians),
+                       rand(Float32, 4, nGaussians), rand(Float32, 1, nGaussians), zeros(Float32, 0, nGaussians))
+    return hostRenderer3D(data, imgSize)
+end
+
+# preprocess(renderer)  src/forward.jl:35-111
+function preprocess(renderer::GaussianRenderer3D)
+    side = hipSide(renderer)
+    hr = side.hr
+    d = renderer.splatData
+    if !side.uploaded || HIP_REUPLOAD_EVERY_FRAME[]
+        HipBackend.check(hr, ccall((:gs_set_model, HipBackend.libgs), Cint,
+                                   (Ptr{Cvoid}, Int64, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cint),
+                                   hr.ctx, hr.n, hr.shDegree, d.means, d.scales, d.quaternions, d.opacities, d.shs, HipBackend.GS_MEM_HOST))
+        side.uploaded = true
+    end
+    (w, h) = size(renderer.imageData)[1:2]
+    camera = defaultCamera()                                        # src/forward.jl:53 (the cameras.json path there is commented out)
+    hip_preprocess(hr, camera, computeTransform(camera).linear, computeProjection(camera, w, h).linear)
+    renderer.camera = camera
+    n = renderer.nGaussians
+    tps = zeros(Float32, 4, n)
+    if HIP_EXPORT_SCRATCH[]
+        hip_getArray!(hr, 1, tps)                                   # GS_ARR_TPS
+        renderer.positions = hip_getArray!(hr, 2, zeros(Float32, 2, n))            # GS_ARR_MU
+        hip_getArray!(hr, 3, renderer.cov3ds); hip_getArray!(hr, 4, renderer.cov2ds)
+        hip_getArray!(hr, 5, renderer.invCov2ds); hip_getArray!(hr, 6, renderer.bbs)
+    end
+    return tps          # (forward ignores it: the per-view payload stays on the device)
+end
+
+# compactIdxs(renderer, threads, blocks)  src/forward.jl:118-161: depth order + per-tile lists (kept on the device as ranges + ids;
+# the reference's dense hitIdxs[tx, ty, slot] is not materialised)
+function compactIdxs(renderer::GaussianRenderer3D, threads, blocks)
+    hr = hipSide(renderer).hr
+    hip_compactIdxs(hr, threads, blocks)
+    if HIP_EXPORT_SCRATCH[]
+        renderer.sortIdxs = hip_getArray!(hr, 11, zeros(UInt32, renderer.nGaussians)) .+ UInt32(1)      # GS_ARR_SORT_IDXS is 0-based
+    end
+    return nothing
+end
+
+# forward(renderer, tps, threads, blocks)  src/forward.jl:163-198: writes renderer.imageData and renderer.transmittance in place
+function forward(renderer::GaussianRenderer3D, tps, threads, blocks)
+    hip_forward!(hipSide(renderer).hr, renderer.imageData, renderer.transmittance)
+    return nothing
+end
+
+# backward(renderer, ΔC)  src/backward.jl:3-38: accumulates into renderer.splatGrads.Δ* (same shapes as the parameters)
+function backward(renderer::GaussianRenderer3D, ΔC)
+    side = hipSide(renderer)
+    hr = side.hr
+    g = renderer.splatGrads
+    d = renderer.splatData
+    for (Δ, p, name) in ((g.Δmeans, d.means, "Δmeans"), (g.Δscales, d.scales, "Δscales"), (g.Δquaternions, d.quaternions, "Δquaternions"),
+                         (g.Δopacities, d.opacities, "Δopacities"), (g.Δshs, d.shs, "Δshs"))
+        size(Δ) == size(p) || error("renderer.splatGrads.$name has size $(size(Δ)), its parameter $(size(p)): build the gradients by " *
+                                    "field name (hostRenderer3D); the reference's initGrads passes them in another order (src/splat.jl:148-155)")
+    end
+    side.grads === nothing && (side.grads = hip_initGrads(hr))
+    dev = side.grads
+    # one frame's gradients on the device (stored, not accumulated: GS_BWD_OVERWRITE = 1), then += on the host arrays
+    HipBackend.check(hr, ccall((:gs_backward_ex, HipBackend.libgs), Cint, (Ptr{Cvoid}, Ptr{Float32}, Cint, Ref{GsGrads}, Cint),
+                               hr.ctx, Array{Float32, 3}(ΔC), HipBackend.GS_MEM_HOST, dev, HipBackend.GS_BWD_OVERWRITE))
+    tm, ts, tq, to, tsh = similar(g.Δmeans), similar(g.Δscales), similar(g.Δquaternions), similar(g.Δopacities), similar(g.Δshs)
+    hip_readGrads!(hr, dev, tm, ts, tq, to, tsh)
+    g.Δmeans .+= tm; g.Δscales .+= ts; g.Δquaternions .+= tq; g.Δopacities .+= to; g.Δshs .+= tsh
+    return nothing
+end
+
+# resetGrads(renderer.splatGrads)  src/splat.jl:158-173 (the reference's 3-D method is typed on SplatData3D, which has no Δ fields)
+function resetGrads(grads::SplatGrads3D)
+    grads.Δmeans .= 0; grads.Δquaternions .= 0; grads.Δscales .= 0; grads.Δshs .= 0; grads.Δopacities .= 0
+    grads.Δfeatures === nothing || (grads.Δfeatures .= 0)
+    return nothing
+end
+
+end # if @isdefined(GaussianRenderer3D)

@@ -80,7 +80,7 @@ def _julia_ccalls():
     src = open(os.path.join(ROOT, "julia", "backend.jl")).read()
     src = re.sub(r"(?m)#.*$", "", src)
     calls = []
-    for m in re.finditer(r"ccall\(\(:(gs_[a-z_0-9]+),\s*libgs\),", src):
+    for m in re.finditer(r"ccall\(\(:(gs_[a-z_0-9]+),\s*(?:HipBackend\.)?libgs\),", src):
         i, depth = m.end(), 1                       # parse the rest of the ccall argument list
         j = i
         while depth:
@@ -189,3 +189,65 @@ def test_config_and_grads_structs_mirror_the_header():
     from gaussiansplat_amd import backend
     assert [f[0] for f in backend.GsConfig._fields_] == [f[0] for f in cf] and C.sizeof(backend.GsConfig) == 96
     assert [f[0] for f in backend.GsGrads._fields_] == [f[0] for f in gf]
+
+
+# ---- the reference's own signatures: julia/backend.jl must define METHODS on the reference's types so that
+# src/examples/main.jl:32-34 runs unchanged.  The strings below are the reference's (held here: /root/reference does not travel):
+#   src/forward.jl:35   function preprocess(renderer::GaussianRenderer3D)
+#   src/forward.jl:118  function compactIdxs(renderer, threads, blocks)
+#   src/forward.jl:163  function forward(renderer, tps, threads, blocks)
+#   src/backward.jl:3   function backward(renderer, ΔC)
+#   src/splat.jl:158    function resetGrads(splatData::SplatGrads2D) / (splatData::SplatData3D)
+#   src/renderer.jl:151 function getRenderer(rendererTypeVal::Val{GAUSSIAN_3D}, path::String, imgSize::Tuple, threads::Tuple, blocks::Tuple)
+REFERENCE_METHODS = {
+    "preprocess": ["renderer::GaussianRenderer3D"],
+    "compactIdxs": ["renderer::GaussianRenderer3D", "threads", "blocks"],
+    "forward": ["renderer::GaussianRenderer3D", "tps", "threads", "blocks"],
+    "backward": ["renderer::GaussianRenderer3D", "ΔC"],
+    "resetGrads": ["grads::SplatGrads3D"],
+}
+# src/renderer.jl:205-219 (GaussianRenderer3D), src/splat.jl:36-52 (SplatData3D, SplatGrads3D)
+RENDERER3D_FIELDS = ["splatData", "splatGrads", "imageData", "positions", "transmittance", "cov2ds", "cov3ds", "bbs", "invCov2ds",
+                     "nGaussians", "hitIdxs", "camera", "sortIdxs"]
+SPLATDATA3D_FIELDS = ["means", "scales", "shs", "quaternions", "opacities", "features"]
+SPLATGRADS3D_FIELDS = ["Δmeans", "Δscales", "Δshs", "Δquaternions", "Δopacities", "Δfeatures"]
+
+
+def _reference_half():
+    src = open(os.path.join(ROOT, "julia", "backend.jl")).read()
+    i = src.index("if @isdefined(GaussianRenderer3D)")
+    return re.sub(r"(?m)#.*$", "", src[i:])
+
+
+def test_reference_signatures_are_defined_on_the_reference_types():
+    half = _reference_half()
+    for name, args in REFERENCE_METHODS.items():
+        m = re.search(r"(?m)^function " + name + r"\(([^)]*)\)", half)
+        assert m, f"julia/backend.jl defines no method {name}(...) on the reference's types"
+        got = [a.strip() for a in m.group(1).split(",")]
+        assert got == args, f"{name}: arguments {got}, the reference's call sites need {args}"
+    # the two getRenderer methods main.jl:14-27 / renderer.jl:164-186 dispatch to
+    for second in ("path::String", "nGaussians::Int"):
+        assert re.search(r"getRenderer\(rendererTypeVal::Val\{GAUSSIAN_3D\}, " + re.escape(second) + r", imgSize::Tuple, threads::Tuple, blocks::Tuple\)", half), second
+
+
+def test_reference_methods_use_the_reference_field_names():
+    half = _reference_half()
+    used_r = set(re.findall(r"\brenderer\.([A-Za-z0-9_]+)", half))
+    assert used_r and used_r <= set(RENDERER3D_FIELDS), f"not fields of GaussianRenderer3D: {sorted(used_r - set(RENDERER3D_FIELDS))}"
+    for need in ("splatData", "splatGrads", "imageData", "transmittance", "camera", "nGaussians"):
+        assert need in used_r, need
+    used_d = set(re.findall(r"\b(?:d|splatData|renderer\.splatData)\.([a-z]+)\b", half)) - {"hr"}
+    assert {"means", "scales", "quaternions", "opacities", "shs"} <= used_d <= set(SPLATDATA3D_FIELDS), used_d
+    used_g = set(re.findall(r"\b(?:g|grads)\.(Δ[a-z]+)", half))
+    assert set(SPLATGRADS3D_FIELDS) - {"Δfeatures"} <= used_g <= set(SPLATGRADS3D_FIELDS), used_g
+    # the constructors are called with one value per field, in the reference's field order
+    m = re.search(r"GaussianRenderer3D\((.*?)\)\nend", half, flags=re.S)
+    assert m and len(_split_top(m.group(1))) == len(RENDERER3D_FIELDS)
+    m = re.search(r"grads = SplatGrads3D\((.*?)\)\n", half, flags=re.S)
+    order = re.findall(r"splatData\.([a-z]+)\)\)", m.group(1))
+    assert order == ["means", "scales", "shs", "quaternions", "opacities"], order      # = SPLATGRADS3D_FIELDS without the Δ
+    # forward writes in place into the renderer's own arrays; backward accumulates (+=) into the renderer's gradient arrays
+    assert "hip_forward!(hipSide(renderer).hr, renderer.imageData, renderer.transmittance)" in half
+    for f in SPLATGRADS3D_FIELDS[:-1]:
+        assert re.search(r"g\." + f + r" \.\+= ", half), f
