@@ -29,7 +29,7 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
            "gs_debug_tile_clock", "gs_debug_clock_mhz", "gs_rank_probe_result", "gs_num_rounds", "gs_set_view_slot", "gs_num_coarse_instances",
-           "gs_get_list_stats", "gs_get_tile_parts", "gs_debug_set_window", "gs_get_sched_rounds")
+           "gs_get_list_stats", "gs_get_tile_parts", "gs_debug_set_window", "gs_get_sched_rounds", "gs_debug_rebuild_order")
 
 GS_ABI_VERSION = 3          # include/gsplat.h; load() refuses a library that reports another version
 GS_DEBUG_WIDE_CURSORS = 1
@@ -126,6 +126,7 @@ def load():
     L.gs_get_tile_parts.argtypes = [vp]
     L.gs_debug_set_window.argtypes = [vp, C.c_int32, C.c_int32]
     L.gs_get_sched_rounds.argtypes = [vp]
+    L.gs_debug_rebuild_order.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     if L.gs_abi_version() != GS_ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} has ABI version {L.gs_abi_version()}, this binding is written for {GS_ABI_VERSION}: "
                            "rebuild with `python -m gaussiansplat_amd.build --force`")
@@ -439,6 +440,10 @@ class Context:
     def set_debug_window(self, start: int = 0, length: int = 0):
         """debug launches cover only order[start : start + length] of the frame's launch order (0, 0: all of it)"""
         self._chk(self.L.gs_debug_set_window(self.h, start, length))
+
+    def rebuild_order(self, which: int, rounds: int, work_mode: int = 1):
+        """debug: launch order for the following debug launches from the per-tile work the last debug launch of kernel `which` left"""
+        self._chk(self.L.gs_debug_rebuild_order(self.h, which, rounds, work_mode))
 
     def clock_mhz(self) -> float:
         """the shader clock the chip runs at right now (one wave counting cycles over 20 us; waits for the stream)"""

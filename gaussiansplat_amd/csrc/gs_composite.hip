@@ -46,9 +46,7 @@
 #ifndef GS_FWD_MINW
 #define GS_FWD_MINW 5               // __launch_bounds__ waves/SIMD of the forward (89 VGPRs)
 #endif
-#ifndef GS_ROUNDS_MINW
-#define GS_ROUNDS_MINW 4            // the static-schedule instantiations: the launch never holds more than four waves per SIMD (lpt_rounds), so they may use 128 VGPRs
-#endif
+// (GS_ROUNDS_MINW, gs_common.h: the static-schedule instantiations -- the launch never holds more than that many waves per SIMD (lpt_rounds))
 #ifndef GS_LIVE_RECT
 #define GS_LIVE_RECT 1              // no-op test against the rectangle of the pixels still taking entries (0: against the whole tile; A/B builds)
 #endif
@@ -264,6 +262,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     const int ty0 = py0 - (lane >> 4);                             // first pixel row of the tile (1-based)
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long cyc0 = a.work_mode ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // Slab frames (binning in depth slabs): the tile's list arrives in several rounds.  A later round resumes the
     // pixel state the previous one left in image / trans and in tile_dead (four 64-bit lane masks per tile: pixel slot p of
@@ -277,7 +276,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     // (a frozen pixel's transmittance is final: it goes to memory when the pixel freezes, not at the end of the tile)
     float Cr[4], Cg[4], Cb[4], T[4], fy[4];
     bool dead[4];
-    uint32_t walked = 0, evaluated = 0;
+    uint32_t walked = 0, evaluated = 0, model = 0;
     constexpr bool PACK = GS_FWD_PACK && EARLY && !SLAB;
     const uint32_t own = (EARLY && !SLAB && MULTI) ? strips_of_part(a, part) : 0xFu;   // tile_parts > 1: the strips this wave composites
     bool first_pack = PACK && MULTI && a.parts > 1;                              // ... packed into K = 2 / 1 slots at the first batch
@@ -499,6 +498,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
 #undef GS_FWD_PIXEL
 #undef GS_FWD_COLUMN
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
+        if (a.work_mode == 2) model += 42u * (uint32_t)cnt + (uint32_t)nk * (K == 4 ? 145u : K == 2 ? 103u : 61u);
         first_use_here(n0, n1, n2, n3);
         if (CLK) {
             const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t;
@@ -527,7 +527,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     }
     if (lane == 0 && part == 0) {                                       // (tile_parts > 1: the counters of a tile are those of its first part)
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
-        if (a.tile_work) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + evaluated : evaluated;
+        const uint32_t wk = a.work_mode == 2 ? model : a.work_mode ? (uint32_t)((__builtin_amdgcn_s_memtime() - cyc0) >> 5) : evaluated;
+        if (a.tile_work) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + wk : wk;
         if (a.tile_walked) a.tile_walked[tile] = SLAB && a.resume ? a.tile_walked[tile] + walked : walked;
         if (SLAB && a.tile_done) a.tile_done[tile] = all_dead ? 1 : 0;
         if (SLAB && a.tile_pos) a.tile_pos[tile] = gp0 + (s1 - s0);
@@ -671,6 +672,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const int ty0 = py0 - (lane >> 4);
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long cyc0 = a.work_mode ? __builtin_amdgcn_s_memtime() : 0ull;
     // transposed reduction: lane (c, s) = (rl >> 2, rl & 3) sums quarter s of component c; lanes >= 36 mirror lanes 0..27
     // (same addresses: broadcasts, no bank conflicts), their sums are not used
     const int rl = lane < 36 ? lane : lane - 36;
@@ -680,7 +682,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
 
     float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
     bool dead[4];
-    uint32_t walked = 0, evaluated = 0;
+    uint32_t walked = 0, evaluated = 0, model = 0;
     const uint32_t own = (EARLY && MULTI) ? strips_of_part(a, part) : 0xFu;   // tile_parts > 1 (frames with the early-out): the strips this wave differentiates
     // (Packing the live pixels into one slot once 64 or fewer are left -- what the forward does -- was built for this kernel too and
     // measured equal to slower, same box: the per-splat reduction, which packing does not shorten, is too large a share of an entry, and
@@ -818,6 +820,11 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             finish();
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
+        if (a.work_mode == 2) {
+            const uint64_t bl = nk >= 64 ? ~0ull : ((1ull << nk) - 1ull);
+            const uint32_t strips_exec = CULL ? (uint32_t)(__popcll(mq[0] & bl) + __popcll(mq[1] & bl) + __popcll(mq[2] & bl) + __popcll(mq[3] & bl)) : 4u * (uint32_t)nk;
+            model += 18u * (uint32_t)cnt + 150u * (uint32_t)nk + 76u * strips_exec;
+        }
         first_use_here(n0, n1, n2, n3);
         if (CLK) {
             const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t;
@@ -831,7 +838,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     if (lane == 0 && part == 0) {                                         // (tile_parts > 1: the counters of a tile are those of its first part)
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
         if (a.tile_walked) a.tile_walked[tile] = walked;
-        if (a.tile_work) a.tile_work[tile] = evaluated;
+        if (a.tile_work) a.tile_work[tile] = a.work_mode == 2 ? model : a.work_mode ? (uint32_t)((__builtin_amdgcn_s_memtime() - cyc0) >> 5) : evaluated;
     }
     if (CLK && a.tile_clock && lane == 0) {
         unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)tile;

@@ -37,7 +37,8 @@ struct DevBuf {
 
 extern std::string g_create_error;         // message of the last failed gs_create (gs_last_error(NULL))
 
-#define GS_COUNTER_BYTES 192      // 32 B of work-counter sums (on demand) | byte 128: the binning totals | 144: list segments appended by waves | 160: debug scratch
+#define GS_COUNTER_BYTES 256      // 32 B of work-counter sums (on demand) | byte 128: the binning totals | 144: list segments appended by waves | 160: debug scratch
+                                  // | 192: tickets of the fused binning kernels (zero between launches; zeroed at gs_create)
 struct gs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -109,6 +110,8 @@ struct gs_ctx {
     size_t spec_cap_coarse = 0, spec_cap_fine = 0;   // ... against these capacities (entries)
     int64_t n_coarse = 0;
     DevBuf tile_dead;                        // slab frames: 4 lane masks per tile (frozen pixels between rounds)
+    int dbg_work_mode = 0;                   // gs_debug_rebuild_order: what the debug launches write as per-tile work
+    DevBuf dbg_order;                        // ... and the launch order it built
     int dbg_win_start = 0, dbg_win_len = 0;  // gs_debug_set_window: the part of the launch order the debug launches cover (len 0: all)
     int rank_probe = -1;                     // lane-order probe of the LDS atomic rank: -1 not run, 0 passed, 1 failed (ballots forced)
     // ---- binning in depth slabs (gs_config.slab_mode)
@@ -125,6 +128,7 @@ struct gs_ctx {
     int64_t coarse_listed = 0;               // coarse instances of the current round
     DevBuf rect_sorted, l1_table, l1_rows, l1_partials, cids, clr, cranges, segcnt, sdone, tilecnt;
     uint32_t *bin_totals() { return counters.as<uint32_t>() + 32; }
+    uint32_t *tickets() { return counters.as<uint32_t>() + 48; }            // byte 192: [0] level-2 count pass, [1] level-1 histogram, [2] depth-bucket histogram
     uint32_t *ext_count() { return counters.as<uint32_t>() + 36; }          // byte 144: list segments appended by composite waves (capped lists)
     // ---- per-tile work counters of the composite launches (walked / evaluated list entries): counters[0..3] hold their sums only
     // after sum_work_counters() (gs_get_work_counters, the radix binning paths); the two-level path sums the walked counts of the
@@ -232,7 +236,7 @@ inline int lpt_rounds(const gs_ctx *c) {
     // (slab frames and frames without the early-out: one tile per wave)
     const bool forced = c->cfg.sched_rounds >= 2 && (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER);      // tests: also on small grids
     if (!lpt_schedule(c) || c->cfg.sched_rounds == 1 || (ntiles <= c->wave_slots && !forced) || c->n_rounds > 1 || !(c->cfg.t_min > 0.0f)) return 1;
-    const int64_t slots4 = (int64_t)c->wave_slots * 4 / 5;               // the static-schedule kernels are built for FOUR waves per SIMD (GS_ROUNDS_MINW)
+    const int64_t slots4 = (int64_t)c->wave_slots * GS_ROUNDS_MINW / 5;   // the static-schedule kernels are built for GS_ROUNDS_MINW waves per SIMD
     int64_t R = (ntiles + slots4 - 1) / slots4;
     if (c->cfg.sched_rounds >= 2) R = std::max<int64_t>(R, c->cfg.sched_rounds);
     return (int)std::min<int64_t>(R, GS_LPT_MAX_ROUNDS);

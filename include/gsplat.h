@@ -419,6 +419,12 @@ int gs_debug_clock_mhz(gs_ctx *ctx, float *mhz);
  * throughput by resident waves directly instead of inferring it from tile lifetimes. */
 int gs_debug_set_window(gs_ctx *ctx, int32_t start, int32_t len);
 
+/* Profiling aid (tools/static_balance_probe.py): rebuild the frame's launch order from the per-tile work the LAST debug launch of
+ * kernel `which` (0 forward, 1 backward) left -- with work_mode 1 the shader cycles each tile took instead of its evaluated entries
+ * -- for `rounds` tiles per wave (1 = one tile per wave), and use it for the following debug launches.  work_mode applies to the debug
+ * launches only. */
+int gs_debug_rebuild_order(gs_ctx *ctx, int which, int rounds, int work_mode);
+
 /* -1: the lane-order probe of the LDS-atomic rank was not run (rank_mode = 1 was asked for); 0: it ran at gs_create and
  * passed; 1: it failed on this device and ballots were forced. */
 int gs_rank_probe_result(const gs_ctx *ctx);

@@ -303,6 +303,9 @@ hip_rankProbeResult(r::HipRenderer) = ccall((:gs_rank_probe_result, libgs), Cint
 hip_debugSetWindow(r::HipRenderer, start::Integer, len::Integer) =
     check(r, ccall((:gs_debug_set_window, libgs), Cint, (Ptr{Cvoid}, Int32, Int32), r.ctx, start, len))
 
+hip_debugRebuildOrder(r::HipRenderer, which::Integer, rounds::Integer, workMode::Integer) =
+    check(r, ccall((:gs_debug_rebuild_order, libgs), Cint, (Ptr{Cvoid}, Cint, Cint, Cint), r.ctx, which, rounds, workMode))
+
 end # module
 
 # ======================================================================================================================
