@@ -29,7 +29,7 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
            "gs_debug_tile_clock", "gs_debug_clock_mhz", "gs_rank_probe_result", "gs_num_rounds", "gs_set_view_slot", "gs_num_coarse_instances",
-           "gs_get_list_stats", "gs_get_tile_parts", "gs_debug_set_window", "gs_get_sched_rounds", "gs_debug_rebuild_order")
+           "gs_get_list_stats", "gs_get_tile_parts", "gs_debug_set_window")
 
 GS_ABI_VERSION = 3          # include/gsplat.h; load() refuses a library that reports another version
 GS_DEBUG_WIDE_CURSORS = 1
@@ -45,7 +45,7 @@ class GsConfig(C.Structure):
                 ("deterministic", C.c_int32), ("export_debug", C.c_int32), ("profile_stages", C.c_int32),
                 ("bin_path", C.c_int32), ("rank_mode", C.c_int32), ("alpha_cull", C.c_int32), ("schedule", C.c_int32),
                 ("slab_mode", C.c_int32), ("slab_max_ratio", C.c_float), ("slab_fractions", C.c_float * 3), ("debug_flags", C.c_int32),
-                ("depth_sort", C.c_int32), ("list_cap", C.c_int32), ("tile_parts", C.c_int32), ("sched_rounds", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("depth_sort", C.c_int32), ("list_cap", C.c_int32), ("tile_parts", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class GsGrads(C.Structure):
@@ -125,8 +125,6 @@ def load():
     L.gs_get_list_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gs_get_tile_parts.argtypes = [vp]
     L.gs_debug_set_window.argtypes = [vp, C.c_int32, C.c_int32]
-    L.gs_get_sched_rounds.argtypes = [vp]
-    L.gs_debug_rebuild_order.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     if L.gs_abi_version() != GS_ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} has ABI version {L.gs_abi_version()}, this binding is written for {GS_ABI_VERSION}: "
                            "rebuild with `python -m gaussiansplat_amd.build --force`")
@@ -147,7 +145,7 @@ class Context:
                  profile_stages: bool = False, deterministic: bool = False, bin_path: int = 0, rank_mode: int = 1,
                  alpha_cull: bool = True, schedule: int = 0, slab_mode: int = 1, slab_fractions=(), slab_max_ratio: float = 0.0,
                  debug_flags: int = 0, depth_sort: int = 0, list_cap: int = 0, tile_parts: "int | None" = None,
-                 sched_rounds: "int | None" = None, cfg: "GsConfig | None" = None):
+                 cfg: "GsConfig | None" = None):
         """schedule 0 = the library default (3); slab_fractions / slab_max_ratio / debug_flags: gs_config fields for tests;
         depth_sort 0 automatic, 1 the four-pass radix sort, 2 always key-range buckets + LDS (same permutation);
         list_cap 0 automatic (tile lists written as far as the view slot's previous frame walked them), 1 never, 2 also on small grids.
@@ -176,8 +174,6 @@ class Context:
         # waves per tile on small grids: 0 = automatic; None = GSPLAT_TILE_PARTS (the test suite pins 1 there: its cross-mode tests
         # assert bit-identical results, which holds under one partition of the pixels only) or automatic
         cfg.tile_parts = int(os.environ.get("GSPLAT_TILE_PARTS", "0")) if tile_parts is None else int(tile_parts)
-        # tiles per wave of the static schedule: 0 automatic, 1 never, 2 .. 16 as given; None = GSPLAT_SCHED_ROUNDS or automatic
-        cfg.sched_rounds = int(os.environ.get("GSPLAT_SCHED_ROUNDS", "0")) if sched_rounds is None else int(sched_rounds)
         cfg.order, cfg.t_min = int(order), float(t_min)
         cfg.export_debug, cfg.profile_stages, cfg.deterministic = int(export_debug), int(profile_stages), int(deterministic)
         cfg.bin_path, cfg.rank_mode, cfg.alpha_cull = int(bin_path), int(rank_mode), int(alpha_cull)
@@ -416,13 +412,6 @@ class Context:
             self._chk(rc)
         return int(rc)
 
-    def sched_rounds_of_frame(self) -> int:
-        """tiles per wave of the last frame's composite backward launch (gs_config.sched_rounds; 1 = one tile per wave)"""
-        rc = self.L.gs_get_sched_rounds(self.h)
-        if rc < 0:
-            self._chk(rc)
-        return int(rc)
-
     def time_composite(self, which: int, variant: int, reps: int = 10) -> float:
         ms = C.c_float()
         self._chk(self.L.gs_debug_time_composite(self.h, which, variant, reps, C.byref(ms)))
@@ -440,10 +429,6 @@ class Context:
     def set_debug_window(self, start: int = 0, length: int = 0):
         """debug launches cover only order[start : start + length] of the frame's launch order (0, 0: all of it)"""
         self._chk(self.L.gs_debug_set_window(self.h, start, length))
-
-    def rebuild_order(self, which: int, rounds: int, work_mode: int = 1):
-        """debug: launch order for the following debug launches from the per-tile work the last debug launch of kernel `which` left"""
-        self._chk(self.L.gs_debug_rebuild_order(self.h, which, rounds, work_mode))
 
     def clock_mhz(self) -> float:
         """the shader clock the chip runs at right now (one wave counting cycles over 20 us; waits for the stream)"""

@@ -60,7 +60,6 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (c0.depth_sort < 0 || c0.depth_sort > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: depth_sort must be 0, 1 or 2");
     if (c0.list_cap < 0 || c0.list_cap > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: list_cap must be 0, 1 or 2");
     if (c0.tile_parts != 0 && c0.tile_parts != 1 && c0.tile_parts != 2 && c0.tile_parts != 4) return fail(nullptr, GS_ERR_INVALID, "gs_create: tile_parts must be 0, 1, 2 or 4");
-    if (c0.sched_rounds < 0 || c0.sched_rounds > GS_LPT_MAX_ROUNDS) return fail(nullptr, GS_ERR_INVALID, "gs_create: sched_rounds must be 0 .. 16");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -78,9 +77,6 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->wave_slots = prop.multiProcessorCount * 4 * 5;
         else (void)hipGetLastError();
-    }
-    if ((e = c->counters.ensure(GS_COUNTER_BYTES)) != hipSuccess || (e = hipMemsetAsync(c->counters.p, 0, GS_COUNTER_BYTES, c->stream)) != hipSuccess) {
-        (void)hipStreamDestroy(c->stream); delete c; return hipfail(nullptr, e, "hipMalloc(counters)");
     }
     if ((e = hipHostMalloc((void **)&c->pinned, 512, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return hipfail(nullptr, e, "hipHostMalloc"); }
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
@@ -110,7 +106,7 @@ int gs_destroy(gs_ctx *c) {
     comm_release(c);
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
-                      &c->counters, &c->dbg_order, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
+                      &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
                       &c->tile_work, &c->tile_clock,
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
                       &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->tilecnt,

@@ -255,12 +255,15 @@ int settle_totals(gs_ctx *c, bool *redo, bool may_relist) {
     c->spec_lists = false;
     if ((size_t)coarse <= c->spec_cap_coarse && (size_t)fine_slab <= c->spec_cap_fine) return GS_OK;
     if (!may_relist) { c->did_bin = false; return GS_OK; }                  // the frame is being abandoned (a new gs_preprocess / gs_bin follows)
-    // a list outgrew its buffer: nothing was listed (all ranges empty).  Grow and list again with the real totals.
+    // a list outgrew its buffer: nothing was listed (all ranges empty).  Grow and list again with the real totals -- in FULL: the caps'
+    // source is the slot's walked array, and the forward that just ran on the empty lists has overwritten it with zeros (rare frame:
+    // a model that outgrew its buffers; full lists are the fast choice there)
     HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * (size_t)(c->n_inst ? c->n_inst : 1)));
+    c->cap_src = nullptr;
     {
         StageTimer t(c, GS_STAGE_TILE_SORT);
         if (int rc = two_level_lists(c, c->perm_ptr, c->n, c->slab_lo[1], (size_t)coarse, (size_t)fine_slab, c->ranges.as<uint32_t>(), c->ids.as<uint32_t>(), nullptr, nullptr,
-                                     c->cap_src)) return rc;
+                                     nullptr)) return rc;
     }
     if (redo) *redo = true;
     return GS_OK;

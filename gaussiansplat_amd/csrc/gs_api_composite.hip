@@ -10,7 +10,6 @@ const uint32_t *forward_order(gs_ctx *c) {
     const int k = order_index(c);
     if (k == GS_MAX_VIEW_SLOTS && c->cfg.schedule != 4) return nullptr;
     if (c->slots[k].tiles != (((int64_t)c->gx << 32) | (int64_t)c->gy)) return nullptr;         // (the order's length and groups belong to one grid)
-    if (c->slots[k].rounds != lpt_rounds(c)) return nullptr;                                       // (... and its layout to one number of tiles per wave)
     if (c->order_pending) {                                              // (long complete by now; an event wait on the stream costs nothing)
         if (hipStreamWaitEvent(c->stream, c->ev_order, 0) != hipSuccess) return nullptr;
         c->order_pending = false;
@@ -25,29 +24,25 @@ const uint32_t *forward_order(gs_ctx *c) {
 int build_frame_order(gs_ctx *c, const uint32_t *used) {
     const int64_t ntiles = (int64_t)c->gx * c->gy;
     c->frame_order = used;
-    if (!used) c->frame_rounds = 1;
     if (!lpt_schedule(c) || ntiles <= 0 || ntiles > GS_LPT_MAX_TILES) return GS_OK;
     const int k = order_index(c);
     const int dst = used ? 1 - c->slots[k].sel : c->slots[k].sel;
-    const int R = lpt_rounds(c);
     DevBuf &ob = c->slots[k].order[dst];
-    HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)R * (size_t)gs_lpt_order_len(c->gx, c->gy, R) + 16)));
+    HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)gs_lpt_order_len(c->gx, c->gy) + 16)));
     if (used && use_side_stream(c)) {
         if (c->order_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0));      // (never two in flight)
         HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
-        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->side, nullptr, 0, R));
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->side));
         HIPCHK(c, hipEventRecord(c->ev_order, c->side));
         c->order_pending = true;
         c->slots[k].sel = dst;
         // (tile_work is rewritten by the next forward of this ctx: it waits for ev_order first, see forward_order / gs_forward)
     } else {
-        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->stream, nullptr, 0, R));
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->stream));
         c->frame_order = ob.as<uint32_t>();
-        c->frame_rounds = R;
     }
     c->slots[k].tiles = ((int64_t)c->gx << 32) | (int64_t)c->gy;
-    c->slots[k].rounds = R;
     return GS_OK;
 }
 
@@ -71,7 +66,7 @@ int gs_set_view_slot(gs_ctx *c, int32_t slot) {
 // waves per tile of this frame's composite launches (gs_config.tile_parts)
 static int composite_parts(const gs_ctx *c) {
     const int want = c->cfg.tile_parts;
-    if (want == 1 || !(c->cfg.t_min > 0.0f) || c->n_rounds > 1 || c->frame_capped || lpt_rounds(c) > 1) return 1;
+    if (want == 1 || !(c->cfg.t_min > 0.0f) || c->n_rounds > 1 || c->frame_capped) return 1;
     if (want == 2 || want == 4) return want;
     const long long ntiles = (long long)c->gx * c->gy, slots = c->wave_slots;   // 256 CUs x 4 SIMDs x five waves (GS_FWD_MINW, GS_BWD_MINW)
     return 4 * ntiles <= slots ? 4 : 2 * ntiles <= slots ? 2 : 1;
@@ -89,8 +84,7 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.cull = c->cfg.alpha_cull != 0;
     a.resume = r > 0; a.final_round = r == R - 1;
     a.tile_work = c->tile_work.as<uint32_t>(); a.tile_walked = const_cast<uint32_t *>(c->last_walked);
-    a.rounds = order ? c->frame_rounds : 1;
-    a.tile_order = order; a.order_len = order ? gs_lpt_order_len(c->gx, c->gy, a.rounds) : 0;
+    a.tile_order = order; a.order_len = order ? gs_lpt_order_len(c->gx, c->gy) : 0;
     a.parts = c->frame_parts;
     if (c->frame_capped && R == 1) {                                        // capped lists: the wave extends its tile's list when it must
         a.tile_ext = c->tile_ext.as<uint2>(); a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>();
@@ -132,7 +126,6 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     }
     c->frame_parts = composite_parts(c);
     const uint32_t *order = forward_order(c);
-    c->frame_rounds = order ? c->slots[order_index(c)].rounds : 1;
     if (c->order_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0)); c->order_pending = false; }     // the order kernel in flight reads tile_work
     for (int r = 0; r < R; ++r) {
         if (r > 0) { if (int rc = bin_round(c, r)) return rc; }
@@ -226,10 +219,7 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         // find their rows in memory instead of the cache, C3 + 1 %; profiles/r04t_ab_nontemporal.log)
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
         // launch order: the one the frame's forward used, or (no history) what the order kernel made of that forward
-        if (lpt_schedule(c)) {
-            a.tile_order = c->frame_order; a.rounds = c->frame_order ? c->frame_rounds : 1;
-            a.order_len = c->frame_order ? gs_lpt_order_len(c->gx, c->gy, a.rounds) : 0;
-        }
+        if (lpt_schedule(c)) { a.tile_order = c->frame_order; a.order_len = c->frame_order ? gs_lpt_order_len(c->gx, c->gy) : 0; }
         {
             StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                   // the kernel alone (what rocprof reports for it)
             HIPCHK(c, gs_launch_composite_bwd(a, c->stream));

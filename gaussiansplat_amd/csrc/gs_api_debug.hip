@@ -175,32 +175,13 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     // variant tens digit (gs_composite.hip: apply_sched_variant): 0 the frame's own launch order (what production uses for the
     // backward and for the next forward of the slot), 1 tile order, 3 = 0 explicitly
     a.tile_order = lpt_schedule(c) ? c->frame_order : nullptr;
-    a.rounds = a.tile_order ? c->frame_rounds : 1;
-    a.order_len = a.tile_order ? gs_lpt_order_len(c->gx, c->gy, a.rounds) : 0;
-    a.parts = c->frame_parts;                                                // as the frame's own launches
-    a.work_mode = c->dbg_work_mode;
-    a.tile_work = which == 0 ? c->tile_work.as<uint32_t>() : c->tile_work_b.as<uint32_t>();   // (the debug launches leave their per-tile work: gs_debug_rebuild_order)
+    a.order_len = a.tile_order ? gs_lpt_order_len(c->gx, c->gy) : 0;
+    a.parts = c->frame_parts;                                                // as the frame's own launches (tile clocks: one wave per tile only)
     if (c->dbg_win_len > 0) {                                                // gs_debug_set_window: a slice of the launch order
-        if (!a.tile_order || a.parts > 1 || a.rounds > 1)
-            return fail(c, GS_ERR_INVALID, "gs_debug_set_window: the frame has no one-tile-per-wave launch order (several waves per tile, or a static schedule: gs_config.sched_rounds = 1)");
+        if (!a.tile_order || a.parts > 1) return fail(c, GS_ERR_INVALID, "gs_debug_set_window: the frame has no launch order (or several waves per tile)");
         if (c->dbg_win_start + c->dbg_win_len > a.order_len) return fail(c, GS_ERR_INVALID, "gs_debug_set_window: beyond the launch order");
         a.tile_order += c->dbg_win_start; a.order_len = c->dbg_win_len;
     }
-    return GS_OK;
-}
-
-int gs_debug_rebuild_order(gs_ctx *c, int which, int rounds, int work_mode) {
-    if (!c || rounds < 1 || rounds > GS_LPT_MAX_ROUNDS) return GS_ERR_INVALID;
-    if (!c->did_fwd || (which == 1 && !c->did_bwd)) return fail(c, GS_ERR_INVALID, "gs_debug_rebuild_order: gs_forward (and gs_backward) first");
-    if (!lpt_schedule(c) || c->frame_parts > 1) return fail(c, GS_ERR_INVALID, "gs_debug_rebuild_order: the frame has no launch order");
-    if (bind_device(c)) return GS_ERR_HIP;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->order_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0)); c->order_pending = false; }
-    HIPCHK(c, c->dbg_order.ensure(sizeof(uint32_t) * ((size_t)rounds * (size_t)gs_lpt_order_len(c->gx, c->gy, rounds) + 16)));
-    const uint32_t *src = which == 0 ? c->tile_work.as<uint32_t>() : c->tile_work_b.as<uint32_t>();
-    HIPCHK(c, gs_launch_tile_lpt_order(src, 0, c->gx, c->gy, c->dbg_order.as<uint32_t>(), c->stream, nullptr, 0, rounds));
-    c->frame_order = c->dbg_order.as<uint32_t>(); c->frame_rounds = rounds;
-    c->dbg_work_mode = work_mode;
     return GS_OK;
 }
 
@@ -313,12 +294,6 @@ int gs_get_tile_parts(gs_ctx *c) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_tile_parts: gs_forward first");
     return c->frame_parts;
-}
-
-int gs_get_sched_rounds(gs_ctx *c) {
-    if (!c) return GS_ERR_INVALID;
-    if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_sched_rounds: gs_forward first");
-    return c->frame_order ? c->frame_rounds : 1;
 }
 
 int gs_get_work_counters_ex(gs_ctx *c, int64_t out[4]) {

@@ -437,6 +437,7 @@ __global__ __launch_bounds__(L2_THREADS) void l2_count_kernel(GsBin3Args a) {
 template <int SBS>
 __global__ __launch_bounds__(GS_WAVE) void l2_cap_kernel(GsBin3Args a) {
     constexpr int SB = 1 << SBS;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.ext_count) *a.ext_count = 0u;      // (also when nothing is listed: gs_get_list_stats reads it)
     if (lists_overflow(a.totals, a.cap_coarse, a.cap_fine)) return;
     const int S = blockIdx.x, lane = threadIdx.x;
     uint32_t w0 = 0;                                           // first work item of S: segments of the super-tiles before it
@@ -465,7 +466,6 @@ __global__ __launch_bounds__(GS_WAVE) void l2_cap_kernel(GsBin3Args a) {
 #pragma unroll
     for (int d = GS_WAVE / 2; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
     if (lane == 0) a.smax[S] = m;
-    if (S == 0 && lane == 0 && a.ext_count) *a.ext_count = 0u;
 }
 
 // tile ranges = exclusive scan of the tile counts in tile order (one workgroup); completed tiles get an empty range

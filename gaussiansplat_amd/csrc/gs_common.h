@@ -257,10 +257,8 @@ struct GsCompositeArgs {
     int cull;                  // 1: drop (tile, splat) entries that are provably no-ops while staging (gs_config.alpha_cull)
     int variant;               // debug launches (gs_debug_time_composite, gs_debug_tile_clock): tens digit 1 = tile order instead of tile_order
     const uint32_t *tile_order; // plain launch: block b composites tile_order[b] (0xFFFFFFFF: none); null: block b = tile b
-    int order_len;              // blocks of the plain launch (0: gx * gy); tile_order holds rounds x order_len entries
-    int rounds;                 // static schedule: block b composites tile_order[r * order_len + b], r = 0 .. rounds - 1, one after the other (0 / 1: one tile)
-    uint32_t *tile_work;       // per tile, the launch orders' input; may be null.  work_mode 0: evaluated entries; 1: shader cycles the wave spent on the tile, / 32
-    int work_mode;
+    int order_len;              // entries of tile_order = blocks of the plain launch (0: gx * gy)
+    uint32_t *tile_work;       // evaluated entries per tile (forward: the backward's exact work measure and the next launch order); may be null
     unsigned long long *zero_words; // forward: two 64-bit words zeroed by block 0 (the backward's work counters: saves a memset command); may be null
     unsigned long long *tile_clock; // debug: GS_TILE_CLOCK_WORDS per tile {start, end (s_memrealtime, 100 MHz), HW_ID | XCC_ID << 32, walked << 32 | evaluated,
                                     // shader cycles (s_memtime) inside the per-entry loops, shader cycles outside them (staging, waiting for the gathers),
@@ -296,17 +294,13 @@ hipError_t gs_launch_sum_listed(const uint2 *ext, int n, unsigned long long *out
 // GS_LPT_BUCKETS work classes inside an XCD's list; one workgroup).  order: gs_lpt_order_len(gx, gy) entries, holes = 0xFFFFFFFF.
 // zero14 (may be null): fourteen 64-bit words zeroed on the way (the backward's work and ticket counters: saves a memset command)
 #define GS_LPT_MAX_TILES 35000
-#define GS_LPT_MAX_ROUNDS 16
-#ifndef GS_ROUNDS_MINW
-#define GS_ROUNDS_MINW 4            // waves per SIMD the static-schedule instantiations of the composite kernels are built for (and lpt_rounds plans for)
-#endif
-int gs_lpt_order_len(int gx, int gy, int rounds = 1);      // workgroups of the launch: order holds rounds x this many entries
+int gs_lpt_order_len(int gx, int gy);
 // out[0] = shader cycles (s_memtime), out[1] = 100 MHz ticks (s_memrealtime) of one wave over ~20 us: the chip's clock right now
 hipError_t gs_launch_clock_probe(unsigned long long *out, hipStream_t s);
 // out[0] = sum of a[0 .. n), out[1] = sum of b[0 .. n) (64 bit): the per-tile work counters of a composite launch, on demand
 hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsigned long long *out, hipStream_t s);
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
-                                    unsigned long long *zero14 = nullptr, int buckets = 0, int rounds = 1);
+                                    unsigned long long *zero14 = nullptr, int buckets = 0);
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);
 

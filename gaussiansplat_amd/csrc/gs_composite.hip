@@ -46,7 +46,6 @@
 #ifndef GS_FWD_MINW
 #define GS_FWD_MINW 5               // __launch_bounds__ waves/SIMD of the forward (89 VGPRs)
 #endif
-// (GS_ROUNDS_MINW, gs_common.h: the static-schedule instantiations -- the launch never holds more than that many waves per SIMD (lpt_rounds))
 #ifndef GS_LIVE_RECT
 #define GS_LIVE_RECT 1              // no-op test against the rectangle of the pixels still taking entries (0: against the whole tile; A/B builds)
 #endif
@@ -70,26 +69,24 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float vgpr_const(float x) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// The tile of this workgroup in round r of the launch: its own index, or -- plain launch over a launch order (gs_config.schedule 3 / 4) --
-// order[r * len + blockIdx] (holes of the order: GS_LPT_NONE).  -1: nothing to do.  With a static schedule (a.rounds > 1) a wave
-// composites the tiles of rounds 0 .. rounds - 1 one after the other (tile_lpt_order_kernel deals them so that the waves' sums are equal).
-__device__ __forceinline__ int tile_of_block(const GsCompositeArgs &a, int ntiles, int &part, int round) {
+// The tile of this workgroup: its own index, or -- plain launch over a launch order (gs_config.schedule 3 / 4) -- order[blockIdx]
+// (holes of the order: GS_LPT_NONE).  -1: nothing to do.
+__device__ __forceinline__ int tile_of_block(const GsCompositeArgs &a, int ntiles, int &part) {
     const int len = (a.tile_order && a.order_len > 0) ? a.order_len : ((ntiles + 7) / 8) * 8;   // composite_grid(): blocks of one part
     int b = (int)blockIdx.x;
     part = 0;
     if (a.parts > 1) { part = b / len; b -= part * len; if (part >= a.parts) return -1; }   // the parts of a tile: same XCD (len % 8 == 0)
     if (a.tile_order) {
         if (b >= (a.order_len > 0 ? a.order_len : ntiles)) return -1;
-        const uint32_t t = a.tile_order[(size_t)round * (size_t)len + (size_t)b];
+        const uint32_t t = a.tile_order[b];
         return t < (uint32_t)ntiles ? (int)t : -1;
     }
-    return (round == 0 && b < ntiles) ? b : -1;
+    return b < ntiles ? b : -1;
 }
 // the pixel strips (slots) part `part` of a tile owns: all four, a pair, or one
 __device__ __forceinline__ uint32_t strips_of_part(const GsCompositeArgs &a, int part) {
     return a.parts == 4 ? (1u << part) : a.parts == 2 ? (3u << (2 * part)) : 0xFu;
 }
-// MULTI = false: an instantiation that never runs several waves per tile (the static-schedule kernels): the part logic folds away
 
 __device__ __forceinline__ unsigned long long wave_hw_id() {
     // HW_REG_HW_ID (4): wave, simd, cu, sh, se ids; HW_REG_XCC_ID (20): the XCD
@@ -234,7 +231,7 @@ __device__ __forceinline__ uint32_t extend_tile_list(const GsCompositeArgs &a, c
 }
 
 // ---------------------------------------------------------------- forward
-template <bool EARLY, bool CULL, bool CLK, bool SLAB, bool MULTI = true>
+template <bool EARLY, bool CULL, bool CLK, bool SLAB>
 // SLAB: the frame is binned in depth slabs (several rounds; resume / tile_pos / tile_done / tile_dead): its own instantiation, the
 // single-round kernel carries none of that state (with it the compiler spilled: 96 VGPRs + 28 bytes of scratch against 90).
 // CLK: per-tile debug clocks (gs_debug_tile_clock); a separate instantiation so that the production kernel carries none of it.
@@ -262,7 +259,6 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     const int ty0 = py0 - (lane >> 4);                             // first pixel row of the tile (1-based)
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long cyc0 = a.work_mode ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // Slab frames (binning in depth slabs): the tile's list arrives in several rounds.  A later round resumes the
     // pixel state the previous one left in image / trans and in tile_dead (four 64-bit lane masks per tile: pixel slot p of
@@ -276,10 +272,10 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     // (a frozen pixel's transmittance is final: it goes to memory when the pixel freezes, not at the end of the tile)
     float Cr[4], Cg[4], Cb[4], T[4], fy[4];
     bool dead[4];
-    uint32_t walked = 0, evaluated = 0, model = 0;
+    uint32_t walked = 0, evaluated = 0;
     constexpr bool PACK = GS_FWD_PACK && EARLY && !SLAB;
-    const uint32_t own = (EARLY && !SLAB && MULTI) ? strips_of_part(a, part) : 0xFu;   // tile_parts > 1: the strips this wave composites
-    bool first_pack = PACK && MULTI && a.parts > 1;                              // ... packed into K = 2 / 1 slots at the first batch
+    const uint32_t own = (EARLY && !SLAB) ? strips_of_part(a, part) : 0xFu;   // tile_parts > 1: the strips this wave composites
+    bool first_pack = PACK && a.parts > 1;                              // ... packed into K = 2 / 1 slots at the first batch
     int K = 4;                                                          // slots per entry: 4 = the tile's pixels in place; 2 / 1 = live pixels packed
     // packed: slots 2 and 3 hold no pixel, and fy[2], fy[3] hold the x of the pixels in slots 0 and 1 (0 = the slot is empty)
 #pragma unroll
@@ -498,7 +494,6 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
 #undef GS_FWD_PIXEL
 #undef GS_FWD_COLUMN
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
-        if (a.work_mode == 2) model += 42u * (uint32_t)cnt + (uint32_t)nk * (K == 4 ? 145u : K == 2 ? 103u : 61u);
         first_use_here(n0, n1, n2, n3);
         if (CLK) {
             const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t;
@@ -527,8 +522,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     }
     if (lane == 0 && part == 0) {                                       // (tile_parts > 1: the counters of a tile are those of its first part)
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
-        const uint32_t wk = a.work_mode == 2 ? model : a.work_mode ? (uint32_t)((__builtin_amdgcn_s_memtime() - cyc0) >> 5) : evaluated;
-        if (a.tile_work) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + wk : wk;
+        if (a.tile_work) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + evaluated : evaluated;
         if (a.tile_walked) a.tile_walked[tile] = SLAB && a.resume ? a.tile_walked[tile] + walked : walked;
         if (SLAB && a.tile_done) a.tile_done[tile] = all_dead ? 1 : 0;
         if (SLAB && a.tile_pos) a.tile_pos[tile] = gp0 + (s1 - s0);
@@ -567,26 +561,16 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     }
 }
 
-template <bool EARLY, int MINW, bool CULL, bool CLK = false, bool SLAB = false, bool ROUNDS = false>
-// ROUNDS: the static schedule (a.rounds tiles per wave, never several waves per tile): an instantiation of its own, so that the
-// one-tile kernel keeps its registers (with the loop around it: 5 VGPRs and 40 SGPRs spilled at five waves per SIMD)
+template <bool EARLY, int MINW, bool CULL, bool CLK = false, bool SLAB = false>
 __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     if (a.zero_words && blockIdx.x == 0 && threadIdx.x < 2) a.zero_words[threadIdx.x] = 0ull;
-    if (!ROUNDS) {
-        int part;
-        const int tile = tile_of_block(a, ntiles, part, 0);
-        if (tile >= 0) forward_tile<EARLY, CULL, CLK, SLAB>(a, tile, part, sp, syhi, nbig);
-        return;
-    }
-    for (int r = 0; r < a.rounds; ++r) {                                   // the wave's tiles, heaviest first
-        const uint32_t t = a.tile_order[(size_t)r * (size_t)a.order_len + blockIdx.x];
-        if (t < (uint32_t)ntiles) forward_tile<EARLY, CULL, CLK, SLAB, false>(a, (int)t, 0, sp, syhi, nbig);
-        __syncthreads();                                                    // the next tile reuses the staging buffer
-    }
+    int part;
+    const int tile = tile_of_block(a, ntiles, part);
+    if (tile >= 0) forward_tile<EARLY, CULL, CLK, SLAB>(a, tile, part, sp, syhi, nbig);
 }
 
 // ---------------------------------------------------------------- wave64 reduction of the nine per-splat sums
@@ -661,7 +645,7 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
     v[6] = dX * qx; v[7] = dX * q1s; v[8] = q2s;
 }
 
-template <bool EARLY, bool DET, bool CULL, bool CLK, bool MULTI = true>
+template <bool EARLY, bool DET, bool CULL, bool CLK>
 __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, const int part, float4 *sp, float *syhi, uint32_t *sid, uint32_t *sstrip,
                                               float *red, const float nbig) {
     const int lane = threadIdx.x;
@@ -672,7 +656,6 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     const int ty0 = py0 - (lane >> 4);
     unsigned long long clk0 = 0;
     if (CLK) clk0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long cyc0 = a.work_mode ? __builtin_amdgcn_s_memtime() : 0ull;
     // transposed reduction: lane (c, s) = (rl >> 2, rl & 3) sums quarter s of component c; lanes >= 36 mirror lanes 0..27
     // (same addresses: broadcasts, no bank conflicts), their sums are not used
     const int rl = lane < 36 ? lane : lane - 36;
@@ -682,8 +665,8 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
 
     float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
     bool dead[4];
-    uint32_t walked = 0, evaluated = 0, model = 0;
-    const uint32_t own = (EARLY && MULTI) ? strips_of_part(a, part) : 0xFu;   // tile_parts > 1 (frames with the early-out): the strips this wave differentiates
+    uint32_t walked = 0, evaluated = 0;
+    const uint32_t own = EARLY ? strips_of_part(a, part) : 0xFu;          // tile_parts > 1 (frames with the early-out): the strips this wave differentiates
     // (Packing the live pixels into one slot once 64 or fewer are left -- what the forward does -- was built for this kernel too and
     // measured equal to slower, same box: the per-splat reduction, which packing does not shorten, is too large a share of an entry, and
     // the packed loop cost the kernel 18 spilled registers: profiles/r04g_ab_backward_packing.log.)
@@ -820,11 +803,6 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             finish();
         }
         walked += (uint32_t)cnt; evaluated += (uint32_t)nk;
-        if (a.work_mode == 2) {
-            const uint64_t bl = nk >= 64 ? ~0ull : ((1ull << nk) - 1ull);
-            const uint32_t strips_exec = CULL ? (uint32_t)(__popcll(mq[0] & bl) + __popcll(mq[1] & bl) + __popcll(mq[2] & bl) + __popcll(mq[3] & bl)) : 4u * (uint32_t)nk;
-            model += 18u * (uint32_t)cnt + 150u * (uint32_t)nk + 76u * strips_exec;
-        }
         first_use_here(n0, n1, n2, n3);
         if (CLK) {
             const unsigned long long t = __builtin_amdgcn_s_memtime(); t_loop += t - t_mark; t_mark = t;
@@ -838,7 +816,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     if (lane == 0 && part == 0) {                                         // (tile_parts > 1: the counters of a tile are those of its first part)
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
         if (a.tile_walked) a.tile_walked[tile] = walked;
-        if (a.tile_work) a.tile_work[tile] = a.work_mode == 2 ? model : a.work_mode ? (uint32_t)((__builtin_amdgcn_s_memtime() - cyc0) >> 5) : evaluated;
+        if (a.tile_work) a.tile_work[tile] = evaluated;
     }
     if (CLK && a.tile_clock && lane == 0) {
         unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)tile;
@@ -849,7 +827,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     }
 }
 
-template <bool EARLY, int MINW, bool DET, bool CULL, bool CLK = false, bool ROUNDS = false>
+template <bool EARLY, int MINW, bool DET, bool CULL, bool CLK = false>
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
@@ -858,17 +836,9 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     __shared__ __attribute__((aligned(16))) float red[RED_FLOATS];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
-    if (!ROUNDS) {
-        int part;
-        const int tile = tile_of_block(a, ntiles, part, 0);
-        if (tile >= 0) backward_tile<EARLY, DET, CULL, CLK>(a, tile, part, sp, syhi, sid, sstrip, red, nbig);
-        return;
-    }
-    for (int r = 0; r < a.rounds; ++r) {                                   // the static schedule (see the forward)
-        const uint32_t t = a.tile_order[(size_t)r * (size_t)a.order_len + blockIdx.x];
-        if (t < (uint32_t)ntiles) backward_tile<EARLY, DET, CULL, CLK, false>(a, (int)t, 0, sp, syhi, sid, sstrip, red, nbig);
-        __syncthreads();
-    }
+    int part;
+    const int tile = tile_of_block(a, ntiles, part);
+    if (tile >= 0) backward_tile<EARLY, DET, CULL, CLK>(a, tile, part, sp, syhi, sid, sstrip, red, nbig);
 }
 
 // Longest-first order for a PLAIN launch (gs_config.schedule 3 / 4).  The dispatcher hands workgroups out in blockIdx order,
@@ -901,22 +871,10 @@ static inline int lpt_group_side(int gx, int gy) {
     for (int gs = 8; gs > 1; gs >>= 1) if (lpt_groups(gx, gy, gs) >= 128) return gs;
     return 1;
 }
-// workgroups of the launch (order holds rounds x this many entries): eight times the longest list an XCD can get, cut into `rounds`
-int gs_lpt_order_len(int gx, int gy, int rounds) {
-    const int gs = lpt_group_side(gx, gy), per = gs * gs * ((lpt_groups(gx, gy, gs) + 7) / 8);
-    return 8 * ((per + (rounds > 1 ? rounds : 1) - 1) / (rounds > 1 ? rounds : 1));
-}
+int gs_lpt_order_len(int gx, int gy) { const int gs = lpt_group_side(gx, gy); return 8 * gs * gs * ((lpt_groups(gx, gy, gs) + 7) / 8); }
 
-//
-// STATIC SCHEDULE (round 5; rounds > 1).  With more tiles than wave slots the dispatcher hands the later tiles to whichever slot
-// frees first, and the launch ends ragged: measured at C3 the backward ran at 0.78 of its five-waves-per-SIMD rate, with SIMDs one
-// to four waves short for a third of the kernel (a lone wave reaches a third of a SIMD's rate, profiles/r05a_occupancy_curve_C3.json).
-// Instead the launch has `len` <= wave-slot workgroups and the wave of workgroup b composites order[r * len + b], r = 0 .. rounds - 1,
-// one after the other.  An XCD's sorted list (heaviest first) is dealt to its bins in snake order -- round 0 left to right, round 1
-// right to left, ... -- so that every bin's sum of work is (nearly) the same: with two rounds the k-th heaviest tile shares a wave
-// with the k-th lightest.  Every wave then starts at once and ends at (nearly) the same time; no SIMD runs short of waves before the end.
 __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int gx, int ng, int gs, int nb,
-                                                               uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14, int rounds, int len) {
+                                                               uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14) {
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wmax;
     __shared__ uint32_t rowtot[8 * 32], rowstart[8 * 32], xcount[8];
@@ -1013,29 +971,19 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
         xcount[tid] = run;
     }
     __syncthreads();
-    // bins per XCD: the longest list cut into `rounds` (<= len / 8: the host sized `len` for the longest list an XCD can get)
-    uint32_t bx = 0;
-    for (int x = 0; x < 8; ++x) bx = max(bx, xcount[x]);
-    bx = (bx + (uint32_t)rounds - 1u) / (uint32_t)rounds;
-    if (bx == 0) bx = 1;
-    // entry (round, bin, XCD) holds position round * bx + (bin, or in odd rounds bx - 1 - bin) of the XCD's list; holes: no such position
-    for (int i = tid; i < rounds * len; i += 1024) {
-        const uint32_t rd = (uint32_t)(i / len), rem = (uint32_t)(i - (int)rd * len), bin = rem >> 3, x = rem & 7u;
-        const uint32_t pos = rd * bx + ((rd & 1u) ? bx - 1u - bin : bin);
-        if (bin >= bx || pos >= xcount[x]) order[i] = GS_LPT_NONE;
-    }
+    for (int i = tid; i < 8 * per; i += 1024)                            // holes behind the shorter lists
+        if ((uint32_t)(i >> 3) >= xcount[i & 7]) order[i] = GS_LPT_NONE;
     for (int t = tid; t < ntiles; t += 1024) {
         int local;
         const uint32_t gi = ginfo[group_of(t, local)];
         const int x = (int)(gi & 7u), r = x * nb + cls[t], i = (int)(gi >> 3) * GT + local;
         const uint32_t pos = rowstart[r] + pre[r * W + (i >> 5)] + (uint32_t)__popc(bm[r * W + (i >> 5)] & ((1u << (i & 31)) - 1u));
-        const uint32_t rd = pos / bx, j = pos - rd * bx, bin = (rd & 1u) ? bx - 1u - j : j;
-        order[(size_t)rd * (size_t)len + 8u * bin + (uint32_t)x] = (uint32_t)t;
+        order[8u * pos + (uint32_t)x] = (uint32_t)t;
     }
 }
 
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
-                                    unsigned long long *zero14, int buckets, int rounds) {
+                                    unsigned long long *zero14, int buckets) {
     const int ntiles = gx * gy;
     if (ntiles <= 0) return hipSuccess;
     if (ntiles > GS_LPT_MAX_TILES) return hipErrorInvalidValue;          // beyond 8K-class images: the callers keep launch order
@@ -1049,10 +997,7 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_lpt_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (rounds < 1) rounds = 1;
-    if (rounds > GS_LPT_MAX_ROUNDS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, gx, ng, gs, nb, order, zero14, rounds,
-                       gs_lpt_order_len(gx, gy, rounds));
+    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, gx, ng, gs, nb, order, zero14);
     return hipGetLastError();
 }
 
@@ -1108,7 +1053,7 @@ static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {           // 
 // variant (debug launches, gs_debug_time_composite / gs_debug_tile_clock): tens digit 1 = tile order instead of the frame's launch order
 static GsCompositeArgs apply_sched_variant(const GsCompositeArgs &a0) {
     GsCompositeArgs a = a0;
-    if ((a.variant / 10) % 10 == 1) { a.tile_order = nullptr; a.order_len = 0; a.rounds = 1; }
+    if ((a.variant / 10) % 10 == 1) { a.tile_order = nullptr; a.order_len = 0; }
     return a;
 }
 
@@ -1118,7 +1063,6 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
-    if (a.rounds > 1 && (!a.tile_order || a.order_len <= 0 || a.parts > 1 || a.rounds > GS_LPT_MAX_ROUNDS || !early || a.tile_pos)) return hipErrorInvalidValue;
     if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.tile_pos || a.tile_clock)) return hipErrorInvalidValue;
     if (a.tile_ext && (gs_bin3_seg() != L2_SEG || !early || !a.cranges || !a.cids || !a.clr || !a.ids_w || a.tile_pos)) return hipErrorInvalidValue;
     if (a.tile_pos) {                                                     // a round of a slab frame (t_min > 0 by construction: plan_rounds)
@@ -1130,14 +1074,8 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     }
     if (a.tile_clock) {                                                   // debug clocks: instantiations of their own (alpha_cull on only)
         if (!a.cull) return hipErrorInvalidValue;
-        if (a.rounds > 1) hipLaunchKernelGGL((composite_fwd_kernel<true, GS_ROUNDS_MINW, true, true, false, true>), grid, block, 0, s, a);
-        else if (early) hipLaunchKernelGGL((composite_fwd_kernel<true, GS_FWD_MINW, true, true>), grid, block, 0, s, a);
+        if (early) hipLaunchKernelGGL((composite_fwd_kernel<true, GS_FWD_MINW, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((composite_fwd_kernel<false, GS_FWD_MINW, true, true>), grid, block, 0, s, a);
-        return hipGetLastError();
-    }
-    if (a.rounds > 1) {                                                   // static schedule (frames with the early-out only)
-        if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<true, GS_ROUNDS_MINW, true, false, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((composite_fwd_kernel<true, GS_ROUNDS_MINW, false, false, false, true>), grid, block, 0, s, a);
         return hipGetLastError();
     }
     if (early) {
@@ -1156,23 +1094,14 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const bool early = a.t_min > 0.0f;
     const dim3 grid = composite_grid(a, ntiles), block(64);
-    if (a.rounds > 1 && (!a.tile_order || a.order_len <= 0 || a.parts > 1 || a.rounds > GS_LPT_MAX_ROUNDS || !early || a.nseg > 1)) return hipErrorInvalidValue;
     if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.nseg > 1 || a.tile_clock)) return hipErrorInvalidValue;
 #define GS_B2(E, D) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, true>), grid, block, 0, s, a); \
                          else hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, false>), grid, block, 0, s, a); } while (0)
 #define GS_B(E) do { if (a.g2d_fixed) GS_B2(E, true); else GS_B2(E, false); } while (0)
     if (a.tile_clock) {                                                   // debug clocks: instantiations of their own (alpha_cull on, float atomics only)
         if (!a.cull || a.g2d_fixed) return hipErrorInvalidValue;
-        if (a.rounds > 1) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_ROUNDS_MINW, false, true, true, true>), grid, block, 0, s, a);
-        else if (early) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_BWD_MINW, false, true, true>), grid, block, 0, s, a);
+        if (early) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_BWD_MINW, false, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((composite_bwd_kernel<false, GS_BWD_MINW, false, true, true>), grid, block, 0, s, a);
-        return hipGetLastError();
-    }
-    if (a.rounds > 1) {                                                   // static schedule (frames with the early-out only)
-        if (a.g2d_fixed) { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_ROUNDS_MINW, true, true, false, true>), grid, block, 0, s, a);
-                           else hipLaunchKernelGGL((composite_bwd_kernel<true, GS_ROUNDS_MINW, true, false, false, true>), grid, block, 0, s, a); }
-        else { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_ROUNDS_MINW, false, true, false, true>), grid, block, 0, s, a);
-               else hipLaunchKernelGGL((composite_bwd_kernel<true, GS_ROUNDS_MINW, false, false, false, true>), grid, block, 0, s, a); }
         return hipGetLastError();
     }
     if (early) GS_B(true); else GS_B(false);

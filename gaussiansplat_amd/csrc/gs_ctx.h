@@ -37,8 +37,7 @@ struct DevBuf {
 
 extern std::string g_create_error;         // message of the last failed gs_create (gs_last_error(NULL))
 
-#define GS_COUNTER_BYTES 256      // 32 B of work-counter sums (on demand) | byte 128: the binning totals | 144: list segments appended by waves | 160: debug scratch
-                                  // | 192: tickets of the fused binning kernels (zero between launches; zeroed at gs_create)
+#define GS_COUNTER_BYTES 192      // 32 B of work-counter sums (on demand) | byte 128: the binning totals | 144: list segments appended by waves | 160: debug scratch
 struct gs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -84,7 +83,6 @@ struct gs_ctx {
         DevBuf order[2];                     // launch orders, double buffered
         int sel = 0;                         // the newest one
         int64_t tiles = 0;                   // ... is valid for this grid (gx << 32 | gy; 0: no history)
-        int rounds = 1;                      // ... and was built for this many tiles per wave
         DevBuf walked;                       // per tile: list entries the slot's last forward walked (the next frame's list caps)
         int64_t walked_grid = 0;             // ... on this grid (0: none yet)
     };
@@ -93,7 +91,6 @@ struct gs_ctx {
     // ---- capped lists (gs_config.list_cap): this frame's tile lists were written only as far as the slot's history says they are walked
     bool frame_capped = false;
     int frame_parts = 1;                   // waves per tile of the frame's composite launches (gs_config.tile_parts; decided by gs_forward)
-    int frame_rounds = 1;                  // tiles a wave composites one after the other (static schedule of the launch order; decided by gs_forward)
     int wave_slots = 5120;                 // waves of the composite kernels the device holds at once: CUs x 4 SIMDs x 5 (GS_FWD_MINW, GS_BWD_MINW); gs_create
     const uint32_t *cap_src = nullptr;       // the history the caps of this frame come from (null: none)
     DevBuf tile_nopen, smax, tile_ext, zero_tiles;
@@ -110,8 +107,6 @@ struct gs_ctx {
     size_t spec_cap_coarse = 0, spec_cap_fine = 0;   // ... against these capacities (entries)
     int64_t n_coarse = 0;
     DevBuf tile_dead;                        // slab frames: 4 lane masks per tile (frozen pixels between rounds)
-    int dbg_work_mode = 0;                   // gs_debug_rebuild_order: what the debug launches write as per-tile work
-    DevBuf dbg_order;                        // ... and the launch order it built
     int dbg_win_start = 0, dbg_win_len = 0;  // gs_debug_set_window: the part of the launch order the debug launches cover (len 0: all)
     int rank_probe = -1;                     // lane-order probe of the LDS atomic rank: -1 not run, 0 passed, 1 failed (ballots forced)
     // ---- binning in depth slabs (gs_config.slab_mode)
@@ -128,7 +123,6 @@ struct gs_ctx {
     int64_t coarse_listed = 0;               // coarse instances of the current round
     DevBuf rect_sorted, l1_table, l1_rows, l1_partials, cids, clr, cranges, segcnt, sdone, tilecnt;
     uint32_t *bin_totals() { return counters.as<uint32_t>() + 32; }
-    uint32_t *tickets() { return counters.as<uint32_t>() + 48; }            // byte 192: [0] level-2 count pass, [1] level-1 histogram, [2] depth-bucket histogram
     uint32_t *ext_count() { return counters.as<uint32_t>() + 36; }          // byte 144: list segments appended by composite waves (capped lists)
     // ---- per-tile work counters of the composite launches (walked / evaluated list entries): counters[0..3] hold their sums only
     // after sum_work_counters() (gs_get_work_counters, the radix binning paths); the two-level path sums the walked counts of the
@@ -219,27 +213,13 @@ inline int bind_device(gs_ctx *c) {
     return GS_OK;
 }
 
-// A launch order is built only when there are more tiles than wave slots (256 CUs x 4 SIMDs x 5 waves).  Below that the isolated
+// A launch order is built only when there are more tiles than wave slots (gs_ctx::wave_slots: 256 CUs x 4 SIMDs x 5 waves on MI355X).  Below that the isolated
 // kernels do gain from it (C2, 2500 tiles: forward 68 -> 61 us, backward 145 -> 122 us, tools/xcd_order.py C2 -- in tile order the
 // heavy tiles of the image centre land on neighbouring SIMDs), but the frame does not: its forward is bound by cold gathers, not by
 // balance, and the order kernel is one more launch in a frame that is bound by launches (C2 0.382 -> 0.400 ms, C1 0.183 -> 0.205 ms
 // with it, same box; 0.393 / 0.197 with the kernel on the side stream).
 inline bool lpt_schedule(const gs_ctx *c) {
     return (c->cfg.schedule == 3 || c->cfg.schedule == 4) && ((int64_t)c->gx * c->gy > c->wave_slots || (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER));
-}
-// Static schedule (round 5): with more tiles than wave slots a plain launch hands the second helping of tiles to whichever slot
-// frees first, and the kernel ends ragged.  Instead the launch has at most as many workgroups as slots and every
-// wave composites R = ceil(tiles / slots) tiles one after the other, dealt so that the waves' sums of work are equal
-// (tile_lpt_order_kernel): nothing is dispatched late, every SIMD keeps its waves to the end.  1 = off (GS_DEBUG_NO_ROUNDS).
-inline int lpt_rounds(const gs_ctx *c) {
-    const int64_t ntiles = (int64_t)c->gx * c->gy;
-    // (slab frames and frames without the early-out: one tile per wave)
-    const bool forced = c->cfg.sched_rounds >= 2 && (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER);      // tests: also on small grids
-    if (!lpt_schedule(c) || c->cfg.sched_rounds == 1 || (ntiles <= c->wave_slots && !forced) || c->n_rounds > 1 || !(c->cfg.t_min > 0.0f)) return 1;
-    const int64_t slots4 = (int64_t)c->wave_slots * GS_ROUNDS_MINW / 5;   // the static-schedule kernels are built for GS_ROUNDS_MINW waves per SIMD
-    int64_t R = (ntiles + slots4 - 1) / slots4;
-    if (c->cfg.sched_rounds >= 2) R = std::max<int64_t>(R, c->cfg.sched_rounds);
-    return (int)std::min<int64_t>(R, GS_LPT_MAX_ROUNDS);
 }
 // The side stream (order kernel beside the backward) costs four more runtime calls per frame: it pays when the composite kernels
 // are long, and costs when the frame is bound by the host's launch rate (config C2, together with the zero fill it once carried: + 9 %).

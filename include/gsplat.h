@@ -151,16 +151,7 @@ typedef struct {
                                  4 x tiles fit the wave slots, else 2 when 2 x tiles fit, else 1; 1, 2, 4: as given.  Always 1 for
                                  frames without the early-out (t_min = 0), frames binned in depth slabs and capped lists.
                                  With more than one part the per-tile work counters are those of the tile's first part.          */
-    int32_t sched_rounds;     /* static schedule of the composite launches on grids with more tiles than the chip holds waves (speed only; a
-                                 former reserved word).  The reference launches one thread block per tile (splat.jl:224-231) and leaves the
-                                 order to the hardware; a plain launch of 8160 tiles on 5120 wave slots ends ragged -- the later tiles go to
-                                 whichever slot frees first, and SIMDs run one to four waves short for a third of the kernel.  0 (default)
-                                 automatic: the launch has at most as many workgroups as the chip holds waves (four per SIMD for these
-                                 kernels) and every wave composites R = ceil(tiles / slots) tiles one after the other, dealt by the view
-                                 slot's work history so that all waves carry the same total (heaviest with lightest); 1: never (one tile per
-                                 wave, longest first: rounds 2-4); 2 .. 16: R as given.  Needs a launch order (schedule 3 / 4, view-slot
-                                 history for the forward), the early-out (t_min > 0) and a single binning round.                     */
-    int32_t reserved[2];      /* sizeof(gs_config) == 96                                                                       */
+    int32_t reserved[3];      /* sizeof(gs_config) == 96                                                                       */
 } gs_config;
 #define GS_DEBUG_WIDE_CURSORS 1   /* two-level binning: 64-bit list cursors although the lists fit 32-bit byte offsets (tests)    */
 #define GS_DEBUG_ALWAYS_ORDER 2    /* longest-first launch orders (and their side stream) also on grids with fewer tiles than wave slots (tests) */
@@ -385,10 +376,6 @@ int gs_get_list_stats(gs_ctx *ctx, int64_t out[3]);
  * No counterpart in the reference (one thread block per tile, splat.jl:224-231). */
 int gs_get_tile_parts(gs_ctx *ctx);
 
-/* Tiles per wave of the last frame's composite BACKWARD launch (gs_config.sched_rounds; 1 = one tile per wave); the forward used the
- * same number if the frame's view slot had a launch order, else 1.  Negative: error.  Call after gs_forward. */
-int gs_get_sched_rounds(gs_ctx *ctx);
-
 /* out = {walked_fwd, walked_bwd, evaluated_fwd, evaluated_bwd}: `evaluated` counts the walked entries that
  * survived the alpha_cull no-op test and were evaluated per pixel (== walked when alpha_cull == 0). */
 int gs_get_work_counters_ex(gs_ctx *ctx, int64_t out[4]);
@@ -418,12 +405,6 @@ int gs_debug_clock_mhz(gs_ctx *ctx, float *mhz);
  * tools/occupancy_curve.py launches 1024, 2048 .. 5120 tiles at once -- one to five waves per SIMD -- and reads the SIMD
  * throughput by resident waves directly instead of inferring it from tile lifetimes. */
 int gs_debug_set_window(gs_ctx *ctx, int32_t start, int32_t len);
-
-/* Profiling aid (tools/static_balance_probe.py): rebuild the frame's launch order from the per-tile work the LAST debug launch of
- * kernel `which` (0 forward, 1 backward) left -- with work_mode 1 the shader cycles each tile took instead of its evaluated entries
- * -- for `rounds` tiles per wave (1 = one tile per wave), and use it for the following debug launches.  work_mode applies to the debug
- * launches only. */
-int gs_debug_rebuild_order(gs_ctx *ctx, int which, int rounds, int work_mode);
 
 /* -1: the lane-order probe of the LDS-atomic rank was not run (rank_mode = 1 was asked for); 0: it ran at gs_create and
  * passed; 1: it failed on this device and ballots were forced. */

@@ -50,8 +50,7 @@ mutable struct GsConfig                      # must mirror gs_config (96 bytes)
     depth_sort::Int32
     list_cap::Int32                          # capped tile lists: 0 automatic, 1 never, 2 also on small grids
     tile_parts::Int32                        # waves per tile on small grids: 0 automatic, 1, 2, 4
-    sched_rounds::Int32                      # tiles per wave of the static schedule: 0 automatic, 1 never, 2 .. 16
-    reserved::NTuple{2, Int32}
+    reserved::NTuple{3, Int32}
 end
 
 struct GsGrads                               # gs_grads: device pointers, may be C_NULL
@@ -77,7 +76,7 @@ function check(r::HipRenderer, rc::Cint)
 end
 
 function defaultConfig()
-    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, 0, 0, 0, 0, ntuple(_ -> Int32(0), 2))
+    cfg = GsConfig(0, 0, 0, 0, 0f0, 0, 0, 0, 0, 0, 0, 0, 0, 0f0, ntuple(_ -> 0f0, 3), 0, 0, 0, 0, ntuple(_ -> Int32(0), 3))
     ccall((:gs_default_config, libgs), Cvoid, (Ref{GsConfig},), cfg)
     # a library built from another header would read this struct with shifted fields: refuse it here, loudly
     (hip_abiVersion() == GS_ABI_VERSION && cfg.abi_version == GS_ABI_VERSION && cfg.struct_size == sizeof(GsConfig)) ||
@@ -251,9 +250,6 @@ end
 # waves per tile (1, 2, 4) of the last frame's composite launches (GsConfig.tile_parts)
 hip_tileParts(r::HipRenderer) = ccall((:gs_get_tile_parts, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 
-# tiles per wave of the last frame's composite launches (GsConfig.sched_rounds; 1 = one tile per wave)
-hip_schedRounds(r::HipRenderer) = ccall((:gs_get_sched_rounds, libgs), Cint, (Ptr{Cvoid},), r.ctx)
-
 # renderer scratch arrays (gs_array ids of include/gsplat.h; e.g. 11 = sortIdxs, 12 = tile ranges, 13 = sorted ids) into a host array
 function hip_getArray!(r::HipRenderer, which::Integer, dst::Array)
     check(r, ccall((:gs_get_array, libgs), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64), r.ctx, which, dst, sizeof(dst)))
@@ -302,9 +298,6 @@ hip_rankProbeResult(r::HipRenderer) = ccall((:gs_rank_probe_result, libgs), Cint
 # profiling: the debug launches cover only order[start+1 : start+len] of the frame's launch order (0, 0: all of it)
 hip_debugSetWindow(r::HipRenderer, start::Integer, len::Integer) =
     check(r, ccall((:gs_debug_set_window, libgs), Cint, (Ptr{Cvoid}, Int32, Int32), r.ctx, start, len))
-
-hip_debugRebuildOrder(r::HipRenderer, which::Integer, rounds::Integer, workMode::Integer) =
-    check(r, ccall((:gs_debug_rebuild_order, libgs), Cint, (Ptr{Cvoid}, Cint, Cint, Cint), r.ctx, which, rounds, workMode))
 
 end # module
 

@@ -37,7 +37,7 @@ def test_abi_version_and_config_layout(lib):
     cfg = backend.default_config()
     assert cfg.struct_size == C.sizeof(backend.GsConfig) == 96 and cfg.abi_version == 3
     assert cfg.schedule == 3 and cfg.slab_mode == 1 and cfg.debug_flags == 0 and cfg.slab_max_ratio == 0.0 and cfg.list_cap == 0
-    assert cfg.tile_parts == 0 and cfg.sched_rounds == 0 and list(cfg.reserved) == [0, 0]     # reserved words, and the ones that got a name, default to 0
+    assert cfg.tile_parts == 0 and list(cfg.reserved) == [0, 0, 0]              # reserved words, and the one that got a name, default to 0
     hdr = open(os.path.join(ROOT, "include", "gsplat.h")).read()
     assert re.search(r"#define GS_ABI_VERSION\s+3\b", hdr)
     assert cfg.tile_size == 16 and cfg.order == backend.ORDER_DEPTH_DESC and abs(cfg.t_min - 1e-5) < 1e-12

@@ -41,20 +41,32 @@ def _frame(ctx, dC, deg, slot=None):
     g = ctx.grads_alloc()
     ctx.backward(dC, g)
     grads = ctx.grads_read(g, deg)
-    return dict(img=img, tr=tr, grads=grads, wc=ctx.work_counters_ex(), st=st, inst=ctx.num_instances)
+    from gaussiansplat_amd import backend as B
+    return dict(img=img, tr=tr, grads=grads, wc=ctx.work_counters_ex(), st=st, inst=ctx.num_instances, g2d=ctx.get_array(B.ARR_GRAD2D))
 
 
-def _same_bits(a, b, det=True):
+def _same_bits(a, b, det=True, oracle_grads=None):
     assert np.array_equal(a["img"], b["img"]) and np.array_equal(a["tr"], b["tr"])
     assert a["wc"]["walked_fwd"] == b["wc"]["walked_fwd"] == b["wc"]["walked_bwd"]
     assert a["wc"]["evaluated_fwd"] == b["wc"]["evaluated_fwd"] == b["wc"]["evaluated_bwd"]
-    for k in GRADS:
-        if det:
+    if det:
+        for k in GRADS:
             assert np.array_equal(a["grads"][k], b["grads"][k]), k
-        else:
-            # float atomics: two runs of the SAME frame differ by the order of the additions; the quaternion chain amplifies that most
-            # (measured 0.8e-5 .. 1.2e-5 between identical runs at this size; the bar against the oracle is 1e-3)
-            assert rel_l2(b["grads"][k].reshape(-1), a["grads"][k].reshape(-1)) <= 3e-5, k
+        return
+    # Float atomics: two runs of the SAME frame differ by the order of the additions.  Bars that do not follow what a run happened to
+    # measure: (1) the per-gaussian 2-D sums, where the order noise is not amplified by the parameter chain, to 2e-6 --
+    # fp32 sums of a few hundred terms each differ by ~1e-7 sqrt(terms) relative; (2) the parameter gradients: both runs inside the
+    # oracle bar of 1e-3, and no further from each other than the worse of them is from the oracle.
+    assert rel_l2(b["g2d"].reshape(-1), a["g2d"].reshape(-1)) <= 2e-6, rel_l2(b["g2d"].reshape(-1), a["g2d"].reshape(-1))
+    for k in GRADS:
+        d_ab = rel_l2(b["grads"][k].reshape(-1), a["grads"][k].reshape(-1))
+        if oracle_grads is None:
+            assert d_ab <= 1e-3, (k, d_ab)
+            continue
+        o = np.asarray(oracle_grads[k]).reshape(-1)
+        d_ao, d_bo = rel_l2(a["grads"][k].reshape(-1), o), rel_l2(b["grads"][k].reshape(-1), o)
+        assert d_ao <= 1e-3 and d_bo <= 1e-3, (k, d_ao, d_bo)
+        assert d_ab <= max(d_ao, d_bo, 2e-6), (k, d_ab, d_ao, d_bo)
 
 
 def _dense_scene(n, W, H, deg, seed, grow=1.0):
@@ -74,15 +86,19 @@ def test_capped_lists_from_slot_history_are_invisible(oracle, det):
     ref = _frame(plain, dC, deg, slot=7)
     assert not ref["st"]["capped"] and ref["st"]["listed"] == ref["inst"]
     assert ref["wc"]["walked_fwd"] < 0.5 * ref["inst"]                         # the scene is dense enough for caps to matter
+    og = None
+    if not det:                                                                # the float-atomic runs are held against the oracle's adjoint
+        o0 = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+        og = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, o0["ranges"], o0["ids"], dC, t_min=1e-5, omp=True)
     ctx = hip_context(sc, cam, T, P, W, H, deg, deterministic=det, list_cap=2, slab_mode=0)
     f1 = _frame(ctx, dC, deg, slot=7)                                          # no history yet: full lists
     assert not f1["st"]["capped"]
-    _same_bits(ref, f1, det)
+    _same_bits(ref, f1, det, og)
     for rep in range(3):                                                       # history from the same view: capped, nothing to extend
         f = _frame(ctx, dC, deg, slot=7)
         assert f["st"]["capped"] and f["st"]["extended_segments"] == 0, f["st"]
         assert f["wc"]["walked_fwd"] <= f["st"]["listed"] < 0.8 * f["inst"], (f["st"], f["inst"], f["wc"])
-        _same_bits(ref, f, det)
+        _same_bits(ref, f, det, og)
     # the full ranges are always there; asking for the ids writes the unwritten rest, and the frame still finishes
     ctx.set_view_slot(7); ctx.preprocess(); ctx.bin()
     oref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
@@ -101,7 +117,7 @@ def test_capped_lists_from_slot_history_are_invisible(oracle, det):
     # a frame under another slot has no history: full lists again
     f = _frame(ctx, dC, deg, slot=2000)                                        # (slots up to 4095: the old limit was 64)
     assert not f["st"]["capped"]
-    _same_bits(ref, f, det)
+    _same_bits(ref, f, det, og)
     plain.close(); ctx.close()
 
 
@@ -145,6 +161,8 @@ def test_minimum_caps_everywhere(oracle, n, W, H, deg, grow, super16):
     O = oracle
     sc, cam, T, P, ocam = _dense_scene(n, W, H, deg, 33, grow=grow)
     dC = synthetic.make_dC(W, H, 33)
+    oref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, oref["ranges"], oref["ids"], dC, t_min=1e-5, omp=True)
     for det in (True, False):
         plain = hip_context(sc, cam, T, P, W, H, deg, deterministic=det, list_cap=1, slab_mode=0)
         ref = _frame(plain, dC, deg); plain.close()
@@ -155,10 +173,8 @@ def test_minimum_caps_everywhere(oracle, n, W, H, deg, grow, super16):
             if n >= 40_000:
                 assert f["st"]["extended_segments"] > 0
             assert f["st"]["listed"] <= f["inst"]
-            _same_bits(ref, f, det)
+            _same_bits(ref, f, det, None if det else gref)
         ctx.close()
-    oref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
-    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, oref["ranges"], oref["ids"], dC, t_min=1e-5, omp=True)
     assert np.all(np.abs(f["img"] - oref["image"]) <= 1e-4 + 1e-4 * np.abs(oref["image"]))
     assert np.all(np.abs(f["tr"] - oref["trans"]) <= 1e-4 + 1e-4 * np.abs(oref["trans"]))
     for k in GRADS:
@@ -208,3 +224,37 @@ def test_caps_engage_by_default_only_on_large_grids_and_through_the_renderer_mir
     for i in range(4):
         tps = R.preprocess(c3, synthetic.scene_camera(W3)); R.compactIdxs(c3); R.forward(c3, tps)
         assert not c3.ctx.list_stats()["capped"]                                # 28 % of the entries walked: full lists
+
+
+def test_capped_lists_meet_the_speculative_overflow_redo():
+    """capped lists (list_cap = 2, view-slot history) on a frame whose lists outgrow the buffers they were enqueued against.
+    The first forward runs on empty lists (and overwrites the slot's walked counts, the caps' source, with zeros); the redo must not
+    take its caps from there.  Image, transmittance and deterministic gradients equal those of uncapped lists bit for bit, the redo
+    lists in full (capped = False) and reports no stale extension count."""
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg = 6000, 480, 352, 1
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 123)
+    dC = synthetic.make_dC(W, H, 9)
+    base = sc["scales"].copy()
+    res = {}
+    for cap in (1, 2):
+        ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, deterministic=True, list_cap=cap, tile_parts=1)
+        out = []
+        for shift in (0.0, 0.0, 1.8, 1.8):                                 # history, history, 30-fold growth (redo), settled again
+            s2 = (base + np.float32(shift)).astype(np.float32)
+            ctx.set_model_host(sc["means"], s2, sc["quats"], sc["opacities"], sc["shs"].reshape(n, -1), deg)
+            ctx.set_view_slot(3)
+            ctx.preprocess(); ctx.bin()
+            img, tr = ctx.forward_host()
+            g = ctx.grads_alloc(); ctx.backward(dC, g)
+            out.append((img, tr, ctx.grads_read(g, deg), ctx.list_stats(), ctx.num_instances))
+        res[cap] = out
+        ctx.close()
+    assert res[2][1][3]["capped"] and res[2][3][3]["capped"]              # the slot's history caps the lists of ordinary frames
+    assert res[2][2][4] > 8 * res[2][1][4]                                 # the growth really outran the buffers
+    assert not res[2][2][3]["capped"] and res[2][2][3]["extended_segments"] == 0 and res[2][2][3]["listed"] == res[2][2][4]
+    for k in range(4):
+        a, b = res[1][k], res[2][k]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), k
+        for name in ("means", "scales", "quats", "opacities", "shs"):
+            assert np.array_equal(a[2][name], b[2][name]), (k, name)

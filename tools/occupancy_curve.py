@@ -29,7 +29,7 @@ def main():
     n, W, H, deg = synthetic.CONFIGS[cfg]
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1234 + list(synthetic.CONFIGS).index(cfg))
     dC = synthetic.make_dC(W, H, 1)
-    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, sched_rounds=1)      # a one-tile-per-wave launch order
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5)
     ctx.preprocess(); ctx.bin(); ctx.forward_host()
     g = ctx.grads_alloc(); ctx.backward(dC, g); ctx.synchronize()
     for _ in range(30):                                                  # the chip's clock ramp

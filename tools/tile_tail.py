@@ -132,12 +132,12 @@ def main():
     n, W, H, deg = synthetic.CONFIGS[cfg]
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 1234 + list(synthetic.CONFIGS).index(cfg))
     dC = synthetic.make_dC(W, H, 1)
-    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5)                  # (GSPLAT_SCHED_ROUNDS=1: the one-tile-per-wave launch of rounds 2-4)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5)
     ctx.preprocess(); ctx.bin(); ctx.forward_host()
     g = ctx.grads_alloc(); ctx.backward(dC, g); ctx.synchronize()
     for _ in range(30):                                                       # the chip's clock ramp: profile the settled clock
         ctx.time_composite(1, 30, 2)
-    res = {"config": cfg, "instances": ctx.num_instances, "work": ctx.work_counters_ex(), "sched_rounds": ctx.sched_rounds_of_frame(), "clock_mhz": ctx.clock_mhz()}
+    res = {"config": cfg, "instances": ctx.num_instances, "work": ctx.work_counters_ex(), "clock_mhz": ctx.clock_mhz()}
     variants = {"fwd": [10, 30], "bwd": [10, 30]}
     for which, name in ((0, "fwd"), (1, "bwd")):
         for v in variants[name]:
