@@ -29,7 +29,7 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
            "gs_debug_tile_clock", "gs_debug_clock_mhz", "gs_rank_probe_result", "gs_num_rounds", "gs_set_view_slot", "gs_num_coarse_instances",
-           "gs_get_list_stats", "gs_get_tile_parts", "gs_debug_set_window")
+           "gs_get_list_stats", "gs_get_tile_parts", "gs_debug_set_window", "gs_debug_tile_clock_rows")
 
 GS_ABI_VERSION = 3          # include/gsplat.h; load() refuses a library that reports another version
 GS_DEBUG_WIDE_CURSORS = 1
@@ -125,6 +125,7 @@ def load():
     L.gs_get_list_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gs_get_tile_parts.argtypes = [vp]
     L.gs_debug_set_window.argtypes = [vp, C.c_int32, C.c_int32]
+    L.gs_debug_tile_clock_rows.argtypes = [vp]
     if L.gs_abi_version() != GS_ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} has ABI version {L.gs_abi_version()}, this binding is written for {GS_ABI_VERSION}: "
                            "rebuild with `python -m gaussiansplat_amd.build --force`")
@@ -422,7 +423,12 @@ class Context:
         inside the per-entry loops, shader cycles outside them, strip slots executed << 32 | slots with live pixels packed,
         strips with a live pixel << 32 | live pixels} of one composite launch (which: 0 forward, 1 backward)."""
         ntiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-        out = np.zeros((ntiles, 15), np.uint64)
+        rows = ntiles
+        if variant < 0:                                     # one record per workgroup of the launch (split tiles as production runs them)
+            rows = int(self.L.gs_debug_tile_clock_rows(self.h))
+            if rows <= 0:
+                raise GsError(-1, "tile_clock: records by workgroup need a frame with a launch order")
+        out = np.zeros((rows, 15), np.uint64)
         self._chk(self.L.gs_debug_tile_clock(self.h, which, variant, C.c_void_p(out.ctypes.data)))
         return out
 

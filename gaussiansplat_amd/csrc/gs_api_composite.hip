@@ -28,18 +28,18 @@ int build_frame_order(gs_ctx *c, const uint32_t *used) {
     const int k = order_index(c);
     const int dst = used ? 1 - c->slots[k].sel : c->slots[k].sel;
     DevBuf &ob = c->slots[k].order[dst];
-    HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)gs_lpt_order_len(c->gx, c->gy) + 16)));
+    HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)lpt_order_entries(c) + 16)));
     if (used && use_side_stream(c)) {
         if (c->order_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0));      // (never two in flight)
         HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
-        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->side));
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->side, nullptr, 0, lpt_front(c), lpt_split_div(c)));
         HIPCHK(c, hipEventRecord(c->ev_order, c->side));
         c->order_pending = true;
         c->slots[k].sel = dst;
         // (tile_work is rewritten by the next forward of this ctx: it waits for ev_order first, see forward_order / gs_forward)
     } else {
-        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->stream));
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->stream, nullptr, 0, lpt_front(c), lpt_split_div(c)));
         c->frame_order = ob.as<uint32_t>();
     }
     c->slots[k].tiles = ((int64_t)c->gx << 32) | (int64_t)c->gy;
@@ -84,8 +84,9 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.cull = c->cfg.alpha_cull != 0;
     a.resume = r > 0; a.final_round = r == R - 1;
     a.tile_work = c->tile_work.as<uint32_t>(); a.tile_walked = const_cast<uint32_t *>(c->last_walked);
-    a.tile_order = order; a.order_len = order ? gs_lpt_order_len(c->gx, c->gy) : 0;
+    a.tile_order = order; a.order_len = order ? lpt_order_entries(c) : 0;
     a.parts = c->frame_parts;
+    a.split_ok = order && lpt_front(c) > 0 && c->frame_parts == 1 && !c->frame_capped && R == 1;   // heavy tiles run as the order's entries say
     if (c->frame_capped && R == 1) {                                        // capped lists: the wave extends its tile's list when it must
         a.tile_ext = c->tile_ext.as<uint2>(); a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>();
         a.ids_w = c->ids.as<uint32_t>(); a.sgx = c->sgx; a.sbs = c->sbs; a.ext_count = c->ext_count();
@@ -219,7 +220,8 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         // find their rows in memory instead of the cache, C3 + 1 %; profiles/r04t_ab_nontemporal.log)
         HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
         // launch order: the one the frame's forward used, or (no history) what the order kernel made of that forward
-        if (lpt_schedule(c)) { a.tile_order = c->frame_order; a.order_len = c->frame_order ? gs_lpt_order_len(c->gx, c->gy) : 0; }
+        if (lpt_schedule(c)) { a.tile_order = c->frame_order; a.order_len = c->frame_order ? lpt_order_entries(c) : 0; }
+        a.split_ok = a.tile_order && lpt_front(c) > 0 && c->frame_parts == 1 && !c->frame_capped && c->n_rounds == 1;
         {
             StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                   // the kernel alone (what rocprof reports for it)
             HIPCHK(c, gs_launch_composite_bwd(a, c->stream));

@@ -175,7 +175,8 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     // variant tens digit (gs_composite.hip: apply_sched_variant): 0 the frame's own launch order (what production uses for the
     // backward and for the next forward of the slot), 1 tile order, 3 = 0 explicitly
     a.tile_order = lpt_schedule(c) ? c->frame_order : nullptr;
-    a.order_len = a.tile_order ? gs_lpt_order_len(c->gx, c->gy) : 0;
+    a.order_len = a.tile_order ? lpt_order_entries(c) : 0;
+    a.split_ok = a.tile_order && lpt_front(c) > 0 && c->frame_parts == 1 && !c->frame_capped && c->n_rounds == 1;
     a.parts = c->frame_parts;                                                // as the frame's own launches (tile clocks: one wave per tile only)
     if (c->dbg_win_len > 0) {                                                // gs_debug_set_window: a slice of the launch order
         if (!a.tile_order || a.parts > 1) return fail(c, GS_ERR_INVALID, "gs_debug_set_window: the frame has no launch order (or several waves per tile)");
@@ -223,16 +224,28 @@ int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
     if (bind_device(c)) return GS_ERR_HIP;
     const size_t ntiles = (size_t)c->gx * c->gy;
     GsCompositeArgs a{};
+    const bool by_block = variant < 0;                                        // negative variant: records per WORKGROUP (launches with split tiles):
+    if (by_block) variant = -variant;                                         // out holds gs_debug_tile_clock_rows() rows
     if (int rc = debug_composite_args(c, which, variant, a)) return rc;
-    HIPCHK(c, c->tile_clock.ensure(sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * (ntiles ? ntiles : 1)));
-    HIPCHK(c, hipMemsetAsync(c->tile_clock.p, 0, sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * ntiles, c->stream));
+    if (by_block) {
+        if (!a.tile_order || (a.variant / 10) % 10 == 1) return fail(c, GS_ERR_INVALID, "gs_debug_tile_clock: records by workgroup need the frame's launch order");
+        a.clock_by_block = 1;
+    } else a.split_ok = 0;                                                    // records by tile: whole tiles only
+    const size_t rows = a.clock_by_block ? (size_t)lpt_order_entries(c) : ntiles;
+    HIPCHK(c, c->tile_clock.ensure(sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * (rows ? rows : 1)));
+    HIPCHK(c, hipMemsetAsync(c->tile_clock.p, 0, sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * rows, c->stream));
     a.tile_clock = c->tile_clock.as<unsigned long long>();
     for (int rep = 0; rep < 2; ++rep) {                                       // the second launch (warm) is the one kept
         HIPCHK(c, which == 0 ? gs_launch_composite_fwd(a, c->stream) : gs_launch_composite_bwd(a, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(out, c->tile_clock.p, sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * ntiles, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->tile_clock.p, sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * rows, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return GS_OK;
+}
+
+int gs_debug_tile_clock_rows(gs_ctx *c) {
+    if (!c) return GS_ERR_INVALID;
+    return lpt_schedule(c) ? lpt_order_entries(c) : 0;
 }
 
 int gs_debug_clock_mhz(gs_ctx *c, float *mhz) {

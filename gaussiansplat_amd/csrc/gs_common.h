@@ -287,6 +287,10 @@ struct GsCompositeArgs {
     // tile's list on its own (gs_config.tile_parts; single-round frames with the early-out and full lists only).  Block b of the launch
     // is part b / len of tile (order[]) b % len, len = the launch length of one part.
     int parts;
+    // heavy tiles (tile_lpt_order_kernel, front region): the order's entries may name a part of a tile.  split_ok = 0: this launch composites
+    // whole tiles (capped lists, slab rounds, no early-out): a split tile's first part stands for the tile, its other parts do nothing.
+    int split_ok;
+    int clock_by_block;        // debug (tile_clock): records indexed by workgroup instead of by tile (launches with split tiles)
 };
 // the written entries of capped lists, summed over the tiles: out[0] = sum ext[t].x
 hipError_t gs_launch_sum_listed(const uint2 *ext, int n, unsigned long long *out, hipStream_t s);
@@ -299,8 +303,12 @@ int gs_lpt_order_len(int gx, int gy);
 hipError_t gs_launch_clock_probe(unsigned long long *out, hipStream_t s);
 // out[0] = sum of a[0 .. n), out[1] = sum of b[0 .. n) (64 bit): the per-tile work counters of a composite launch, on demand
 hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsigned long long *out, hipStream_t s);
+// front (a multiple of 24; 0: none): entries reserved at the start of `order` for the extra parts of split tiles (tiles with at least
+// sum(work) / split_div work: two parts, from twice that: four; the front / 24 heaviest tiles of every XCD are eligible, three entries
+// each); the ordinary entries start at order[front]
+#define GS_LPT_FRONT 2304
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
-                                    unsigned long long *zero14 = nullptr, int buckets = 0);
+                                    unsigned long long *zero14 = nullptr, int buckets = 0, int front = 0, int split_div = 1);
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);
 

@@ -70,22 +70,31 @@ __device__ __forceinline__ float vgpr_const(float x) { float r; asm volatile("v_
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // The tile of this workgroup: its own index, or -- plain launch over a launch order (gs_config.schedule 3 / 4) -- order[blockIdx]
-// (holes of the order: GS_LPT_NONE).  -1: nothing to do.
-__device__ __forceinline__ int tile_of_block(const GsCompositeArgs &a, int ntiles, int &part) {
+// (holes of the order: GS_LPT_NONE).  -1: nothing to do.  nparts / part: the waves that share the tile and which of them this is --
+// the same for every tile (a.parts: small grids), or per tile, carried by the order entry: tile | part << 28 | log2(nparts) << 30
+// (tile_lpt_order_kernel splits the tiles whose work stands far above the rest: a trained scene's heavy tail).
+#define GS_ORDER_TILE_MASK 0x0FFFFFFFu
+__device__ __forceinline__ int tile_of_block(const GsCompositeArgs &a, int ntiles, int &part, int &nparts) {
     const int len = (a.tile_order && a.order_len > 0) ? a.order_len : ((ntiles + 7) / 8) * 8;   // composite_grid(): blocks of one part
     int b = (int)blockIdx.x;
-    part = 0;
+    part = 0; nparts = a.parts > 1 ? a.parts : 1;
     if (a.parts > 1) { part = b / len; b -= part * len; if (part >= a.parts) return -1; }   // the parts of a tile: same XCD (len % 8 == 0)
     if (a.tile_order) {
         if (b >= (a.order_len > 0 ? a.order_len : ntiles)) return -1;
-        const uint32_t t = a.tile_order[b];
+        uint32_t t = a.tile_order[b];
+        if (t == 0xFFFFFFFFu) return -1;
+        if (a.parts <= 1 && (t >> 28)) {                                  // a split tile's entry
+            part = (int)((t >> 28) & 3u); nparts = 1 << (t >> 30);
+            if (!a.split_ok) { if (part) return -1; nparts = 1; }         // this launch composites whole tiles only: part 0 stands for the tile
+        }
+        t &= GS_ORDER_TILE_MASK;
         return t < (uint32_t)ntiles ? (int)t : -1;
     }
     return b < ntiles ? b : -1;
 }
-// the pixel strips (slots) part `part` of a tile owns: all four, a pair, or one
-__device__ __forceinline__ uint32_t strips_of_part(const GsCompositeArgs &a, int part) {
-    return a.parts == 4 ? (1u << part) : a.parts == 2 ? (3u << (2 * part)) : 0xFu;
+// the pixel strips (slots) part `part` of a tile's `nparts` owns: all four, a pair, or one
+__device__ __forceinline__ uint32_t strips_of_part(int nparts, int part) {
+    return nparts == 4 ? (1u << part) : nparts == 2 ? (3u << (2 * part)) : 0xFu;
 }
 
 __device__ __forceinline__ unsigned long long wave_hw_id() {
@@ -246,7 +255,7 @@ template <bool EARLY, bool CULL, bool CLK, bool SLAB>
 // K = 2 or 1 slots per entry instead of 4.  A packed slot carries its own x (the shared per-lane column is gone), so a slot costs
 // 18 VALU instructions instead of 12 + 6 shared: K = 2 is 36 against 54, K = 1 is 18.  Every pixel sees the same entries in the same
 // order with the same arithmetic, so the image and the transmittance are bit-identical to the unpacked walk.
-__device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, const int part, float4 *sp, float *syhi, const float nbig) {
+__device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, const int part, const int nparts, float4 *sp, float *syhi, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
@@ -274,8 +283,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     bool dead[4];
     uint32_t walked = 0, evaluated = 0;
     constexpr bool PACK = GS_FWD_PACK && EARLY && !SLAB;
-    const uint32_t own = (EARLY && !SLAB) ? strips_of_part(a, part) : 0xFu;   // tile_parts > 1: the strips this wave composites
-    bool first_pack = PACK && a.parts > 1;                              // ... packed into K = 2 / 1 slots at the first batch
+    const uint32_t own = (EARLY && !SLAB) ? strips_of_part(nparts, part) : 0xFu;   // several waves per tile: the strips this wave composites
+    bool first_pack = PACK && nparts > 1;                              // ... packed into K = 2 / 1 slots at the first batch
     int K = 4;                                                          // slots per entry: 4 = the tile's pixels in place; 2 / 1 = live pixels packed
     // packed: slots 2 and 3 hold no pixel, and fy[2], fy[3] hold the x of the pixels in slots 0 and 1 (0 = the slot is empty)
 #pragma unroll
@@ -548,7 +557,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         }
     }
     if (CLK && a.tile_clock && lane == 0) {
-        unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)tile;
+        unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)(a.clock_by_block ? (int)blockIdx.x : tile);
         c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
         c[3] = ((unsigned long long)walked << 32) | evaluated;
         c[4] = t_loop; c[5] = t_stage;
@@ -568,9 +577,9 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     if (a.zero_words && blockIdx.x == 0 && threadIdx.x < 2) a.zero_words[threadIdx.x] = 0ull;
-    int part;
-    const int tile = tile_of_block(a, ntiles, part);
-    if (tile >= 0) forward_tile<EARLY, CULL, CLK, SLAB>(a, tile, part, sp, syhi, nbig);
+    int part, nparts;
+    const int tile = tile_of_block(a, ntiles, part, nparts);
+    if (tile >= 0) forward_tile<EARLY, CULL, CLK, SLAB>(a, tile, part, nparts, sp, syhi, nbig);
 }
 
 // ---------------------------------------------------------------- wave64 reduction of the nine per-splat sums
@@ -646,8 +655,8 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
 }
 
 template <bool EARLY, bool DET, bool CULL, bool CLK>
-__device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, const int part, float4 *sp, float *syhi, uint32_t *sid, uint32_t *sstrip,
-                                              float *red, const float nbig) {
+__device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, const int part, const int nparts, float4 *sp, float *syhi, uint32_t *sid,
+                                              uint32_t *sstrip, float *red, const float nbig) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
@@ -666,7 +675,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     float dCr[4], dCg[4], dCb[4], T[4], S[4], fy[4];
     bool dead[4];
     uint32_t walked = 0, evaluated = 0;
-    const uint32_t own = EARLY ? strips_of_part(a, part) : 0xFu;          // tile_parts > 1 (frames with the early-out): the strips this wave differentiates
+    const uint32_t own = EARLY ? strips_of_part(nparts, part) : 0xFu;     // several waves per tile (frames with the early-out): the strips this wave differentiates
     // (Packing the live pixels into one slot once 64 or fewer are left -- what the forward does -- was built for this kernel too and
     // measured equal to slower, same box: the per-splat reduction, which packing does not shorten, is too large a share of an entry, and
     // the packed loop cost the kernel 18 spilled registers: profiles/r04g_ab_backward_packing.log.)
@@ -819,7 +828,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         if (a.tile_work) a.tile_work[tile] = evaluated;
     }
     if (CLK && a.tile_clock && lane == 0) {
-        unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)tile;
+        unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)(a.clock_by_block ? (int)blockIdx.x : tile);
         c[0] = clk0; c[1] = __builtin_amdgcn_s_memrealtime(); c[2] = wave_hw_id();
         c[3] = ((unsigned long long)walked << 32) | evaluated;
         c[4] = t_loop; c[5] = t_stage;
@@ -836,9 +845,9 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     __shared__ __attribute__((aligned(16))) float red[RED_FLOATS];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
-    int part;
-    const int tile = tile_of_block(a, ntiles, part);
-    if (tile >= 0) backward_tile<EARLY, DET, CULL, CLK>(a, tile, part, sp, syhi, sid, sstrip, red, nbig);
+    int part, nparts;
+    const int tile = tile_of_block(a, ntiles, part, nparts);
+    if (tile >= 0) backward_tile<EARLY, DET, CULL, CLK>(a, tile, part, nparts, sp, syhi, sid, sstrip, red, nbig);
 }
 
 // Longest-first order for a PLAIN launch (gs_config.schedule 3 / 4).  The dispatcher hands workgroups out in blockIdx order,
@@ -873,10 +882,19 @@ static inline int lpt_group_side(int gx, int gy) {
 }
 int gs_lpt_order_len(int gx, int gy) { const int gs = lpt_group_side(gx, gy); return 8 * gs * gs * ((lpt_groups(gx, gy, gs) + 7) / 8); }
 
+// (3) SPLIT TILES (round 5; front > 0).  A trained scene's work is heavy-tailed: a tile whose list is ten times the median is one wave64
+//     running alone long after the rest of the chip has drained (measured on the clustered scene of tools/clustered_probe.py: 55 % of the
+//     SIMD time idle).  A tile whose work is at least (sum of all work) / split_div -- about what a wave slot gets when the work is spread
+//     evenly -- is composited by two waves, from twice that by four, each owning two or one of the tile's four 16 x 4 pixel strips (the
+//     machinery of gs_config.tile_parts).  Its first part keeps the tile's place in the order (entry = tile | log2(parts) << 30); the other
+//     parts go to the FRONT region order[0 .. front) -- they are among the heaviest units of the launch and must start first.  Only the
+//     front / 24 heaviest tiles of every XCD's list are eligible (the heaviest must never be the one left whole): the tile at position
+//     pos of XCD x owns the entries order[8 (3 pos + j) + x], j = 0 .. 2.  The ordinary entries follow from order[front] on; unused
+//     entries of the front region hold GS_LPT_NONE (an empty workgroup).  front = 0: no tile is split.
 __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int gx, int ng, int gs, int nb,
-                                                               uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14) {
+                                                               uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14, int front, int split_div) {
     extern __shared__ uint32_t lds[];
-    __shared__ uint32_t wmax;
+    __shared__ uint32_t wmax, wtot;
     __shared__ uint32_t rowtot[8 * 32], rowstart[8 * 32], xcount[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int GT = gs * gs;                                              // tiles of a full group (gs = 8, 4, 2 or 1: a power of two)
@@ -891,6 +909,7 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
     uint16_t *ginfo = pre + rows * W;                                    // [ng] XCD | ordinal << 3
     uint8_t *cls = reinterpret_cast<uint8_t *>(ginfo + ng + (ng & 1) + ((rows * W) & 1));   // [ntiles]
     for (int i = tid; i < rows * W + ng; i += 1024) bm[i] = 0;          // bitmap and group sums
+    for (int i = tid; i < front; i += 1024) order[i] = GS_LPT_NONE;     // the front region: filled by the split tiles at the very end
     if (tid == 0) wmax = 1;
     if (zero14 && tid < 14) zero14[tid] = 0ull;
     __syncthreads();
@@ -924,6 +943,13 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
     for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
     if (lane == 0) atomicMax(&wmax, m);
     __syncthreads();
+    if (wv == 0) {                                                       // the frame's total work (the group sums are complete)
+        uint32_t sw = 0;
+        for (int g = lane; g < ng; g += 64) sw += gsum[g];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sw += (uint32_t)__shfl_xor((int)sw, d);
+        if (lane == 0) wtot = sw;
+    }
     // rank of every group by work (ties by index), dealt in snake order: round r = rank / 8 gives each XCD one group
     for (int g = tid; g < ng; g += 1024) {
         const uint32_t mine = gsum[g];
@@ -971,19 +997,30 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
         xcount[tid] = run;
     }
     __syncthreads();
+    uint32_t *main_order = order + front;
     for (int i = tid; i < 8 * per; i += 1024)                            // holes behind the shorter lists
-        if ((uint32_t)(i >> 3) >= xcount[i & 7]) order[i] = GS_LPT_NONE;
+        if ((uint32_t)(i >> 3) >= xcount[i & 7]) main_order[i] = GS_LPT_NONE;
+    const uint32_t thr = front > 0 ? max(wtot / (uint32_t)max(split_div, 1), 256u) : 0xFFFFFFFFu, eligible = (uint32_t)front / 24u;
     for (int t = tid; t < ntiles; t += 1024) {
         int local;
         const uint32_t gi = ginfo[group_of(t, local)];
         const int x = (int)(gi & 7u), r = x * nb + cls[t], i = (int)(gi >> 3) * GT + local;
         const uint32_t pos = rowstart[r] + pre[r * W + (i >> 5)] + (uint32_t)__popc(bm[r * W + (i >> 5)] & ((1u << (i & 31)) - 1u));
-        order[8u * pos + (uint32_t)x] = (uint32_t)t;
+        uint32_t entry = (uint32_t)t;
+        if (pos < eligible) {                                            // among the heaviest of its XCD (front = 0: nobody)
+            const uint32_t w = ranges_mode ? src[2 * t + 1] - src[2 * t] : src[t];
+            if (w >= thr) {
+                const uint32_t pc = w >= 2u * thr ? 2u : 1u, extra = (1u << pc) - 1u;
+                for (uint32_t j = 0; j < extra; ++j) order[8u * (3u * pos + j) + (uint32_t)x] = (uint32_t)t | ((j + 1u) << 28) | (pc << 30);
+                entry |= pc << 30;
+            }
+        }
+        main_order[8u * pos + (uint32_t)x] = entry;
     }
 }
 
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
-                                    unsigned long long *zero14, int buckets) {
+                                    unsigned long long *zero14, int buckets, int front, int split_div) {
     const int ntiles = gx * gy;
     if (ntiles <= 0) return hipSuccess;
     if (ntiles > GS_LPT_MAX_TILES) return hipErrorInvalidValue;          // beyond 8K-class images: the callers keep launch order
@@ -997,7 +1034,8 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_lpt_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, gx, ng, gs, nb, order, zero14);
+    if (front < 0 || (front % 24) || ntiles > (int)GS_ORDER_TILE_MASK) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, gx, ng, gs, nb, order, zero14, front, split_div);
     return hipGetLastError();
 }
 
@@ -1053,7 +1091,7 @@ static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {           // 
 // variant (debug launches, gs_debug_time_composite / gs_debug_tile_clock): tens digit 1 = tile order instead of the frame's launch order
 static GsCompositeArgs apply_sched_variant(const GsCompositeArgs &a0) {
     GsCompositeArgs a = a0;
-    if ((a.variant / 10) % 10 == 1) { a.tile_order = nullptr; a.order_len = 0; }
+    if ((a.variant / 10) % 10 == 1) { a.tile_order = nullptr; a.order_len = 0; a.split_ok = 0; }
     return a;
 }
 
@@ -1064,6 +1102,7 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
     if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.tile_pos || a.tile_clock)) return hipErrorInvalidValue;
+    if (a.split_ok && (!early || a.tile_ext || a.tile_pos || a.parts > 1)) return hipErrorInvalidValue;   // split entries: frames with the early-out, full lists, one round
     if (a.tile_ext && (gs_bin3_seg() != L2_SEG || !early || !a.cranges || !a.cids || !a.clr || !a.ids_w || a.tile_pos)) return hipErrorInvalidValue;
     if (a.tile_pos) {                                                     // a round of a slab frame (t_min > 0 by construction: plan_rounds)
         if (!early || a.tile_clock) return hipErrorInvalidValue;
@@ -1095,6 +1134,7 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
     const bool early = a.t_min > 0.0f;
     const dim3 grid = composite_grid(a, ntiles), block(64);
     if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.nseg > 1 || a.tile_clock)) return hipErrorInvalidValue;
+    if (a.split_ok && (!early || a.tile_ext || a.nseg > 1 || a.parts > 1)) return hipErrorInvalidValue;
 #define GS_B2(E, D) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, true>), grid, block, 0, s, a); \
                          else hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, false>), grid, block, 0, s, a); } while (0)
 #define GS_B(E) do { if (a.g2d_fixed) GS_B2(E, true); else GS_B2(E, false); } while (0)

@@ -221,6 +221,16 @@ inline int bind_device(gs_ctx *c) {
 inline bool lpt_schedule(const gs_ctx *c) {
     return (c->cfg.schedule == 3 || c->cfg.schedule == 4) && ((int64_t)c->gx * c->gy > c->wave_slots || (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER));
 }
+// Heavy tiles (round 5): the launch orders reserve a front region for the extra parts of split tiles (tile_lpt_order_kernel) when the
+// ctx may use them at all: automatic tile_parts, the early-out on, and a grid on which the frame-wide 2 / 4 waves per tile cannot engage.
+// A property of the ctx and the grid, so every order of a slot has one layout; whether a LAUNCH honours the split entries is decided
+// per frame (split_ok: full lists, one binning round).
+inline int lpt_front(const gs_ctx *c) {
+    const int64_t ntiles = (int64_t)c->gx * c->gy;
+    return (lpt_schedule(c) && c->cfg.tile_parts == 0 && c->cfg.t_min > 0.0f && 2 * ntiles > c->wave_slots && ntiles <= GS_LPT_MAX_TILES) ? GS_LPT_FRONT : 0;
+}
+inline int lpt_order_entries(const gs_ctx *c) { return lpt_front(c) + gs_lpt_order_len(c->gx, c->gy); }   // = workgroups of a launch over the order
+inline int lpt_split_div(const gs_ctx *c) { return c->wave_slots * 4 / 5; }      // a tile with more work than an even share of ~4 waves per SIMD is split
 // The side stream (order kernel beside the backward) costs four more runtime calls per frame: it pays when the composite kernels
 // are long, and costs when the frame is bound by the host's launch rate (config C2, together with the zero fill it once carried: + 9 %).
 inline bool use_side_stream(const gs_ctx *c) { return c->n >= 262144 || (c->cfg.debug_flags & GS_DEBUG_ALWAYS_ORDER); }

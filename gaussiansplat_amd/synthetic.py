@@ -32,12 +32,19 @@ def scene_camera(W: int, view: int = 0) -> Camera:
     return cam
 
 
-def make_scene(n: int, W: int, H: int, sh_degree: int, seed: int = 1234):
+def make_scene(n: int, W: int, H: int, sh_degree: int, seed: int = 1234, clustered: bool = False, raw_quaternions: bool = False):
     """Returns dict(means[n,3], scales[n,3], quats[n,4], opacities[n], shs[n,K,3]) float32.
 
     Quaternions are drawn N(0,1)^4 and normalised HERE: the reference kernel does not
     normalise (projection.jl:126) and applies R four times (J*R*Sigma*(J*R)'), so raw N(0,1)
     draws would inflate every footprint by |q|^4; trained scenes carry near-unit quaternions.
+    raw_quaternions = True leaves them as drawn, exactly as SURVEY 8d words the scene.
+
+    clustered = True: a HEAVY-TAILED scene in the shape of a trained one (what splat.jl:106-119 loads) instead of the spatially
+    uniform BASELINE scene: 60 % of the gaussians sit in three blobs that cover 5 % of the frame and are faint (opacity logits
+    U(-5, -2): their tiles walk thousands of entries before they saturate), and 0.1 % are huge (scale logits U(-0.6, 0.2): footprints
+    of hundreds of pixels, in the list of hundreds of tiles each).  The rest is the uniform scene.  Tile lists beyond the reference's
+    UInt16 limit of 65 535 entries (forward.jl:137,141) at 1080p-class sizes.
     """
     rng = np.random.default_rng(seed)
     fx = 3200.0 * W / 1920.0
@@ -53,6 +60,21 @@ def make_scene(n: int, W: int, H: int, sh_degree: int, seed: int = 1234):
     K = (sh_degree + 1) ** 2
     shs = (rng.standard_normal((n, K, 3)) * 0.1).astype(np.float32)
     shs[:, 0, :] = (rng.standard_normal((n, 3)) * 0.3).astype(np.float32)
+    if raw_quaternions:
+        quats = q.astype(np.float32)
+    if clustered:
+        r2 = np.random.default_rng(seed + 77)                                   # (a stream of its own: the uniform scene above is untouched)
+        kind = r2.random(n)
+        blob = kind < 0.6
+        huge = kind > 0.999
+        centres = np.array([[-0.25, 0.10], [0.20, -0.22], [0.30, 0.28]]) * np.array([Wv, Hv])
+        rb = np.sqrt(0.05 * Wv * Hv / (3.0 * np.pi))                            # three discs of this radius cover 5 % of the frame
+        which = r2.integers(0, 3, n)
+        ang, rad = r2.uniform(0.0, 2.0 * np.pi, n), rb * np.sqrt(r2.random(n))
+        means[blob, 0] = (centres[which, 0] + rad * np.cos(ang))[blob]
+        means[blob, 1] = (centres[which, 1] + rad * np.sin(ang))[blob]
+        opacities[blob] = r2.uniform(-5.0, -2.0, n).astype(np.float32)[blob]
+        scales[huge] = r2.uniform(-0.6, 0.2, (n, 3)).astype(np.float32)[huge]
     return dict(means=means, scales=scales, quats=quats, opacities=opacities, shs=shs)
 
 

@@ -394,6 +394,10 @@ int gs_debug_time_composite(gs_ctx *ctx, int which, int variant, int reps, float
  * and the entries that would survive the no-op test against the rectangle of the live pixels instead of the whole tile}.
  * tools/tile_tail.py turns it into the occupancy-over-time, tail and frozen-pixel summaries under profiles/. */
 int gs_debug_tile_clock(gs_ctx *ctx, int which, int variant, uint64_t *out);
+/* A NEGATIVE variant v runs variant -v with one record per WORKGROUP of the launch instead of per tile -- the launch as production runs
+ * it, heavy tiles split into two or four waves (the parts of a split tile would overwrite each other's per-tile record): out then
+ * holds gs_debug_tile_clock_rows(ctx) rows of 15 words, rows of workgroups without a tile all zero.  0: the frame has no launch order. */
+int gs_debug_tile_clock_rows(gs_ctx *ctx);
 
 /* Profiling hook: the shader clock (MHz) the chip runs at right now, from one wave that counts s_memtime cycles over 20 us of
  * s_memrealtime on the ctx stream (waits for the stream).  tools/frames_probe.py samples it between frames. */

@@ -287,6 +287,7 @@ function hip_debugTileClock(r::HipRenderer, which::Integer, variant::Integer, nt
     check(r, ccall((:gs_debug_tile_clock, libgs), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), r.ctx, which, variant, out))
     return out
 end
+hip_debugTileClockRows(r::HipRenderer) = ccall((:gs_debug_tile_clock_rows, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 function hip_clockMHz(r::HipRenderer)
     mhz = Ref{Cfloat}(0f0)
     check(r, ccall((:gs_debug_clock_mhz, libgs), Cint, (Ptr{Cvoid}, Ref{Cfloat}), r.ctx, mhz))

@@ -94,9 +94,99 @@ def test_automatic_choice_and_frames_without_early_out(oracle):
             ctx.close()
         assert np.array_equal(res[0][0], res[expect][0]) and np.array_equal(res[0][1], res[expect][1])
         for k in GRADS:
-            assert np.array_equal(res[0][2][k], res[expect][2][k]), k
+            if expect > 1:
+                assert np.array_equal(res[0][2][k], res[expect][2][k]), k
+            else:       # a grid with a launch order: the automatic mode may split the few tiles that stand above an even share (below)
+                assert rel_l2(res[0][2][k], res[expect][2][k]) <= 1e-5, k
     sc, cam, T, P, ocam = scene_and_cameras(3_000, 160, 96, 1, 9)
     ctx = hip_context(sc, cam, T, P, 160, 96, 1, order=1, t_min=0.0, tile_parts=4)
     ctx.preprocess(); ctx.bin(); ctx.forward_host()
     assert ctx.tile_parts_of_frame() == 1
+    ctx.close()
+
+
+# ---------------------------------------------------------------- heavy tiles split by the launch order (round 5)
+ALWAYS_ORDER = 2
+FRONT = 2304          # GS_LPT_FRONT: entries of a launch order reserved for the extra waves of split tiles
+
+
+def _slot_frames(ctx, dC, deg, nframes=2):
+    """frames under one view slot: from the second on the forward runs on the slot's launch order (with its split tiles)"""
+    out = None
+    for _ in range(nframes):
+        ctx.set_view_slot(0)
+        out = _frame(ctx, dC, deg)
+    return out
+
+
+def _split_units(ctx, cull=True):
+    """records of the launch order's front region = the extra waves of split tiles in a (debug) forward launch over the last frame's
+    order (the clocked kernels exist with the no-op cull only: + 1000 = the other cull setting than the ctx's)"""
+    clk = ctx.tile_clock(0, -30 if cull else -1030)
+    return int((clk[:FRONT, 1] > 0).sum()), clk
+
+
+@pytest.mark.parametrize("cull", [False, True])
+def test_heavy_tiles_split_by_the_launch_order(oracle, cull):
+    """A heavy-tailed scene (synthetic.make_scene(clustered=True): what a trained .ply looks like, splat.jl:106-119) on a grid with a
+    launch order: tiles whose work stands far above an even share run as two or four waves, chosen per tile by tile_lpt_order_kernel.
+    Same bars as the frame-wide partitions: image / transmittance bit-identical to whole tiles with the cull off, 1e-6 with it on;
+    gradients 1e-5 between partitions (deterministic mode); the oracle bars either way."""
+    from gaussiansplat_amd import synthetic
+    O = oracle
+    n, W, H, deg, seed = 150_000, 1024, 768, 1, 1236                          # 64 x 48 = 3072 tiles: too many for frame-wide 2 waves per tile
+    sc = synthetic.make_scene(n, W, H, deg, seed=seed, clustered=True)
+    _, cam, T, P, ocam = scene_and_cameras(16, W, H, deg, seed)
+    dC = synthetic.make_dC(W, H, seed)
+    res = {}
+    for parts in (1, 0):
+        ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5, tile_parts=parts, alpha_cull=cull, deterministic=True, debug_flags=ALWAYS_ORDER)
+        res[parts] = _slot_frames(ctx, dC, deg)
+        if parts == 0:                                                         # (tile_parts = 1: the orders have no front region at all)
+            units, clk = _split_units(ctx, cull)
+            assert units >= 8, units                                           # the blobs' tiles are split
+        ctx.close()
+    a, b = res[1], res[0]
+    if not cull:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    else:
+        assert np.abs(a[0] - b[0]).max() <= 1e-6 and np.abs(a[1] - b[1]).max() <= 1e-6
+    for k in GRADS:
+        assert rel_l2(b[2][k], a[2][k]) <= 1e-5, (k, rel_l2(b[2][k], a[2][k]))
+    if cull:                                                                   # against the oracle, with the production settings
+        ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+        gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC, t_min=1e-5, omp=True)
+        img, tr, grads = b[0], b[1], b[2]
+        assert np.all(np.abs(img - ref["image"]) <= PIX_ATOL + PIX_RTOL * np.abs(ref["image"])), np.abs(img - ref["image"]).max()
+        assert np.all(np.abs(tr - ref["trans"]) <= PIX_ATOL + PIX_RTOL * np.abs(ref["trans"]))
+        for k in GRADS:
+            e = rel_l2(grads[k], np.asarray(gref[k]).reshape(grads[k].shape))
+            assert e <= GRAD_REL_L2, (k, e)
+
+
+def test_split_entries_are_whole_tiles_for_capped_lists_and_uniform_scenes():
+    """(a) a launch that composites whole tiles only (capped lists) under an order with split entries: the first part stands for the tile,
+    the others do nothing -- bits as without the order's splits; (b) the uniform BASELINE scene splits nothing."""
+    from gaussiansplat_amd import synthetic
+    n, W, H, deg, seed = 120_000, 1024, 768, 1, 1236
+    sc = synthetic.make_scene(n, W, H, deg, seed=seed, clustered=True)
+    _, cam, T, P, ocam = scene_and_cameras(16, W, H, deg, seed)
+    dC = synthetic.make_dC(W, H, seed)
+    res = {}
+    for name, kw in (("whole", dict(tile_parts=1, list_cap=1)), ("capped_under_split_order", dict(tile_parts=0, list_cap=2))):
+        ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5, deterministic=True, debug_flags=ALWAYS_ORDER, **kw)
+        res[name] = _slot_frames(ctx, dC, deg, nframes=3) + (ctx.list_stats(),)
+        ctx.close()
+    a, b = res["whole"], res["capped_under_split_order"]
+    assert b[4]["capped"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for k in GRADS:
+        assert np.array_equal(a[2][k], b[2][k]), k
+    # the uniform BASELINE scene on a grid with more tiles than wave slots: no tile stands above an even share
+    n, W, H = 250_000, 1920, 1080
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
+    sc["scales"] = (sc["scales"] + np.float32(0.6)).astype(np.float32)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5)
+    _slot_frames(ctx, synthetic.make_dC(W, H, seed), deg)
+    assert _split_units(ctx)[0] == 0
     ctx.close()
