@@ -188,6 +188,7 @@ def main():
                     "the driver's W = 5 would time that transient, not the rate a training run sees")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-literal", action="store_true", help="skip the extra literal (t_min=0) measurement")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the extra heavy-tailed scene (synthetic.make_scene(clustered=True)) measurement")
     ap.add_argument("--no-train-iteration", action="store_true", help="skip the extra training-iteration measurement (loss + SGD, N = 1)")
     ap.add_argument("--no-c4-anchor", action="store_true", help="N = 1, C3: skip the extra 8-view batch (the N = 1 anchor of the C4 scaling curve)")
     ap.add_argument("--grad-sync", default="allreduce", choices=["factored", "allreduce"],
@@ -275,8 +276,8 @@ def main():
     cams = {v: camera_of(v) for v in all_views}
     dCs = {v: torch.as_tensor(synthetic.make_dC(W, H, seed + v)).cuda() for v in all_views}
 
-    def make(t_min, profile_stages):
-        return R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene, device=local, order=args.order, t_min=t_min,
+    def make(t_min, profile_stages, sc=None):
+        return R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene if sc is None else sc, device=local, order=args.order, t_min=t_min,
                              profile_stages=profile_stages, alpha_cull=not args.no_cull, rank_mode=args.rank_mode, schedule=args.schedule,
                              list_cap=args.list_cap, debug_flags=args.debug_flags)
 
@@ -560,6 +561,38 @@ def main():
             out["literal_t_min_0"] = {"value": n * k0 / dt0 / 1e6, "unit": "Msplats/s", "ms_per_step": dt0 / k0 * 1e3, "steps": k0,
                                       "stage_ms": {k: round(s / c if c else 0.0, 4) for k, (s, c) in st0.items()}}
         del r0
+    if not args.no_clustered and args.t_min > 0 and extras and args.config in ("C3", "C5"):
+        # A heavy-tailed scene of the same size beside the spatially uniform BASELINE one (trained scenes, splat.jl:106-119):
+        # 60 % of the gaussians in three faint blobs on 5 % of the frame, 0.1 % huge.  Reported, never `value`.
+        gc.collect()
+        torch.cuda.empty_cache()
+        rc = make(args.t_min, 1, synthetic.make_scene(n, W, H, deg, seed=seed, clustered=True))
+        kc = max(2, min(args.steps, 10))
+        dtc = timed(rc, kc, 6, settle_frames=args.settle_frames)
+        stc = stage_stats(rc)
+        cctx = rc._bench_hv.last_ctx
+        wcc = cctx.work_counters_ex()
+        import numpy as _np
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        from tile_tail import analyse as _analyse
+        ev = (cctx.tile_clock(1, 30)[:, 3] & _np.uint64(0xFFFFFFFF)).astype(_np.int64)          # whole tiles: the work as the scene has it
+        try:
+            as_run = _analyse(cctx.tile_clock(1, -30))                                            # the backward launch as production runs it
+            tail = {"mean_over_peak": as_run["mean_over_peak"], "span_us": as_run["span_us"], "simd_time_share_by_resident_waves_0_to_8": as_run["simd_time_share_by_resident_waves_0_to_8"]}
+        except Exception as e:                                                                    # (no launch order on this grid)
+            tail = {"error": str(e)}
+        if rank == 0:
+            ms_c = dtc / kc * 1e3
+            same_work = out["ms_per_step"] * wcc["evaluated_fwd"] / max(wc["evaluated_fwd"], 1)
+            out["clustered"] = {"value": n * kc / dtc / 1e6, "unit": "Msplats/s", "ms_per_step": ms_c, "steps": kc, "instances": cctx.num_instances,
+                                "walked_fwd": wcc["walked_fwd"], "evaluated_fwd": wcc["evaluated_fwd"],
+                                "evaluated_per_tile_max": int(ev.max()), "evaluated_per_tile_median": float(_np.median(ev)),
+                                "stage_ms": {k: round(s / c if c else 0.0, 4) for k, (s, c) in stc.items()},
+                                "backward_tile_tail_as_run": tail,
+                                "uniform_frame_scaled_to_the_same_evaluated_entries_ms": same_work, "over_that": ms_c / same_work,
+                                "what": "synthetic.make_scene(clustered=True): 60 % of the gaussians in three faint blobs covering 5 % of the frame, 0.1 % "
+                                        "with footprints of hundreds of pixels; tiles above an even share of the frame's work run as two or four waves"}
+        del rc
     if not args.no_train_iteration and extras and args.config in ("C1", "C2", "C3"):
         # SURVEY 8(f).2 beside the headline: one iteration of src/train.jl as intended = the fwd+bwd step + the L1/DSSIM loss
         # with its image gradient (gs_loss.hip) + the SGD update; reported, never `value`

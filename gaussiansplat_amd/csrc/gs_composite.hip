@@ -52,6 +52,9 @@
 #ifndef GS_FWD_PACK
 #define GS_FWD_PACK 1               // forward: pack the live pixels into one or two slots once they fit (0: A/B builds)
 #endif
+#ifndef GS_FWD_NO_PREFETCH
+#define GS_FWD_NO_PREFETCH 0        // 1: measurement build -- no payload rows / ids gathered ahead of the early-out decision (exposes the gather latency)
+#endif
 #ifndef GS_FWD_UNROLL
 #define GS_FWD_UNROLL 2             // entries interleaved in the forward's per-entry loop
 #endif
@@ -431,6 +434,11 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             for (int cidx = 0; cidx < 16; ++cidx) cmax = max(cmax, colcnt[cidx]);
             clk_k[0] = (int)((clk_live + 63u) >> 6); clk_k[1] = (int)((rows + 3u) >> 2); clk_k[2] = (int)((cmax + 3u) >> 2);
         }
+#if GS_FWD_NO_PREFETCH                                                  // measurement build (tools/fwd_traffic_split.sh): the rows of a batch are gathered
+        if (base > s0 && pos < s1) {                                    // only once the tile is known to go on: nothing is fetched for nobody
+            const size_t g = a.ids[pos]; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; n3 = pay4[4 * g + 3];
+        }
+#endif
         uint32_t strips;
         bool keep;
         stage_record<false>(n0, n1, n3, qx0, qx1, qy0, qy1, ty0, keep, strips);
@@ -454,11 +462,13 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         __syncthreads();
         base += (uint32_t)cnt; gp += (uint32_t)cnt;
         pos = base + lane;
+#if !GS_FWD_NO_PREFETCH
         {
             if (pos < s1) { const size_t g = id2; n0 = pay4[4 * g]; n1 = pay4[4 * g + 1]; n2 = pay4[4 * g + 2]; n3 = pay4[4 * g + 3]; }
             const uint32_t pos2 = pos + min((uint32_t)CB, s1 - base);                   // (batches after the first start at multiples of CB)
             if (base < s1 && pos2 < s1) id2 = a.ids[pos2];
         }
+#endif
         if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
 // one pixel slot p of one entry (A0, B0: the column terms of the slot's x)
 #define GS_FWD_PIXEL(e, A0, B0, p) do {                                               \

@@ -18,6 +18,13 @@ view's camera, which every rank knows.  So the ranks all-reduce only the geometr
 (11 N floats), all-gather the three floats d rgb per (view, gaussian), and rebuild Δshs = sum_v basis(dir_v) (x) d rgb_v
 locally (gs_sh_grads_from_views): 44 MB all-reduced + 12 MB per view gathered instead of 236 MB all-reduced at 1 M
 gaussians.  Sums over views are taken in view order, so the result is also reproducible run to run.
+
+`sync="touched"` (round 5; gloo-tested, never run on more than one GPU) is "factored" with the colour gradients of a view sent
+as the rows of the gaussians the view TOUCHED only: a view's composite adjoint leaves d rgb = 0 for every gaussian no pixel
+evaluated (63 % of them at C3, 90 % at C5: tools/touched_rows.py), so a view travels as a bitmap of N bits plus 12 bytes per
+touched gaussian -- 0.125 + 4.4 MB instead of 12 MB at C3 -- padded to the largest count among the views (two small
+all-gathers: counts, then bitmaps and rows).  The receiver scatters the rows back and rebuilds the SH gradients as "factored"
+does, so the result is the same, bit for bit.
 """
 from __future__ import annotations
 
@@ -107,15 +114,18 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
         elif world > 1:
             dist.all_reduce(r.flat, op=dist.ReduceOp.SUM, group=group)      # the ONE collective of the step
         return r.flat
-    if sync != "factored":
+    if sync not in ("factored", "touched"):
         raise ValueError(sync)
     if len(cameras) % world:
-        raise ValueError("factored sync needs the same number of views on every rank")
+        raise ValueError("factored / touched sync needs the same number of views on every rank")
     slots = r.color_slots(len(mine))                                        # [len(mine), n, 3] on the renderer's device
     for i, v in enumerate(mine):
         r.render_view_factored(cameras[v], dCs[v], slots[i])                # geometry grads accumulate, d rgb -> slot i
     geo = r.flat[:r.geometry_floats]
-    if world > 1:
+    if world > 1 and sync == "touched":
+        dist.all_reduce(geo, op=dist.ReduceOp.SUM, group=group)             # 11 N floats
+        allc = exchange_touched_rows(slots, world, group, dist)             # per view: N bits + 3 floats per touched gaussian
+    elif world > 1:
         dist.all_reduce(geo, op=dist.ReduceOp.SUM, group=group)             # 11 N floats
         allc = torch.empty(world * slots.numel(), dtype=slots.dtype, device=slots.device)
         dist.all_gather_into_tensor(allc, slots.reshape(-1), group=group)   # 3 N floats per view
@@ -124,6 +134,66 @@ def multi_view_step(r: ViewRenderer, cameras: Sequence, dCs: Sequence, group=Non
         allc = slots
     r.sh_from_views(list(cameras), allc)                                    # overwrites the Δshs part of flat
     return r.flat
+
+
+def pack_touched_rows(slots):
+    """slots [views, N, 3] -> (bits [views, ceil(N / 32)] int32: bit g % 32 of word g / 32 set when view v left gaussian g a non-zero
+    colour gradient; counts [views] int64; rows: list of [count_v, 3] tensors, the touched rows in gaussian order).  Host-side
+    torch plumbing (boolean indexing synchronises); a device kernel would pack in one pass -- not built: no N > 1 hardware to time it on."""
+    import torch
+    V, N, _ = slots.shape
+    touched = (slots != 0).any(dim=2)                                       # an exactly-zero row adds nothing to the SH sums either way
+    words = (N + 31) // 32
+    pad = torch.zeros((V, words * 32), dtype=torch.int64, device=slots.device)
+    pad[:, :N] = touched.to(torch.int64)
+    weights = (torch.ones(32, dtype=torch.int64, device=slots.device) << torch.arange(32, dtype=torch.int64, device=slots.device))
+    bits = (pad.reshape(V, words, 32) * weights).sum(dim=2)
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)      # (two's complement: the 32 bits as stored)
+    rows = [slots[v][touched[v]] for v in range(V)]
+    return bits, touched.sum(dim=1), rows
+
+
+def unpack_touched_rows(bits, counts, rows_padded, N, dtype):
+    """inverse of pack_touched_rows for the gathered views: -> [views, N, 3] with zeros where a view touched nothing"""
+    import torch
+    V, words = bits.shape
+    b = bits.to(torch.int64) & 0xFFFFFFFF
+    shifts = torch.arange(32, dtype=torch.int64, device=bits.device)
+    touched = (((b.unsqueeze(2) >> shifts) & 1) != 0).reshape(V, words * 32)[:, :N]
+    out = torch.zeros((V, N, 3), dtype=dtype, device=bits.device)
+    for v in range(V):
+        out[v][touched[v]] = rows_padded[v, :int(counts[v])]
+    return out
+
+
+def exchange_touched_rows(slots, world, group, dist):
+    """all ranks' views' colour gradients [world * views, N, 3] from this rank's `slots` [views, N, 3], sending per view its bitmap of
+    touched gaussians and their rows only (padded to the largest count among all views of the step)"""
+    import torch
+    V, N, _ = slots.shape
+    bits, counts, rows = pack_touched_rows(slots)
+    all_counts = torch.empty(world * V, dtype=torch.int64, device=slots.device)
+    dist.all_gather_into_tensor(all_counts, counts.to(torch.int64).contiguous(), group=group)
+    cap = max(int(all_counts.max()), 1)
+    mine = torch.zeros((V, cap, 3), dtype=slots.dtype, device=slots.device)
+    for v in range(V):
+        mine[v, :rows[v].shape[0]] = rows[v]
+    all_bits = torch.empty((world * V, bits.shape[1]), dtype=torch.int32, device=slots.device)
+    all_rows = torch.empty((world * V, cap, 3), dtype=slots.dtype, device=slots.device)
+    dist.all_gather_into_tensor(all_bits.reshape(-1), bits.contiguous().reshape(-1), group=group)       # N / 8 bytes per view
+    dist.all_gather_into_tensor(all_rows.reshape(-1), mine.reshape(-1), group=group)                    # 12 bytes per touched gaussian (padded)
+    return unpack_touched_rows(all_bits, all_counts, all_rows, N, slots.dtype)
+
+
+def touched_exchange_bytes(n: int, views_per_rank: int, world: int, touched_share: float, k3: int = 48):
+    """bytes leaving each GPU per step for the three exchanges (ring all-reduce: 2 (w - 1) / w of the buffer; all-gather: w - 1 times the
+    rank's share): {flat, factored, touched} -- the paper figures of DESIGN.md section 6"""
+    ar = lambda b: 2.0 * (world - 1) / world * b
+    ag = lambda b: (world - 1) * b
+    geo = 11 * n * 4
+    return {"allreduce_flat": ar((11 + k3) * n * 4),
+            "factored": ar(geo) + ag(views_per_rank * 3 * n * 4),
+            "touched": ar(geo) + ag(views_per_rank * (n / 8 + 8 + 12 * touched_share * n))}
 
 
 class HipViewRenderer:

@@ -149,12 +149,12 @@ def _worker_split(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def _worker_factored(rank, world, port, out):
+def _worker_factored(rank, world, port, out, sync="factored"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         cams, dCs = _views()
-        flat = D.multi_view_step(OracleFactoredRenderer(), cams, dCs, sync="factored")
+        flat = D.multi_view_step(OracleFactoredRenderer(), cams, dCs, sync=sync)
         if rank == 1:
             np.save(out, flat.numpy())
     finally:
@@ -228,3 +228,41 @@ def test_two_rank_gloo_unequal_shares_post_matching_collectives(tmp_path, nviews
     got, want = np.load(out), single.flat.numpy()
     assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
     assert np.abs(got).max() > 0
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_touched_rows_exchange_equals_factored_and_plain_sum(tmp_path):
+    """the colour gradients of a view travel as a bitmap + the rows of the touched gaussians only.  Same result as the
+    colour-factored exchange bit for bit (the receiver rebuilds the very same [views, N, 3] array), and as the plain sum to fp rounding."""
+    outs = {}
+    for sync in ("factored", "touched"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        outs[sync] = str(tmp_path / f"flat_{sync}.npy")
+        mp.spawn(_worker_factored, args=(2, port, outs[sync], sync), nprocs=2, join=True)
+    a, b = np.load(outs["factored"]), np.load(outs["touched"])
+    assert np.array_equal(a, b)
+    cams, dCs = _views()
+    single = OracleViewRenderer()
+    D.multi_view_step(single, cams, dCs)
+    want = single.flat.numpy()
+    assert np.allclose(b[:11 * N], want[:11 * N], rtol=1e-12, atol=1e-14)
+    assert np.linalg.norm(b[11 * N:] - want[11 * N:]) <= 1e-6 * np.linalg.norm(want[11 * N:])
+
+
+def test_touched_rows_pack_unpack_round_trip_and_bytes():
+    rng = np.random.default_rng(3)
+    for n in (1, 31, 32, 33, 300, 1000):
+        sl = torch.from_numpy(rng.standard_normal((3, n, 3)))
+        sl[rng.random((3, n)) < 0.6] = 0.0                                   # most gaussians untouched
+        sl[1] = 0.0                                                          # a view that touched nothing
+        bits, counts, rows = D.pack_touched_rows(sl)
+        assert bits.shape == (3, (n + 31) // 32) and bits.dtype == torch.int32
+        assert [int(c) for c in counts] == [int((sl[v] != 0).any(dim=1).sum()) for v in range(3)]
+        cap = max(int(counts.max()), 1)
+        padded = torch.zeros((3, cap, 3), dtype=sl.dtype)
+        for v in range(3):
+            padded[v, :rows[v].shape[0]] = rows[v]
+        assert torch.equal(D.unpack_touched_rows(bits, counts, padded, n, sl.dtype), sl)
+    # the paper figures of DESIGN.md section 6: 1 M gaussians, one view per rank, eight ranks, 37 % touched (C3)
+    by = D.touched_exchange_bytes(1_000_000, 1, 8, 0.37)
+    assert round(by["allreduce_flat"] / 1e6) == 413 and round(by["factored"] / 1e6) == 161 and 100 < by["touched"] / 1e6 < 115
