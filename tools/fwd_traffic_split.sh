@@ -3,7 +3,7 @@
 #   production order (8 x 8-tile groups per XCD) / tile order (neighbours on eight XCDs) / a build that gathers nothing ahead of the early-out.
 export TMPDIR=/tmp
 TAG=${1:-r05}
-python3 -m gaussiansplat_amd.build --tag nopf -DGS_FWD_NO_PREFETCH=1 > /dev/null 2>&1 || { echo "variant build failed"; exit 1; }
+[ -f gaussiansplat_amd/lib_nopf/libgsplat_hip.so ] || { echo "build the variant first: python -m gaussiansplat_amd.build --tag nopf -DGS_FWD_NO_PREFETCH=1"; exit 1; }
 O=$PWD/gpurun_out/fwdsplit_$TAG; rm -rf $O; mkdir -p $O
 FWD_SPLIT_HOST_STATS=1 python3 tools/fwd_traffic_split.py 30 4 2>/dev/null | tail -1 > $O/host_stats.json
 for v in "30 lib" "10 lib" "30 lib_nopf"; do
