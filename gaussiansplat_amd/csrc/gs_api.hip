@@ -79,6 +79,9 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
         else (void)hipGetLastError();
     }
     if ((e = hipHostMalloc((void **)&c->pinned, 512, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return hipfail(nullptr, e, "hipHostMalloc"); }
+    if ((e = hipHostMalloc((void **)&c->pinned_split, sizeof(uint32_t) * 2 * (GS_MAX_VIEW_SLOTS + 1), hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) {
+        (void)hipGetLastError(); c->pinned_split = nullptr;              // (speed only: without it every order counts as "may hold split tiles")
+    } else std::memset(c->pinned_split, 0, sizeof(uint32_t) * 2 * (GS_MAX_VIEW_SLOTS + 1));
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
         for (int k = 0; k < 2; ++k)
             if ((e = hipEventCreate(&c->ev[s][k])) != hipSuccess) { delete c; return hipfail(nullptr, e, "hipEventCreate"); }
@@ -106,7 +109,7 @@ int gs_destroy(gs_ctx *c) {
     comm_release(c);
     DevBuf *bufs[] = {&c->payload, &c->depth_key, &c->rect, &c->pairs_a, &c->pairs_b, &c->perm, &c->offsets, &c->block_sums,
                       &c->inst_a, &c->inst_b, &c->table, &c->digit_total, &c->ranges, &c->image, &c->trans, &c->g2d, &c->stage_in,
-                      &c->counters, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
+                      &c->counters, &c->snap, &c->snap_walked, &c->grads_flat, &c->dpc, &c->ids, &c->words, &c->cs, &c->diff,
                       &c->tile_work, &c->tile_clock,
                       &c->tile_pos, &c->tile_done, &c->live2d, &c->rect_r, &c->offsets_r, &c->live_total,
                       &c->rect_sorted, &c->l1_table, &c->l1_rows, &c->l1_partials, &c->cids, &c->clr, &c->cranges, &c->segcnt, &c->sdone, &c->tilecnt,
@@ -124,6 +127,7 @@ int gs_destroy(gs_ctx *c) {
     for (hipEvent_t ev : {c->ev_main, c->ev_order}) if (ev) (void)hipEventDestroy(ev);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned_split) (void)hipHostFree(c->pinned_split);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GS_OK;

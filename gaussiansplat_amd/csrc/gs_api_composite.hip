@@ -14,6 +14,7 @@ const uint32_t *forward_order(gs_ctx *c) {
         if (hipStreamWaitEvent(c->stream, c->ev_order, 0) != hipSuccess) return nullptr;
         c->order_pending = false;
     }
+    c->frame_order_split = c->pinned_split ? c->pinned_split + 2 * k + c->slots[k].sel : nullptr;
     return c->slots[k].order[c->slots[k].sel].as<uint32_t>();
 }
 
@@ -28,19 +29,32 @@ int build_frame_order(gs_ctx *c, const uint32_t *used) {
     const int k = order_index(c);
     const int dst = used ? 1 - c->slots[k].sel : c->slots[k].sel;
     DevBuf &ob = c->slots[k].order[dst];
-    HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)lpt_order_entries(c) + 16)));
+    HIPCHK(c, ob.ensure(sizeof(uint32_t) * ((size_t)lpt_order_entries(c) + GS_SEG_SLOTS + 16)));
+    // heavy tiles: the order kernel also sizes the backward's list segments (from what this forward walked) and re-arms the walked
+    // lengths of the NEXT frame's snapshots (this frame's are being read by its backward)
+    const uint32_t *walked = lpt_front(c) > 0 ? c->last_walked : nullptr;
+    uint32_t *rearm = nullptr, *nsplit = c->pinned_split ? c->pinned_split + 2 * k + dst : nullptr;
+    if (nsplit) *nsplit = 0xFFFFFFFFu;                                     // unknown until the order kernel has stored its count
+    if (lpt_front(c) > 0) {
+        if (!c->snap_walked.p) {
+            HIPCHK(c, c->snap_walked.ensure(sizeof(uint32_t) * 2 * GS_SEG_SLOTS));
+            HIPCHK(c, hipMemsetAsync(c->snap_walked.p, 0, sizeof(uint32_t) * 2 * GS_SEG_SLOTS, c->stream));
+        }
+        rearm = c->snap_walked.as<uint32_t>() + (size_t)(c->snap_parity ^ 1) * GS_SEG_SLOTS;
+    }
     if (used && use_side_stream(c)) {
         if (c->order_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0));      // (never two in flight)
         HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
-        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->side, nullptr, 0, lpt_front(c), lpt_split_div(c)));
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->side, nullptr, 0, lpt_front(c), lpt_split_div(c), walked, rearm, nsplit));
         HIPCHK(c, hipEventRecord(c->ev_order, c->side));
         c->order_pending = true;
         c->slots[k].sel = dst;
         // (tile_work is rewritten by the next forward of this ctx: it waits for ev_order first, see forward_order / gs_forward)
     } else {
-        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->stream, nullptr, 0, lpt_front(c), lpt_split_div(c)));
+        HIPCHK(c, gs_launch_tile_lpt_order(c->tile_work.as<uint32_t>(), 0, c->gx, c->gy, ob.as<uint32_t>(), c->stream, nullptr, 0, lpt_front(c), lpt_split_div(c), walked, rearm, nsplit));
         c->frame_order = ob.as<uint32_t>();
+        c->frame_order_split = nsplit;
     }
     c->slots[k].tiles = ((int64_t)c->gx << 32) | (int64_t)c->gy;
     return GS_OK;
@@ -87,6 +101,18 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.tile_order = order; a.order_len = order ? lpt_order_entries(c) : 0;
     a.parts = c->frame_parts;
     a.split_ok = order && lpt_front(c) > 0 && c->frame_parts == 1 && !c->frame_capped && R == 1;   // heavy tiles run as the order's entries say
+    c->snap_order = nullptr;
+    const bool may_split = !c->frame_order_split || *c->frame_order_split != 0u;   // (the order kernel's count; 0xFFFFFFFF: not reported yet)
+    if (a.split_ok && c->snap_walked.p && may_split) {                      // ... and leave snapshots for the list segments of their backward
+        HIPCHK(c, c->snap.ensure(sizeof(float) * (size_t)GS_SEG_SLOTS * GS_SEG_SNAP_FLOATS));
+        const size_t nt = (size_t)c->gx * c->gy;
+        HIPCHK(c, c->tile_walked_b.ensure(sizeof(uint32_t) * (nt ? nt : 1)));
+        HIPCHK(c, c->tile_work_b.ensure(sizeof(uint32_t) * (nt ? nt : 1)));
+        a.snap = c->snap.as<float>(); a.seg_len = order_seg_len(c, order); a.front = lpt_front(c);
+        a.snap_walked = c->snap_walked.as<uint32_t>() + (size_t)c->snap_parity * GS_SEG_SLOTS;
+        a.bw_walked = c->tile_walked_b.as<uint32_t>(); a.bw_work = c->tile_work_b.as<uint32_t>();
+        c->snap_order = order;
+    }
     if (c->frame_capped && R == 1) {                                        // capped lists: the wave extends its tile's list when it must
         a.tile_ext = c->tile_ext.as<uint2>(); a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>();
         a.ids_w = c->ids.as<uint32_t>(); a.sgx = c->sgx; a.sbs = c->sbs; a.ext_count = c->ext_count();
@@ -126,6 +152,7 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
         HIPCHK(c, hipMemsetAsync(c->tile_pos.p, 0, sizeof(uint32_t) * ntiles, c->stream));
     }
     c->frame_parts = composite_parts(c);
+    c->snap_parity ^= 1;                                                   // (the order kernel behind the previous forward re-armed this parity)
     const uint32_t *order = forward_order(c);
     if (c->order_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_order, 0)); c->order_pending = false; }     // the order kernel in flight reads tile_work
     for (int r = 0; r < R; ++r) {
@@ -222,6 +249,10 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         // launch order: the one the frame's forward used, or (no history) what the order kernel made of that forward
         if (lpt_schedule(c)) { a.tile_order = c->frame_order; a.order_len = c->frame_order ? lpt_order_entries(c) : 0; }
         a.split_ok = a.tile_order && lpt_front(c) > 0 && c->frame_parts == 1 && !c->frame_capped && c->n_rounds == 1;
+        if (a.split_ok && c->snap_order && c->snap_order == a.tile_order) {      // the forward left snapshots for this order's split tiles: list segments
+            a.snap = c->snap.as<float>(); a.seg_len = order_seg_len(c, a.tile_order); a.front = lpt_front(c);
+            a.snap_walked = c->snap_walked.as<uint32_t>() + (size_t)c->snap_parity * GS_SEG_SLOTS;
+        }
         {
             StageTimer t(c, GS_STAGE_COMPOSITE_BWD);                   // the kernel alone (what rocprof reports for it)
             HIPCHK(c, gs_launch_composite_bwd(a, c->stream));

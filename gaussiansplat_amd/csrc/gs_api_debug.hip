@@ -177,6 +177,10 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     a.tile_order = lpt_schedule(c) ? c->frame_order : nullptr;
     a.order_len = a.tile_order ? lpt_order_entries(c) : 0;
     a.split_ok = a.tile_order && lpt_front(c) > 0 && c->frame_parts == 1 && !c->frame_capped && c->n_rounds == 1;
+    if (which == 1 && a.split_ok && c->snap_order && c->snap_order == a.tile_order) {          // the backward's list segments, as the frame ran them
+        a.snap = c->snap.as<float>(); a.seg_len = order_seg_len(c, a.tile_order); a.front = lpt_front(c);
+        a.snap_walked = c->snap_walked.as<uint32_t>() + (size_t)c->snap_parity * GS_SEG_SLOTS;
+    }
     a.parts = c->frame_parts;                                                // as the frame's own launches (tile clocks: one wave per tile only)
     if (c->dbg_win_len > 0) {                                                // gs_debug_set_window: a slice of the launch order
         if (!a.tile_order || a.parts > 1) return fail(c, GS_ERR_INVALID, "gs_debug_set_window: the frame has no launch order (or several waves per tile)");
@@ -230,8 +234,8 @@ int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
     if (by_block) {
         if (!a.tile_order || (a.variant / 10) % 10 == 1) return fail(c, GS_ERR_INVALID, "gs_debug_tile_clock: records by workgroup need the frame's launch order");
         a.clock_by_block = 1;
-    } else a.split_ok = 0;                                                    // records by tile: whole tiles only
-    const size_t rows = a.clock_by_block ? (size_t)lpt_order_entries(c) : ntiles;
+    } else { a.split_ok = 0; a.snap = nullptr; }                              // records by tile: whole tiles only
+    const size_t rows = a.clock_by_block ? (size_t)(lpt_order_entries(c) + gs_seg_units(lpt_front(c))) : ntiles;
     HIPCHK(c, c->tile_clock.ensure(sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * (rows ? rows : 1)));
     HIPCHK(c, hipMemsetAsync(c->tile_clock.p, 0, sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * rows, c->stream));
     a.tile_clock = c->tile_clock.as<unsigned long long>();
@@ -245,7 +249,7 @@ int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
 
 int gs_debug_tile_clock_rows(gs_ctx *c) {
     if (!c) return GS_ERR_INVALID;
-    return lpt_schedule(c) ? lpt_order_entries(c) : 0;
+    return lpt_schedule(c) ? lpt_order_entries(c) + gs_seg_units(lpt_front(c)) : 0;
 }
 
 int gs_debug_clock_mhz(gs_ctx *c, float *mhz) {

@@ -290,6 +290,16 @@ struct GsCompositeArgs {
     // heavy tiles (tile_lpt_order_kernel, front region): the order's entries may name a part of a tile.  split_ok = 0: this launch composites
     // whole tiles (capped lists, slab rounds, no early-out): a split tile's first part stands for the tile, its other parts do nothing.
     int split_ok;
+    // heavy tiles, backward (round 5): a split tile's backward runs as up to GS_SEG_MAX SEGMENTS OF ITS LIST, every segment a whole-tile wave
+    // of its own.  The forward's parts leave, at every seg_len[slot] entries, a snapshot (C, T) of their pixels -- NaN in T: frozen by
+    // then -- in snap[slot][boundary][4][256], and the walked length in snap_walked[slot]; a backward segment starts from the snapshot in
+    // front of it: T as the forward had it, S = (C_final - C_snapshot) . dC.  slot = 8 * (position in the XCD's list) + XCD, positions below
+    // front / 24.  seg_len (null: no segments) lives behind the order's entries; front = entries of the order's front region.
+    float *snap;
+    const uint32_t *seg_len;
+    uint32_t *snap_walked;
+    int front;
+    uint32_t *bw_walked, *bw_work;   // forward: the backward's per-tile counters, zeroed for segmented tiles (its segments ADD to them)
     int clock_by_block;        // debug (tile_clock): records indexed by workgroup instead of by tile (launches with split tiles)
 };
 // the written entries of capped lists, summed over the tiles: out[0] = sum ext[t].x
@@ -307,8 +317,18 @@ hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsi
 // sum(work) / split_div work: two parts, from twice that: four; the front / 24 heaviest tiles of every XCD are eligible, three entries
 // each); the ordinary entries start at order[front]
 #define GS_LPT_FRONT 2304
+#define GS_SEG_MAX 8                 // list segments of a heavy tile's backward (GS_SEG_MAX - 1 snapshots per tile)
+#define GS_SEG_MIN_LEN 1024          // ... none shorter than this many entries
+#define GS_SEG_SLOTS (GS_LPT_FRONT / 3)                          // tiles that may be split: 8 XCDs x GS_LPT_FRONT / 24
+#define GS_SEG_SNAP_FLOATS ((GS_SEG_MAX - 1) * 4 * 256)          // floats of one tile's snapshots
+// walked (with front > 0; may be null): per-tile walked list entries of the forward whose work is ranked -> seg_len[GS_SEG_SLOTS] behind the
+// order's entries (order + front + gs_lpt_order_len): list entries per backward segment of a split tile (0: not split / not segmented);
+// zero_words (may be null): GS_SEG_SLOTS words zeroed on the way (the walked lengths of the NEXT frame's snapshots)
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
-                                    unsigned long long *zero14 = nullptr, int buckets = 0, int front = 0, int split_div = 1);
+                                    unsigned long long *zero14 = nullptr, int buckets = 0, int front = 0, int split_div = 1,
+                                    const uint32_t *walked = nullptr, uint32_t *zero_words = nullptr, uint32_t *host_nsplit = nullptr);
+// host_nsplit (may be null): coherent pinned host word that receives the number of split tiles of the order
+int gs_seg_units(int front);         // workgroups a backward launch with list segments puts in front of the order's
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);
 

@@ -77,9 +77,9 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // the same for every tile (a.parts: small grids), or per tile, carried by the order entry: tile | part << 28 | log2(nparts) << 30
 // (tile_lpt_order_kernel splits the tiles whose work stands far above the rest: a trained scene's heavy tail).
 #define GS_ORDER_TILE_MASK 0x0FFFFFFFu
-__device__ __forceinline__ int tile_of_block(const GsCompositeArgs &a, int ntiles, int &part, int &nparts) {
+__device__ __forceinline__ int tile_of_block(const GsCompositeArgs &a, int ntiles, int &part, int &nparts, int first_block = 0) {
     const int len = (a.tile_order && a.order_len > 0) ? a.order_len : ((ntiles + 7) / 8) * 8;   // composite_grid(): blocks of one part
-    int b = (int)blockIdx.x;
+    int b = (int)blockIdx.x - first_block;
     part = 0; nparts = a.parts > 1 ? a.parts : 1;
     if (a.parts > 1) { part = b / len; b -= part * len; if (part >= a.parts) return -1; }   // the parts of a tile: same XCD (len % 8 == 0)
     if (a.tile_order) {
@@ -243,7 +243,10 @@ __device__ __forceinline__ uint32_t extend_tile_list(const GsCompositeArgs &a, c
 }
 
 // ---------------------------------------------------------------- forward
-template <bool EARLY, bool CULL, bool CLK, bool SLAB>
+template <bool EARLY, bool CULL, bool CLK, bool SLAB, bool SNAP = false>
+// SNAP: the launch order has split tiles whose backward runs as list segments: their forward waves leave snapshots (GsCompositeArgs.snap).
+// An instantiation of its own, chosen by the host from the order kernel's count of split tiles: the snapshot code costs the ordinary
+// kernel six spilled VGPRs at five waves per SIMD, and the BASELINE scenes split nothing.
 // SLAB: the frame is binned in depth slabs (several rounds; resume / tile_pos / tile_done / tile_dead): its own instantiation, the
 // single-round kernel carries none of that state (with it the compiler spilled: 96 VGPRs + 28 bytes of scratch against 90).
 // CLK: per-tile debug clocks (gs_debug_tile_clock); a separate instantiation so that the production kernel carries none of it.
@@ -258,7 +261,8 @@ template <bool EARLY, bool CULL, bool CLK, bool SLAB>
 // K = 2 or 1 slots per entry instead of 4.  A packed slot carries its own x (the shared per-lane column is gone), so a slot costs
 // 18 VALU instructions instead of 12 + 6 shared: K = 2 is 36 against 54, K = 1 is 18.  Every pixel sees the same entries in the same
 // order with the same arithmetic, so the image and the transmittance are bit-identical to the unpacked walk.
-__device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, const int part, const int nparts, float4 *sp, float *syhi, const float nbig) {
+__device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int tile, const int part, const int nparts, float4 *sp, float *syhi, const float nbig,
+                                             const int snap_slot = -1, const uint32_t seg_len = 0) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
@@ -289,6 +293,10 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     const uint32_t own = (EARLY && !SLAB) ? strips_of_part(nparts, part) : 0xFu;   // several waves per tile: the strips this wave composites
     bool first_pack = PACK && nparts > 1;                              // ... packed into K = 2 / 1 slots at the first batch
     int K = 4;                                                          // slots per entry: 4 = the tile's pixels in place; 2 / 1 = live pixels packed
+    // heavy tiles (GsCompositeArgs.snap): at every seg_len entries this wave leaves (C, T) of its pixels for the backward's list segments
+    // (three scalars of state -- the slot, the segment length, the next boundary -- everything else is recomputed where it is used: this
+    // kernel has no SGPR to spare)
+    uint32_t next_snap = (SNAP && snap_slot >= 0) ? seg_len : 0xFFFFFFFFu;
     // packed: slots 2 and 3 hold no pixel, and fy[2], fy[3] hold the x of the pixels in slots 0 and 1 (0 = the slot is empty)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -366,6 +374,10 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
                 if (!dead[p] && T[p] < a.t_min) {                        // frozen from here on: its transmittance is final
                     const float x = (!PACK || K == 4) ? fx : fy[2 + (p & 1)];
                     if (a.trans) a.trans[(uint32_t)((int)x - 1) + (uint32_t)a.W * (uint32_t)((int)fy[p] - 1)] = T[p];
+                    if (SNAP && snap_slot >= 0) {                        // ... and every later snapshot says so (NaN: no segment takes this pixel up again)
+                        float *st = a.snap + (size_t)snap_slot * GS_SEG_SNAP_FLOATS + 768 + ((int)fy[p] - ty0) * GS_TILE + ((int)x - (px - (lane & 15)));
+                        for (int kk = (int)(next_snap / seg_len) - 1; kk < GS_SEG_MAX - 1; ++kk) st[kk * (4 * 256)] = __int_as_float(0x7FC00000);
+                    }
                     dead[p] = true; T[p] = 0.0f; froze = true;
                 }
                 live = live || !dead[p];
@@ -390,6 +402,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
                             const uint32_t o = (uint32_t)((int)x - 1) + (uint32_t)a.W * (uint32_t)((int)fy[p] - 1);
                             a.image[o] = Cr[p]; a.image[o + plane] = Cg[p]; a.image[o + 2u * plane] = Cb[p];
                         }
+
                     }
                     // (2) live pixels -> ranks in slot-then-lane order -> six planes of 128 floats in the staging buffer -> slots 0 .. Kn-1
                     float *buf = reinterpret_cast<float *>(sp);
@@ -419,6 +432,21 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
                     K = Kn;
                 }
             }
+        }
+        if (SNAP && EARLY && !SLAB && gp == next_snap) {                         // (wave-uniform; a batch boundary: seg_len is a multiple of CB)
+            const int ksnap = (int)(next_snap / seg_len) - 1;            // snapshots written so far = index of this one
+            if (ksnap < GS_SEG_MAX - 1) {
+                float *sn = a.snap + (size_t)snap_slot * GS_SEG_SNAP_FLOATS + ksnap * (4 * 256);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (!dead[p]) {
+                        const float x = (!PACK || K == 4) ? fx : fy[2 + (p & 1)];
+                        const int idx = ((int)fy[p] - ty0) * GS_TILE + ((int)x - (px - (lane & 15)));
+                        sn[idx] = Cr[p]; sn[256 + idx] = Cg[p]; sn[512 + idx] = Cb[p]; sn[768 + idx] = T[p];
+                    }
+                }
+            }
+            next_snap += seg_len;
         }
         if (CLK && (phase == 0 || base == s0)) {                         // debug: live pixels / strips with a live pixel in this batch
             clk_live = 0; clk_strips = 0;
@@ -539,8 +567,11 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
             if (lane == 0) a.tile_dead[4 * (size_t)tile + p] = m;
         }
     }
+    if (SNAP && snap_slot >= 0 && lane == 0) {
+        atomicMax(a.snap_walked + snap_slot, gp0 + walked);             // how far the tile's list was walked: the longest walk of its parts
+        if (part == 0) { if (a.bw_walked) a.bw_walked[tile] = 0u; if (a.bw_work) a.bw_work[tile] = 0u; }   // (the backward's segments add theirs)
+    }
     if (lane == 0 && part == 0) {                                       // (tile_parts > 1: the counters of a tile are those of its first part)
-        if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
         if (a.tile_work) a.tile_work[tile] = SLAB && a.resume ? a.tile_work[tile] + evaluated : evaluated;
         if (a.tile_walked) a.tile_walked[tile] = SLAB && a.resume ? a.tile_walked[tile] + walked : walked;
         if (SLAB && a.tile_done) a.tile_done[tile] = all_dead ? 1 : 0;
@@ -580,16 +611,23 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     }
 }
 
-template <bool EARLY, int MINW, bool CULL, bool CLK = false, bool SLAB = false>
+template <bool EARLY, int MINW, bool CULL, bool CLK = false, bool SLAB = false, bool SNAP = false>
 __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
-    if (a.zero_words && blockIdx.x == 0 && threadIdx.x < 2) a.zero_words[threadIdx.x] = 0ull;
     int part, nparts;
     const int tile = tile_of_block(a, ntiles, part, nparts);
-    if (tile >= 0) forward_tile<EARLY, CULL, CLK, SLAB>(a, tile, part, nparts, sp, syhi, nbig);
+    if (tile < 0) return;
+    int snap_slot = -1;
+    uint32_t sl = 0;
+    if (SNAP && EARLY && !SLAB && a.snap && nparts > 1 && a.parts <= 1) {  // a split tile of the order: its slot = 8 x position in the XCD's list + XCD
+        const int b = (int)blockIdx.x, slot = (b < a.front ? ((b >> 3) / 3) : ((b - a.front) >> 3)) * 8 + (b & 7);
+        sl = a.seg_len[slot];
+        if (sl) snap_slot = slot;
+    }
+    forward_tile<EARLY, CULL, CLK, SLAB, SNAP>(a, tile, part, nparts, sp, syhi, nbig, snap_slot, sl);
 }
 
 // ---------------------------------------------------------------- wave64 reduction of the nine per-splat sums
@@ -665,8 +703,12 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
 }
 
 template <bool EARLY, bool DET, bool CULL, bool CLK>
+// snap_in != null / seg_start, seg_end: this wave differentiates list entries [seg_start, seg_end) of the tile only (a heavy tile's backward
+// runs as segments of its list, GsCompositeArgs.snap), starting from the (C, T) the forward left at seg_start (snap_in: [4][256]; null:
+// the list's start).  seg_tile: the tile's counters are the sum over its segments.
 __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const int tile, const int part, const int nparts, float4 *sp, float *syhi, uint32_t *sid,
-                                              uint32_t *sstrip, float *red, const float nbig) {
+                                              uint32_t *sstrip, float *red, const float nbig, const float *snap_in = nullptr, const uint32_t seg_start = 0,
+                                              const uint32_t seg_end = 0xFFFFFFFFu, const bool seg_tile = false) {
     const int lane = threadIdx.x;
     const int px = (tile % a.gx) * GS_TILE + (lane & 15) + 1;
     const int py0 = (tile / a.gx) * GS_TILE + (lane >> 4) + 1;
@@ -701,6 +743,15 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
         T[p] = in ? 1.0f : 0.0f;
         S[p] = in ? (a.image[o] * dCr[p] + a.image[o + plane] * dCg[p] + a.image[o + 2 * plane] * dCb[p]) : 0.0f;
         dead[p] = !in;
+        if (snap_in && in) {                                               // a later segment of a heavy tile's list: the forward's state at its start
+            const int idx = (lane >> 4) * GS_TILE + 64 * p + (lane & 15);   // pixel (x, y) of the tile: 16 (y - ty0) + (x - tx0)
+            const float tin = snap_in[768 + idx];
+            if (tin != tin) { T[p] = 0.0f; S[p] = 0.0f; dead[p] = true; }   // frozen before this segment
+            else {
+                T[p] = tin;
+                S[p] = (a.image[o] - snap_in[idx]) * dCr[p] + (a.image[o + plane] - snap_in[256 + idx]) * dCg[p] + (a.image[o + 2 * plane] - snap_in[512 + idx]) * dCb[p];
+            }
+        }
     }
     // the rectangle of the pixels still taking entries: the no-op test runs against it, exactly as in the forward (same pixels frozen at
     // the same batch boundaries, so the same entries are evaluated)
@@ -716,6 +767,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     };
     qx0 = (tile % a.gx) * GS_TILE + 1; qx1 = min(qx0 + GS_TILE - 1, a.W);   // every pixel of the part's strips inside the image is live
     qy0 = ty0 + 4 * (int)__builtin_ctz(own); qy1 = min(ty0 + 4 * (31 - (int)__builtin_clz(own)) + 3, a.H);
+    if (snap_in) live_rect();                                               // (... except those the snapshot says were frozen by then)
     const float4 *pay4 = reinterpret_cast<const float4 *>(a.payload);
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;
     uint32_t nid = 0;
@@ -731,7 +783,7 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     };
     // The tile's list is the concatenation of its segments, one per binning round of the frame (one segment unless the
     // frame was binned in depth slabs); batches end at multiples of CB of the WHOLE list, as in the forward.
-    uint32_t gp = 0;
+    uint32_t gp = seg_start;                                              // (a multiple of CB)
     uint32_t alive = own;                                                 // strips with a live pixel (refreshed at every batch boundary)
     bool stop = false;
     unsigned long long t_loop = 0, t_stage = 0, t_mark = 0;               // debug clocks (a.tile_clock)
@@ -740,9 +792,11 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     if (CLK) t_mark = __builtin_amdgcn_s_memtime();
     for (int sg = 0; sg < a.nseg && !stop; ++sg) {
     const uint32_t *ids = a.seg_ids[sg];
-    const uint32_t s0 = a.seg_ranges[sg][2 * tile];
+    const uint32_t r0s = a.seg_ranges[sg][2 * tile];
     // capped lists: the list ends where gs_bin -- or the forward, if it had to go further -- stopped writing it (>= what the forward walked)
-    const uint32_t s1 = a.tile_ext ? s0 + a.tile_ext[tile].x : a.seg_ranges[sg][2 * tile + 1];
+    const uint32_t r1s = a.tile_ext ? r0s + a.tile_ext[tile].x : a.seg_ranges[sg][2 * tile + 1];
+    // a heavy tile's list segment (else the whole list): [s0, s1)
+    const uint32_t s0 = min(r1s, r0s + seg_start), s1 = seg_end < r1s - r0s ? r0s + seg_end : r1s;
     uint32_t pos = s0 + lane;
     uint32_t id2 = 0;                                                     // ids run two batches ahead, payload rows one (see the forward)
     {
@@ -834,8 +888,13 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     }
     if (lane == 0 && part == 0) {                                         // (tile_parts > 1: the counters of a tile are those of its first part)
         if (a.walked) { atomicAdd(a.walked, (unsigned long long)walked); atomicAdd(a.walked + 1, (unsigned long long)evaluated); }
-        if (a.tile_walked) a.tile_walked[tile] = walked;
-        if (a.tile_work) a.tile_work[tile] = evaluated;
+        if (seg_tile) {                                                   // a heavy tile's segments add up (the forward zeroed the words)
+            if (a.tile_walked) atomicAdd(a.tile_walked + tile, walked);
+            if (a.tile_work) atomicAdd(a.tile_work + tile, evaluated);
+        } else {
+            if (a.tile_walked) a.tile_walked[tile] = walked;
+            if (a.tile_work) a.tile_work[tile] = evaluated;
+        }
     }
     if (CLK && a.tile_clock && lane == 0) {
         unsigned long long *c = a.tile_clock + GS_TILE_CLOCK_WORDS * (size_t)(a.clock_by_block ? (int)blockIdx.x : tile);
@@ -855,9 +914,34 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     __shared__ __attribute__((aligned(16))) float red[RED_FLOATS];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
-    int part, nparts;
-    const int tile = tile_of_block(a, ntiles, part, nparts);
-    if (tile >= 0) backward_tile<EARLY, DET, CULL, CLK>(a, tile, part, nparts, sp, syhi, sid, sstrip, red, nbig);
+    int part = 0, nparts = 1, tile;
+    const float *snap_in = nullptr;
+    uint32_t seg_start = 0, seg_end = 0xFFFFFFFFu;
+    bool seg_tile = false;
+    const int segunits = (EARLY && a.snap) ? 8 * (a.front / 24) * (GS_SEG_MAX - 1) : 0;     // workgroups in front of the order: segments 1 .. of the heavy tiles
+    if ((int)blockIdx.x < segunits) {
+        const int b = (int)blockIdx.x, x = b & 7, q = b >> 3, pos = q / (GS_SEG_MAX - 1), k = q - pos * (GS_SEG_MAX - 1) + 1, slot = 8 * pos + x;
+        const uint32_t sl = a.seg_len[slot], t = a.tile_order[a.front + 8 * pos + x];
+        if (sl == 0u || t == 0xFFFFFFFFu || (t >> 30) == 0u) return;          // the tile at this position is not split, or walks one segment
+        const uint32_t wk = a.snap_walked[slot];
+        if ((uint32_t)k * sl >= wk) return;                                   // the forward never got here
+        tile = (int)(t & GS_ORDER_TILE_MASK);
+        if (tile >= ntiles) return;
+        snap_in = a.snap + (size_t)slot * GS_SEG_SNAP_FLOATS + (size_t)(k - 1) * (4 * 256);
+        seg_start = (uint32_t)k * sl; seg_end = k == GS_SEG_MAX - 1 ? 0xFFFFFFFFu : seg_start + sl; seg_tile = true;
+    } else {
+        tile = tile_of_block(a, ntiles, part, nparts, segunits);
+        if (tile < 0) return;
+        if (segunits && nparts > 1) {                                         // a split tile: with segments its first entry is segment 0, its other parts do nothing
+            const int b = (int)blockIdx.x - segunits, slot = (b < a.front ? ((b >> 3) / 3) : ((b - a.front) >> 3)) * 8 + (b & 7);
+            const uint32_t sl = a.seg_len[slot];
+            if (sl) {
+                if (part) return;
+                nparts = 1; seg_end = sl; seg_tile = true;
+            }
+        }
+    }
+    backward_tile<EARLY, DET, CULL, CLK>(a, tile, part, nparts, sp, syhi, sid, sstrip, red, nbig, snap_in, seg_start, seg_end, seg_tile);
 }
 
 // Longest-first order for a PLAIN launch (gs_config.schedule 3 / 4).  The dispatcher hands workgroups out in blockIdx order,
@@ -902,9 +986,11 @@ int gs_lpt_order_len(int gx, int gy) { const int gs = lpt_group_side(gx, gy); re
 //     pos of XCD x owns the entries order[8 (3 pos + j) + x], j = 0 .. 2.  The ordinary entries follow from order[front] on; unused
 //     entries of the front region hold GS_LPT_NONE (an empty workgroup).  front = 0: no tile is split.
 __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__restrict__ src, int ranges_mode, int ntiles, int gx, int ng, int gs, int nb,
-                                                               uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14, int front, int split_div) {
+                                                               uint32_t *__restrict__ order, unsigned long long *__restrict__ zero14, int front, int split_div,
+                                                               const uint32_t *__restrict__ walked, uint32_t *__restrict__ zero_words,
+                                                               uint32_t *__restrict__ host_nsplit) {
     extern __shared__ uint32_t lds[];
-    __shared__ uint32_t wmax, wtot;
+    __shared__ uint32_t wmax, wtot, nsplit;
     __shared__ uint32_t rowtot[8 * 32], rowstart[8 * 32], xcount[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int GT = gs * gs;                                              // tiles of a full group (gs = 8, 4, 2 or 1: a power of two)
@@ -920,7 +1006,9 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
     uint8_t *cls = reinterpret_cast<uint8_t *>(ginfo + ng + (ng & 1) + ((rows * W) & 1));   // [ntiles]
     for (int i = tid; i < rows * W + ng; i += 1024) bm[i] = 0;          // bitmap and group sums
     for (int i = tid; i < front; i += 1024) order[i] = GS_LPT_NONE;     // the front region: filled by the split tiles at the very end
-    if (tid == 0) wmax = 1;
+    uint32_t *seg_len = order + front + 8 * per;                        // [front / 3] list entries per backward segment of the split tiles (0: none)
+    if (front > 0) for (int i = tid; i < front / 3; i += 1024) { seg_len[i] = 0; if (zero_words) zero_words[i] = 0; }
+    if (tid == 0) { wmax = 1; nsplit = 0; }
     if (zero14 && tid < 14) zero14[tid] = 0ull;
     __syncthreads();
     // the tiles' work is read twice (maximum + group sums, then classes), eight independent loads in flight per thread each time:
@@ -1023,14 +1111,24 @@ __global__ __launch_bounds__(1024) void tile_lpt_order_kernel(const uint32_t *__
                 const uint32_t pc = w >= 2u * thr ? 2u : 1u, extra = (1u << pc) - 1u;
                 for (uint32_t j = 0; j < extra; ++j) order[8u * (3u * pos + j) + (uint32_t)x] = (uint32_t)t | ((j + 1u) << 28) | (pc << 30);
                 entry |= pc << 30;
+                atomicAdd(&nsplit, 1u);
+                if (walked) {                                            // the backward's list segments: GS_SEG_MAX at most, none shorter than GS_SEG_MIN_LEN
+                    const uint32_t wk = walked[t], per_seg = (wk + GS_SEG_MAX - 1) / GS_SEG_MAX;
+                    const uint32_t sl = max((per_seg + 63u) & ~63u, (uint32_t)GS_SEG_MIN_LEN);
+                    seg_len[8u * pos + (uint32_t)x] = wk > sl ? sl : 0u;   // (a walk of one segment: nothing to split)
+                }
             }
         }
         main_order[8u * pos + (uint32_t)x] = entry;
     }
+    if (host_nsplit) {                                                   // coherent pinned host word: how many tiles of this order are split (the host picks
+        __syncthreads();                                                 // the composite kernels' instantiations by it; it holds 0xFFFFFFFF until this store lands)
+        if (tid == 0) *host_nsplit = nsplit;
+    }
 }
 
 hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_mode, int gx, int gy, uint32_t *order, hipStream_t s,
-                                    unsigned long long *zero14, int buckets, int front, int split_div) {
+                                    unsigned long long *zero14, int buckets, int front, int split_div, const uint32_t *walked, uint32_t *zero_words, uint32_t *host_nsplit) {
     const int ntiles = gx * gy;
     if (ntiles <= 0) return hipSuccess;
     if (ntiles > GS_LPT_MAX_TILES) return hipErrorInvalidValue;          // beyond 8K-class images: the callers keep launch order
@@ -1045,7 +1143,7 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
         if (e != hipSuccess) return e;
     }
     if (front < 0 || (front % 24) || ntiles > (int)GS_ORDER_TILE_MASK) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, gx, ng, gs, nb, order, zero14, front, split_div);
+    hipLaunchKernelGGL(tile_lpt_order_kernel, dim3(1), dim3(1024), lds, s, work_or_ranges, ranges_mode, ntiles, gx, ng, gs, nb, order, zero14, front, split_div, walked, zero_words, host_nsplit);
     return hipGetLastError();
 }
 
@@ -1093,9 +1191,11 @@ hipError_t gs_launch_clock_probe(unsigned long long *out, hipStream_t s) {
     return hipGetLastError();
 }
 
-static dim3 composite_grid(const GsCompositeArgs &a, int ntiles) {           // (tile_of_block computes the same length of one part)
+// workgroups in front of the order's in a backward launch: list segments 1 .. GS_SEG_MAX - 1 of the tiles that may be split (composite_bwd_kernel)
+int gs_seg_units(int front) { return 8 * (front / 24) * (GS_SEG_MAX - 1); }
+static dim3 composite_grid(const GsCompositeArgs &a, int ntiles, bool bwd = false) {   // (tile_of_block computes the same length of one part)
     const int len = (a.tile_order && a.order_len > 0) ? a.order_len : ((ntiles + 7) / 8) * 8;
-    return dim3((unsigned)(len * (a.parts > 1 ? a.parts : 1)));
+    return dim3((unsigned)(len * (a.parts > 1 ? a.parts : 1) + ((bwd && a.snap && a.t_min > 0.0f) ? gs_seg_units(a.front) : 0)));
 }
 
 // variant (debug launches, gs_debug_time_composite / gs_debug_tile_clock): tens digit 1 = tile order instead of the frame's launch order
@@ -1113,6 +1213,7 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     const bool early = a.t_min > 0.0f;
     if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.tile_pos || a.tile_clock)) return hipErrorInvalidValue;
     if (a.split_ok && (!early || a.tile_ext || a.tile_pos || a.parts > 1)) return hipErrorInvalidValue;   // split entries: frames with the early-out, full lists, one round
+    if (a.snap && (!a.split_ok || !a.seg_len || !a.snap_walked || !a.tile_order || a.front <= 0)) return hipErrorInvalidValue;
     if (a.tile_ext && (gs_bin3_seg() != L2_SEG || !early || !a.cranges || !a.cids || !a.clr || !a.ids_w || a.tile_pos)) return hipErrorInvalidValue;
     if (a.tile_pos) {                                                     // a round of a slab frame (t_min > 0 by construction: plan_rounds)
         if (!early || a.tile_clock) return hipErrorInvalidValue;
@@ -1127,7 +1228,10 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
         else hipLaunchKernelGGL((composite_fwd_kernel<false, GS_FWD_MINW, true, true>), grid, block, 0, s, a);
         return hipGetLastError();
     }
-    if (early) {
+    if (early && a.snap) {                                                // the order has split tiles: their waves leave snapshots
+        if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<true, GS_FWD_MINW, true, false, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((composite_fwd_kernel<true, GS_FWD_MINW, false, false, false, true>), grid, block, 0, s, a);
+    } else if (early) {
         if (a.cull) hipLaunchKernelGGL((composite_fwd_kernel<true, GS_FWD_MINW, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((composite_fwd_kernel<true, GS_FWD_MINW, false>), grid, block, 0, s, a);
     } else {
@@ -1142,7 +1246,8 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
     const int ntiles = a.gx * a.gy;
     if (ntiles <= 0) return hipSuccess;
     const bool early = a.t_min > 0.0f;
-    const dim3 grid = composite_grid(a, ntiles), block(64);
+    const dim3 grid = composite_grid(a, ntiles, true), block(64);
+    if (a.snap && (!a.split_ok || !a.seg_len || !a.snap_walked || !a.tile_order || a.front <= 0)) return hipErrorInvalidValue;
     if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.nseg > 1 || a.tile_clock)) return hipErrorInvalidValue;
     if (a.split_ok && (!early || a.tile_ext || a.nseg > 1 || a.parts > 1)) return hipErrorInvalidValue;
 #define GS_B2(E, D) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, true>), grid, block, 0, s, a); \

@@ -97,6 +97,14 @@ struct gs_ctx {
     GsBin3Args last_l2{};                    // the level-2 arguments of the frame's lists (gs_get_array writes the capped rest with them)
     bool have_l2 = false;
     const uint32_t *frame_order = nullptr;   // the launch order of THIS frame's composite kernels (null: tile order)
+    // ---- heavy tiles: list segments of the backward (GsCompositeArgs.snap)
+    DevBuf snap, snap_walked;                // the forward's snapshots of the split tiles; their walked lengths, two frame parities
+    const uint32_t *snap_order = nullptr;    // the order whose split tiles this frame's forward left snapshots for (null: none)
+    uint32_t *pinned_split = nullptr;        // coherent pinned host words, two per view slot (one per order buffer): split tiles of that order, as its
+                                             // order kernel counted them (0xFFFFFFFF: the kernel has not reported yet); null: unknown, assume some
+    const uint32_t *frame_order_split = nullptr;   // ... the word of this frame's order
+    int snap_parity = 0;                     // the parity of snap_walked this frame's forward writes (and its backward reads); the order kernel
+                                             // behind every forward re-arms the other one and the parities swap
     // ---- side stream: the order kernel (needed by the slot's NEXT frame, not by this one) runs beside the backward composite
     hipStream_t side = nullptr;
     hipEvent_t ev_main = nullptr, ev_order = nullptr;
@@ -229,6 +237,8 @@ inline int lpt_front(const gs_ctx *c) {
     const int64_t ntiles = (int64_t)c->gx * c->gy;
     return (lpt_schedule(c) && c->cfg.tile_parts == 0 && c->cfg.t_min > 0.0f && 2 * ntiles > c->wave_slots && ntiles <= GS_LPT_MAX_TILES) ? GS_LPT_FRONT : 0;
 }
+// the words behind an order's entries: list entries per backward segment of the split tiles (GS_SEG_SLOTS of them)
+inline const uint32_t *order_seg_len(const gs_ctx *c, const uint32_t *order) { return order + lpt_front(c) + gs_lpt_order_len(c->gx, c->gy); }
 inline int lpt_order_entries(const gs_ctx *c) { return lpt_front(c) + gs_lpt_order_len(c->gx, c->gy); }   // = workgroups of a launch over the order
 inline int lpt_split_div(const gs_ctx *c) { return c->wave_slots * 4 / 5; }      // a tile with more work than an even share of ~4 waves per SIMD is split
 // The side stream (order kernel beside the backward) costs four more runtime calls per frame: it pays when the composite kernels

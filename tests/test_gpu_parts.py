@@ -190,3 +190,42 @@ def test_split_entries_are_whole_tiles_for_capped_lists_and_uniform_scenes():
     _slot_frames(ctx, synthetic.make_dC(W, H, seed), deg)
     assert _split_units(ctx)[0] == 0
     ctx.close()
+
+
+def test_heavy_tiles_backward_as_list_segments(oracle):
+    """Round 5: a split tile's backward runs as segments of its LIST (the forward's parts leave (C, T) snapshots at the segment
+    boundaries; every segment is a whole-tile wave starting from the snapshot in front of it).  Gradients against the oracle's adjoint
+    (bars of BASELINE.json) and against whole tiles (1e-5, deterministic mode); the backward's work counters are the sums over the
+    segments and equal the forward's walk; several frames under one slot (the snapshots' walked lengths are re-armed every frame)."""
+    from gaussiansplat_amd import synthetic
+    O = oracle
+    n, W, H, deg, seed = 150_000, 1024, 768, 1, 1236
+    sc = synthetic.make_scene(n, W, H, deg, seed=seed, clustered=True)
+    sc["opacities"] = (sc["opacities"] - np.float32(1.5)).astype(np.float32)   # fainter still: the blobs' tiles walk several thousand entries
+    _, cam, T, P, ocam = scene_and_cameras(16, W, H, deg, seed)
+    dC = synthetic.make_dC(W, H, seed)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC, t_min=1e-5, omp=True)
+    res = {}
+    for parts in (1, 0):
+        ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5, tile_parts=parts, deterministic=True, debug_flags=ALWAYS_ORDER)
+        for _ in range(4):
+            ctx.set_view_slot(0)
+            res[parts] = _frame(ctx, dC, deg)
+        ctx.close()
+    # the segments really ran: clocked backward launch (float atomics) of the same frame, records per workgroup; the segment units come first
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5, tile_parts=0, debug_flags=ALWAYS_ORDER)
+    for _ in range(3):
+        ctx.set_view_slot(0)
+        _frame(ctx, dC, deg)
+    clk = ctx.tile_clock(1, -30)
+    nseg_units = 8 * (FRONT // 24) * 7
+    assert clk.shape[0] > nseg_units + FRONT and int((clk[:nseg_units, 1] > 0).sum()) >= 8, int((clk[:nseg_units, 1] > 0).sum())
+    ctx.close()
+    a, b = res[1], res[0]
+    assert np.abs(a[0] - b[0]).max() <= 1e-6 and np.abs(a[1] - b[1]).max() <= 1e-6
+    for k in GRADS:
+        assert rel_l2(b[2][k], a[2][k]) <= 1e-5, (k, rel_l2(b[2][k], a[2][k]))
+        e = rel_l2(b[2][k], np.asarray(gref[k]).reshape(b[2][k].shape))
+        assert e <= GRAD_REL_L2, (k, e)
+    assert b[3]["walked_bwd"] == b[3]["walked_fwd"] or b[3]["walked_bwd"] >= a[3]["walked_bwd"]
