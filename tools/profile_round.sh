@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 CFG=C3
 for a in "$@"; do case "$prev" in --config) CFG=$a;; esac; prev=$a; done
-B="python3 $PWD/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-train-iteration --no-c4-anchor $*"
+B="python3 $PWD/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-train-iteration --no-c4-anchor --no-clustered $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B > "$OUT/bench_stats.log" 2>&1
 echo "stats done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_valu" -- $B > "$OUT/bench_pmc_valu.log" 2>&1
