@@ -116,7 +116,7 @@ int gs_destroy(gs_ctx *c) {
                       &c->ranges_r[0], &c->ranges_r[1], &c->ranges_r[2], &c->ranges_r[3],
                       &c->invcov, &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams, &c->tile_dead, &c->key_range, &c->tile_walked, &c->tile_walked_b, &c->tile_work_b};
     for (DevBuf *b : bufs) b->release();
-    for (auto &v : c->slots) { v.order[0].release(); v.order[1].release(); v.walked.release(); }
+    for (auto &v : c->slots) { v.order[0].release(); v.order[1].release(); v.walkbuf[0].release(); v.walkbuf[1].release(); }
     for (DevBuf *b : {&c->tile_nopen, &c->smax, &c->tile_ext, &c->zero_tiles}) b->release();
     for (auto &b : c->model) b.release();
     for (auto &b : c->dbg) b.release();

@@ -138,8 +138,8 @@ static int list_cap_source(gs_ctx *c, int rounds, const uint32_t **out) {
     if (c->cfg.list_cap != 2 && (ntiles <= c->wave_slots || !(c->walked_ratio >= 0.0 && c->walked_ratio < GS_LIST_CAP_MAX_RATIO))) return GS_OK;
     const int k = order_index(c);
     if (k == GS_MAX_VIEW_SLOTS && c->cfg.schedule != 4) return GS_OK;          // frames without a slot: history only under schedule 4
-    if (c->slots[k].walked_grid != grid || !c->slots[k].walked.p) return GS_OK;
-    *out = c->slots[k].walked.as<uint32_t>();
+    if (c->slots[k].walked_grid != grid || !c->slots[k].walked().p) return GS_OK;
+    *out = c->slots[k].walked().as<uint32_t>();
     return GS_OK;
 }
 

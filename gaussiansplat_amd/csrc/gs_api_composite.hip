@@ -102,6 +102,14 @@ static int enqueue_forward_round(gs_ctx *c, int r, const uint32_t *order) {
     a.parts = c->frame_parts;
     a.split_ok = order && lpt_front(c) > 0 && c->frame_parts == 1 && !c->frame_capped && R == 1;   // heavy tiles run as the order's entries say
     c->snap_order = nullptr;
+    if (c->frame_seg_n && R == 1) {                                         // small grid: every tile leaves snapshots for its backward's list segments
+        const size_t nt = (size_t)c->gx * c->gy;
+        HIPCHK(c, c->snap.ensure(sizeof(float) * nt * (size_t)(c->frame_seg_n - 1) * 4 * 256));
+        HIPCHK(c, c->tile_walked_b.ensure(sizeof(uint32_t) * (nt ? nt : 1)));
+        HIPCHK(c, c->tile_work_b.ensure(sizeof(uint32_t) * (nt ? nt : 1)));
+        a.snap = c->snap.as<float>(); a.seg_hist = c->seg_hist; a.seg_n = c->frame_seg_n;
+        a.bw_walked = c->tile_walked_b.as<uint32_t>(); a.bw_work = c->tile_work_b.as<uint32_t>();
+    }
     const bool may_split = !c->frame_order_split || *c->frame_order_split != 0u;   // (the order kernel's count; 0xFFFFFFFF: not reported yet)
     if (a.split_ok && c->snap_walked.p && may_split) {                      // ... and leave snapshots for the list segments of their backward
         HIPCHK(c, c->snap.ensure(sizeof(float) * (size_t)GS_SEG_SLOTS * GS_SEG_SNAP_FLOATS));
@@ -137,12 +145,29 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
     HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
     HIPCHK(c, c->tile_work.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
     c->counters_grid = ((int64_t)c->gx << 32) | (int64_t)c->gy;
-    {   // the per-tile walked counts go to the frame's view slot (the caps of the slot's next lists), else to the ctx's own array
+    c->frame_seg_n = 0; c->seg_hist = nullptr;
+    int flip_slot = -1;
+    {   // the per-tile walked counts go to the frame's view slot (the caps of the slot's next lists; double buffered: this frame may read the
+        // previous walk while it writes its own), else to the ctx's own array
         const int k = order_index(c);
-        DevBuf &wb = (k < GS_MAX_VIEW_SLOTS || c->cfg.schedule == 4) ? c->slots[k].walked : c->tile_walked;
-        HIPCHK(c, wb.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
-        if (&wb != &c->tile_walked) c->slots[k].walked_grid = c->counters_grid;
-        c->last_walked = wb.as<uint32_t>();
+        if (k < GS_MAX_VIEW_SLOTS || c->cfg.schedule == 4) {
+            gs_ctx::ViewSlot &vs = c->slots[k];
+            DevBuf &wb = vs.walkbuf[vs.wsel ^ 1];
+            HIPCHK(c, wb.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
+            const bool hist = vs.walked_grid == c->counters_grid && vs.walked().p;
+            // small grids (no launch order, fewer tiles than half the wave slots): with the slot's previous walk at hand EVERY tile's backward
+            // runs as 2 / 4 list segments; the forward's waves leave the snapshots
+            if (hist && c->cfg.tile_parts == 0 && c->cfg.t_min > 0.0f && c->n_rounds == 1 && !c->frame_capped && !lpt_schedule(c) && c->kind == 0 &&
+                2 * (int64_t)ntiles <= c->wave_slots && ntiles > 0) {
+                c->frame_seg_n = 2;                        // (four segments lost to four pixel parts at C1: a tile there walks ~ 300 entries)
+                c->seg_hist = vs.walked().as<uint32_t>();
+            }
+            c->last_walked = wb.as<uint32_t>();
+            flip_slot = k;
+        } else {
+            HIPCHK(c, c->tile_walked.ensure(sizeof(uint32_t) * (ntiles ? ntiles : 1)));
+            c->last_walked = c->tile_walked.as<uint32_t>();
+        }
     }
     const int R = c->n_rounds;
     if (R > 1) {
@@ -167,6 +192,7 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
             }
         }
     }
+    if (flip_slot >= 0) { c->slots[flip_slot].wsel ^= 1; c->slots[flip_slot].walked_grid = c->counters_grid; }   // this frame's walk is the slot's history now
     if (int rc = build_frame_order(c, order)) return rc;
     const hipMemcpyKind kind = mem == GS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     if (image && image != c->img()) HIPCHK(c, hipMemcpyAsync(image, c->img(), sizeof(float) * 3 * px, kind, c->stream));
@@ -238,6 +264,12 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
     if (c->frame_capped && c->n_rounds == 1) a.tile_ext = c->tile_ext.as<uint2>();      // the lists end where gs_bin / the forward stopped writing them
     a.cull = c->cfg.alpha_cull != 0;
     a.parts = c->frame_parts;                                              // as the frame's forward
+    if (c->frame_seg_n && c->n_rounds == 1 && !c->frame_capped) {          // small grid: list segments instead of pixel parts (the forward left the snapshots)
+        // two list segments, and as many pixel parts on top as still fit the wave slots (C1: 4 x 2 waves per tile; C2: 1 x 2)
+        const long long nt = (long long)c->gx * c->gy;
+        a.snap = c->snap.as<float>(); a.seg_hist = c->seg_hist; a.seg_n = c->frame_seg_n;
+        a.parts = 8 * nt <= c->wave_slots ? 4 : 4 * nt <= c->wave_slots ? 2 : 1;
+    }
     if (!params_only) {
         c->last_dC = dC_dev;
         // zero fill of the gradient rows (64 B per gaussian), in line: on a side stream beside the forward composite it cost more than

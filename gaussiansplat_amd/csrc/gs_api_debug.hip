@@ -182,6 +182,11 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
         a.snap_walked = c->snap_walked.as<uint32_t>() + (size_t)c->snap_parity * GS_SEG_SLOTS;
     }
     a.parts = c->frame_parts;                                                // as the frame's own launches (tile clocks: one wave per tile only)
+    if (which == 1 && c->frame_seg_n && c->n_rounds == 1 && !c->frame_capped && !a.tile_order) {   // small grid: the backward's list segments
+        const long long nt = (long long)c->gx * c->gy;
+        a.snap = c->snap.as<float>(); a.seg_hist = c->seg_hist; a.seg_n = c->frame_seg_n;
+        a.parts = 8 * nt <= c->wave_slots ? 4 : 4 * nt <= c->wave_slots ? 2 : 1;
+    }
     if (c->dbg_win_len > 0) {                                                // gs_debug_set_window: a slice of the launch order
         if (!a.tile_order || a.parts > 1) return fail(c, GS_ERR_INVALID, "gs_debug_set_window: the frame has no launch order (or several waves per tile)");
         if (c->dbg_win_start + c->dbg_win_len > a.order_len) return fail(c, GS_ERR_INVALID, "gs_debug_set_window: beyond the launch order");

@@ -300,6 +300,11 @@ struct GsCompositeArgs {
     uint32_t *snap_walked;
     int front;
     uint32_t *bw_walked, *bw_work;   // forward: the backward's per-tile counters, zeroed for segmented tiles (its segments ADD to them)
+    // ... and on SMALL grids (fewer tiles than wave slots, no launch order) EVERY tile's backward runs as seg_n = 2 / 4 list segments: snapshot
+    // slot = tile, (seg_n - 1) snapshots per tile, segment length from the view slot's previous walk of the tile (seg_hist[tile]:
+    // gs_seg_len_all), block b of the backward = segment b / len of tile b % len.  seg_hist = null: not this mode.
+    const uint32_t *seg_hist;
+    int seg_n;
     int clock_by_block;        // debug (tile_clock): records indexed by workgroup instead of by tile (launches with split tiles)
 };
 // the written entries of capped lists, summed over the tiles: out[0] = sum ext[t].x
@@ -319,6 +324,7 @@ hipError_t gs_launch_sum_tiles(const uint32_t *a, const uint32_t *b, int n, unsi
 #define GS_LPT_FRONT 2304
 #define GS_SEG_MAX 8                 // list segments of a heavy tile's backward (GS_SEG_MAX - 1 snapshots per tile)
 #define GS_SEG_MIN_LEN 1024          // ... none shorter than this many entries
+#define GS_SEG_ALL_MIN_LEN 128       // ... on small grids, where every tile is segmented (two batches)
 #define GS_SEG_SLOTS (GS_LPT_FRONT / 3)                          // tiles that may be split: 8 XCDs x GS_LPT_FRONT / 24
 #define GS_SEG_SNAP_FLOATS ((GS_SEG_MAX - 1) * 4 * 256)          // floats of one tile's snapshots
 // walked (with front > 0; may be null): per-tile walked list entries of the forward whose work is ranked -> seg_len[GS_SEG_SLOTS] behind the
@@ -328,6 +334,11 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
                                     unsigned long long *zero14 = nullptr, int buckets = 0, int front = 0, int split_div = 1,
                                     const uint32_t *walked = nullptr, uint32_t *zero_words = nullptr, uint32_t *host_nsplit = nullptr);
 // host_nsplit (may be null): coherent pinned host word that receives the number of split tiles of the order
+// small grids: entries per list segment of a tile that walked w entries last time (0: one segment, no snapshots)
+__host__ __device__ inline uint32_t gs_seg_len_all(uint32_t w, int seg_n) {
+    const uint32_t per = (w + (uint32_t)seg_n - 1u) / (uint32_t)seg_n, sl = ((per + 63u) & ~63u) < (uint32_t)GS_SEG_ALL_MIN_LEN ? (uint32_t)GS_SEG_ALL_MIN_LEN : ((per + 63u) & ~63u);
+    return w > sl ? sl : 0u;
+}
 int gs_seg_units(int front);         // workgroups a backward launch with list segments puts in front of the order's
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);

@@ -375,8 +375,9 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
                     const float x = (!PACK || K == 4) ? fx : fy[2 + (p & 1)];
                     if (a.trans) a.trans[(uint32_t)((int)x - 1) + (uint32_t)a.W * (uint32_t)((int)fy[p] - 1)] = T[p];
                     if (SNAP && snap_slot >= 0) {                        // ... and every later snapshot says so (NaN: no segment takes this pixel up again)
-                        float *st = a.snap + (size_t)snap_slot * GS_SEG_SNAP_FLOATS + 768 + ((int)fy[p] - ty0) * GS_TILE + ((int)x - (px - (lane & 15)));
-                        for (int kk = (int)(next_snap / seg_len) - 1; kk < GS_SEG_MAX - 1; ++kk) st[kk * (4 * 256)] = __int_as_float(0x7FC00000);
+                        const int nsn = a.seg_hist ? a.seg_n - 1 : GS_SEG_MAX - 1;      // snapshots per tile
+                        float *st = a.snap + (size_t)snap_slot * (size_t)(nsn * 4 * 256) + 768 + ((int)fy[p] - ty0) * GS_TILE + ((int)x - (px - (lane & 15)));
+                        for (int kk = (int)(next_snap / seg_len) - 1; kk < nsn; ++kk) st[kk * (4 * 256)] = __int_as_float(0x7FC00000);
                     }
                     dead[p] = true; T[p] = 0.0f; froze = true;
                 }
@@ -435,8 +436,9 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         }
         if (SNAP && EARLY && !SLAB && gp == next_snap) {                         // (wave-uniform; a batch boundary: seg_len is a multiple of CB)
             const int ksnap = (int)(next_snap / seg_len) - 1;            // snapshots written so far = index of this one
-            if (ksnap < GS_SEG_MAX - 1) {
-                float *sn = a.snap + (size_t)snap_slot * GS_SEG_SNAP_FLOATS + ksnap * (4 * 256);
+            const int nsn = a.seg_hist ? a.seg_n - 1 : GS_SEG_MAX - 1;
+            if (ksnap < nsn) {
+                float *sn = a.snap + (size_t)snap_slot * (size_t)(nsn * 4 * 256) + ksnap * (4 * 256);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     if (!dead[p]) {
@@ -568,7 +570,7 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
         }
     }
     if (SNAP && snap_slot >= 0 && lane == 0) {
-        atomicMax(a.snap_walked + snap_slot, gp0 + walked);             // how far the tile's list was walked: the longest walk of its parts
+        if (a.snap_walked) atomicMax(a.snap_walked + snap_slot, gp0 + walked);   // how far the tile's list was walked: the longest walk of its parts
         if (part == 0) { if (a.bw_walked) a.bw_walked[tile] = 0u; if (a.bw_work) a.bw_work[tile] = 0u; }   // (the backward's segments add theirs)
     }
     if (lane == 0 && part == 0) {                                       // (tile_parts > 1: the counters of a tile are those of its first part)
@@ -622,7 +624,10 @@ __global__ __launch_bounds__(64, MINW) void composite_fwd_kernel(GsCompositeArgs
     if (tile < 0) return;
     int snap_slot = -1;
     uint32_t sl = 0;
-    if (SNAP && EARLY && !SLAB && a.snap && nparts > 1 && a.parts <= 1) {  // a split tile of the order: its slot = 8 x position in the XCD's list + XCD
+    if (SNAP && EARLY && !SLAB && a.snap && a.seg_hist) {                  // small grid: every tile is segmented, slot = tile
+        sl = gs_seg_len_all(a.seg_hist[tile], a.seg_n);
+        if (sl) snap_slot = tile;
+    } else if (SNAP && EARLY && !SLAB && a.snap && nparts > 1 && a.parts <= 1) {  // a split tile of the order: its slot = 8 x position in the XCD's list + XCD
         const int b = (int)blockIdx.x, slot = (b < a.front ? ((b >> 3) / 3) : ((b - a.front) >> 3)) * 8 + (b & 7);
         sl = a.seg_len[slot];
         if (sl) snap_slot = slot;
@@ -918,8 +923,21 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
     const float *snap_in = nullptr;
     uint32_t seg_start = 0, seg_end = 0xFFFFFFFFu;
     bool seg_tile = false;
-    const int segunits = (EARLY && a.snap) ? 8 * (a.front / 24) * (GS_SEG_MAX - 1) : 0;     // workgroups in front of the order: segments 1 .. of the heavy tiles
-    if ((int)blockIdx.x < segunits) {
+    const int segunits = (EARLY && a.snap && !a.seg_hist) ? 8 * (a.front / 24) * (GS_SEG_MAX - 1) : 0;   // workgroups in front of the order: segments 1 .. of the heavy tiles
+    if (EARLY && a.snap && a.seg_hist) {                                      // small grid: block b = unit b / len of tile b % len; unit = segment x parts + pixel part
+        const int len = ((ntiles + 7) / 8) * 8, unit = (int)blockIdx.x / len;
+        tile = (int)blockIdx.x - unit * len;
+        nparts = a.parts > 1 ? a.parts : 1; part = unit % nparts;
+        const int k = unit / nparts;
+        if (tile >= ntiles || k >= a.seg_n) return;
+        const uint32_t sl = gs_seg_len_all(a.seg_hist[tile], a.seg_n);
+        if (k > 0) {
+            if (sl == 0u) return;                                             // this tile runs as one segment
+            snap_in = a.snap + (size_t)tile * (size_t)((a.seg_n - 1) * 4 * 256) + (size_t)(k - 1) * (4 * 256);
+            seg_start = (uint32_t)k * sl;
+        }
+        if (sl) { seg_end = k == a.seg_n - 1 ? 0xFFFFFFFFu : seg_start + sl; seg_tile = true; }
+    } else if ((int)blockIdx.x < segunits) {
         const int b = (int)blockIdx.x, x = b & 7, q = b >> 3, pos = q / (GS_SEG_MAX - 1), k = q - pos * (GS_SEG_MAX - 1) + 1, slot = 8 * pos + x;
         const uint32_t sl = a.seg_len[slot], t = a.tile_order[a.front + 8 * pos + x];
         if (sl == 0u || t == 0xFFFFFFFFu || (t >> 30) == 0u) return;          // the tile at this position is not split, or walks one segment
@@ -1195,6 +1213,7 @@ hipError_t gs_launch_clock_probe(unsigned long long *out, hipStream_t s) {
 int gs_seg_units(int front) { return 8 * (front / 24) * (GS_SEG_MAX - 1); }
 static dim3 composite_grid(const GsCompositeArgs &a, int ntiles, bool bwd = false) {   // (tile_of_block computes the same length of one part)
     const int len = (a.tile_order && a.order_len > 0) ? a.order_len : ((ntiles + 7) / 8) * 8;
+    if (bwd && a.snap && a.seg_hist && a.t_min > 0.0f) return dim3((unsigned)(len * a.seg_n * (a.parts > 1 ? a.parts : 1)));   // small grid: segments x pixel parts per tile
     return dim3((unsigned)(len * (a.parts > 1 ? a.parts : 1) + ((bwd && a.snap && a.t_min > 0.0f) ? gs_seg_units(a.front) : 0)));
 }
 
@@ -1213,7 +1232,8 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     const bool early = a.t_min > 0.0f;
     if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.tile_pos || a.tile_clock)) return hipErrorInvalidValue;
     if (a.split_ok && (!early || a.tile_ext || a.tile_pos || a.parts > 1)) return hipErrorInvalidValue;   // split entries: frames with the early-out, full lists, one round
-    if (a.snap && (!a.split_ok || !a.seg_len || !a.snap_walked || !a.tile_order || a.front <= 0)) return hipErrorInvalidValue;
+    if (a.snap && !a.seg_hist && (!a.split_ok || !a.seg_len || !a.snap_walked || !a.tile_order || a.front <= 0)) return hipErrorInvalidValue;
+    if (a.snap && a.seg_hist && (a.tile_order || a.seg_n < 2 || a.seg_n > GS_SEG_MAX || !early || a.tile_ext || a.tile_pos)) return hipErrorInvalidValue;
     if (a.tile_ext && (gs_bin3_seg() != L2_SEG || !early || !a.cranges || !a.cids || !a.clr || !a.ids_w || a.tile_pos)) return hipErrorInvalidValue;
     if (a.tile_pos) {                                                     // a round of a slab frame (t_min > 0 by construction: plan_rounds)
         if (!early || a.tile_clock) return hipErrorInvalidValue;
@@ -1247,7 +1267,8 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const bool early = a.t_min > 0.0f;
     const dim3 grid = composite_grid(a, ntiles, true), block(64);
-    if (a.snap && (!a.split_ok || !a.seg_len || !a.snap_walked || !a.tile_order || a.front <= 0)) return hipErrorInvalidValue;
+    if (a.snap && !a.seg_hist && (!a.split_ok || !a.seg_len || !a.snap_walked || !a.tile_order || a.front <= 0)) return hipErrorInvalidValue;
+    if (a.snap && a.seg_hist && (a.tile_order || a.seg_n < 2 || a.seg_n > GS_SEG_MAX || !early || a.tile_ext || a.nseg > 1)) return hipErrorInvalidValue;
     if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.nseg > 1 || a.tile_clock)) return hipErrorInvalidValue;
     if (a.split_ok && (!early || a.tile_ext || a.nseg > 1 || a.parts > 1)) return hipErrorInvalidValue;
 #define GS_B2(E, D) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, true>), grid, block, 0, s, a); \

@@ -83,8 +83,10 @@ struct gs_ctx {
         DevBuf order[2];                     // launch orders, double buffered
         int sel = 0;                         // the newest one
         int64_t tiles = 0;                   // ... is valid for this grid (gx << 32 | gy; 0: no history)
-        DevBuf walked;                       // per tile: list entries the slot's last forward walked (the next frame's list caps)
+        DevBuf walkbuf[2];                   // per tile: list entries the slot's forwards walked, double buffered: [wsel] = the last completed forward's
+        int wsel = 0;                        // (the next frame's list caps and segment lengths), the other one is what the frame being rendered writes
         int64_t walked_grid = 0;             // ... on this grid (0: none yet)
+        DevBuf &walked() { return walkbuf[wsel]; }
     };
     std::vector<ViewSlot> slots;             // GS_MAX_VIEW_SLOTS + 1 (allocated at gs_create; device buffers on first use)
     const uint32_t *last_walked = nullptr;   // per-tile walked counts of the most recent forward (the slot's array, or tile_walked)
@@ -100,6 +102,8 @@ struct gs_ctx {
     // ---- heavy tiles: list segments of the backward (GsCompositeArgs.snap)
     DevBuf snap, snap_walked;                // the forward's snapshots of the split tiles; their walked lengths, two frame parities
     const uint32_t *snap_order = nullptr;    // the order whose split tiles this frame's forward left snapshots for (null: none)
+    int frame_seg_n = 0;                     // small grids: list segments per tile of this frame's backward (0: none; the forward left snapshots for them)
+    const uint32_t *seg_hist = nullptr;      // ... and the walk history their lengths come from (the slot's previous forward)
     uint32_t *pinned_split = nullptr;        // coherent pinned host words, two per view slot (one per order buffer): split tiles of that order, as its
                                              // order kernel counted them (0xFFFFFFFF: the kernel has not reported yet); null: unknown, assume some
     const uint32_t *frame_order_split = nullptr;   // ... the word of this frame's order

@@ -229,3 +229,33 @@ def test_heavy_tiles_backward_as_list_segments(oracle):
         e = rel_l2(b[2][k], np.asarray(gref[k]).reshape(b[2][k].shape))
         assert e <= GRAD_REL_L2, (k, e)
     assert b[3]["walked_bwd"] == b[3]["walked_fwd"] or b[3]["walked_bwd"] >= a[3]["walked_bwd"]
+
+
+@pytest.mark.parametrize("n,W,H,deg,seed,boost,segs", [(10_000, 256, 256, 0, 1235, 0.0, 2),       # C1: 256 tiles, two segments x four pixel parts
+                                                       (100_000, 800, 800, 3, 1236, 0.0, 2),      # C2: 2500 tiles, two segments
+                                                       (6_001, 200, 120, 2, 31, 1.0, 2)])         # ragged edges, dense
+def test_small_grids_backward_as_list_segments(oracle, n, W, H, deg, seed, boost, segs):
+    """Round 5: on a grid with fewer tiles than wave slots and a view slot with history, EVERY tile's backward runs as two segments
+    of its list (the forward's waves -- two or four per tile, by pixel strips -- leave one snapshot per tile), with as many pixel parts on
+    top as still fit the wave slots, instead of pixel parts that each walk the whole list.  Oracle bars; 1e-5 against the frame without history (pixel parts); the image is the same bits."""
+    from gaussiansplat_amd import synthetic
+    O = oracle
+    sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
+    sc["scales"] = (sc["scales"] + np.float32(boost)).astype(np.float32)
+    dC = synthetic.make_dC(W, H, seed)
+    ref = O.render(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, order=1, t_min=1e-5, omp=True)
+    gref = O.backward(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam, ref["ranges"], ref["ids"], dC, t_min=1e-5, omp=True)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, order=1, t_min=1e-5, tile_parts=0, deterministic=True)
+    ctx.set_view_slot(2)
+    first = _frame(ctx, dC, deg)                                               # no history yet: pixel parts
+    for _ in range(2):
+        ctx.set_view_slot(2)
+        got = _frame(ctx, dC, deg)                                             # list segments
+    ctx.close()
+    assert np.array_equal(first[0], got[0]) and np.array_equal(first[1], got[1])
+    assert np.all(np.abs(got[0] - ref["image"]) <= PIX_ATOL + PIX_RTOL * np.abs(ref["image"]))
+    for k in GRADS:
+        assert rel_l2(got[2][k], first[2][k]) <= 1e-5, (k, rel_l2(got[2][k], first[2][k]))
+        e = rel_l2(got[2][k], np.asarray(gref[k]).reshape(got[2][k].shape))
+        assert e <= GRAD_REL_L2, (k, e)
+    assert got[3]["walked_bwd"] >= first[3]["walked_bwd"] > 0                   # (the segments' sum is the tile's whole walk; a part's count is its own)
