@@ -7,9 +7,11 @@ A/B run, loaded with GSPLAT_HIP_LIB=.../lib_NAME/libgsplat_hip.so (tools/ab_libs
 in rounds 1-3 (persistent ticket queues, the reduction tree, the software-pipelined backward, the 64-VGPR forward) and their
 environment switches are no longer in the tree: profiles/HISTORY.md names the commit that last had them.
 
-The preprocess translation unit is compiled with -ffp-contract=off (numeric spec: tile ids
-and depth keys must be bit-identical to the CPU oracle); the composite kernels keep hipcc's
-default contraction (pixels/gradients are tolerance-checked).
+The preprocess translation units are compiled with -ffp-contract=off (numeric spec: tile ids
+and depth keys must be bit-identical to the CPU oracle).  The composite kernels turn contraction
+off themselves (`#pragma clang fp contract(off)` at the top of gs_composite.hip: only the fmaf()
+calls written there fuse, so that every instantiation rounds a pixel's T the same way) and are
+built without the SLP vectoriser; their pixels and gradients are tolerance-checked.
 """
 from __future__ import annotations
 

@@ -141,16 +141,25 @@ typedef struct {
                                  than 5120 tiles (measured: at 28 % walked the shorter write pass only pays for the extra cap pass).
                                  1 never; 2 also on small grids (tests).  GS_ARR_TILE_RANGES is always the full ranges; asking for
                                  GS_ARR_SORTED_IDS / _KEYS of a capped frame first writes the unwritten rest.                   */
-    int32_t tile_parts;       /* waves per tile on small grids (speed only).  The reference runs one 16 x 16 thread block per tile
+    int32_t tile_parts;       /* how a tile is shared between waves (speed only).  The reference runs one 16 x 16 thread block per tile
                                  (splat.jl:224-231, threads = (16, 16)); here one wave64 composites a tile, four pixels per lane in four
-                                 16 x 4 strips.  A grid with fewer tiles than the chip has wave slots (256 CUs x 4 SIMDs x 5) leaves
-                                 slots idle and every wave runs alone on its SIMD; then 2 or 4 waves share a tile, each owning two
-                                 strips or one and walking the tile's list on its own (forward and backward alike; the entries a
-                                 wave evaluates are tested against ITS pixels, so pixels may differ from the one-wave result by
-                                 contributions below 2^-27 -- the no-op rule of alpha_cull).  0 (default) automatic: 4 when
-                                 4 x tiles fit the wave slots, else 2 when 2 x tiles fit, else 1; 1, 2, 4: as given.  Always 1 for
-                                 frames without the early-out (t_min = 0), frames binned in depth slabs and capped lists.
-                                 With more than one part the per-tile work counters are those of the tile's first part.          */
+                                 16 x 4 strips.  0 (default) automatic:
+                                 (a) a grid with fewer tiles than the chip has wave slots (256 CUs x 4 SIMDs x 5) leaves slots idle and every
+                                     wave runs alone on its SIMD: 4 waves share a tile when 4 x tiles fit the slots, else 2 when 2 x tiles fit,
+                                     each owning two strips or one and walking the tile's list on its own (the entries a wave evaluates are
+                                     tested against ITS pixels, so pixels may differ from the one-wave result by contributions below 2^-27
+                                     -- the no-op rule of alpha_cull).  Once the frame's VIEW SLOT has history, the BACKWARD of every tile
+                                     runs instead as two segments of its list (x pixel parts where they still fit): the forward's waves
+                                     leave a snapshot (C, T) of their pixels at the boundary, the second segment starts from it;
+                                 (b) on larger grids the launch order (schedule 3 / 4) gives the FEW tiles whose work stands far above an
+                                     even share -- a trained scene's heavy tail -- two or four waves (by strips) in the forward, and up to
+                                     eight list segments in the backward (snapshots as above); a spatially uniform scene splits nothing.
+                                 Gradients of a tile shared this way differ from the one-wave result by the order of the additions
+                                 (<= 1e-5 relative; bitwise reproducible run to run in deterministic mode).
+                                 1: always one wave per tile (what cross-mode bit-identity tests pin); 2, 4: that many pixel parts on every
+                                 tile (small grids only).  Always 1 for frames without the early-out (t_min = 0), frames binned in depth
+                                 slabs and capped lists.  With several waves per tile the forward's per-tile work counters are those of the
+                                 tile's first part.                                                                                   */
     int32_t reserved[3];      /* sizeof(gs_config) == 96                                                                       */
 } gs_config;
 #define GS_DEBUG_WIDE_CURSORS 1   /* two-level binning: 64-bit list cursors although the lists fit 32-bit byte offsets (tests)    */

@@ -24,7 +24,9 @@ def _setup():
     scene["scales"] = (scene["scales"] + np.float32(0.5)).astype(np.float32)
     cams = [synthetic.scene_camera(W, view=v) for v in range(VIEWS)]
     dCs = [torch.as_tensor(synthetic.make_dC(W, H, 500 + v)).cuda() for v in range(VIEWS)]
-    r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, scene, t_min=1e-5, deterministic=True)
+    # one wave per tile: the comparisons below are BIT for bit, across runs with and without view-slot history, and how a tile is shared
+    # between waves (pixel parts, list segments: gs_config.tile_parts) follows from that history on this small grid
+    r = R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), None, scene, t_min=1e-5, deterministic=True, tile_parts=1)
     return r, cams, dCs
 
 
