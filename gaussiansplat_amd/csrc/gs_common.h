@@ -335,8 +335,12 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
                                     const uint32_t *walked = nullptr, uint32_t *zero_words = nullptr, uint32_t *host_nsplit = nullptr);
 // host_nsplit (may be null): coherent pinned host word that receives the number of split tiles of the order
 // small grids: entries per list segment of a tile that walked w entries last time (0: one segment, no snapshots)
+#ifndef GS_SEG_ALL_NUM
+#define GS_SEG_ALL_NUM 5             // first-segment share of the slot's previous walk with two segments: 5 / 8 (measured at C2, composite backward:
+#define GS_SEG_ALL_DEN 8             // 3/8 0.131, 1/2 0.125, 5/8 0.121, 11/16 0.134, 3/4 0.141 ms -- the history is the walk of the tile's FIRST pixel part, a lower bound)
+#endif
 __host__ __device__ inline uint32_t gs_seg_len_all(uint32_t w, int seg_n) {
-    const uint32_t per = (w + (uint32_t)seg_n - 1u) / (uint32_t)seg_n, sl = ((per + 63u) & ~63u) < (uint32_t)GS_SEG_ALL_MIN_LEN ? (uint32_t)GS_SEG_ALL_MIN_LEN : ((per + 63u) & ~63u);
+    const uint32_t per = seg_n == 2 ? (w * GS_SEG_ALL_NUM + GS_SEG_ALL_DEN - 1u) / GS_SEG_ALL_DEN : (w + (uint32_t)seg_n - 1u) / (uint32_t)seg_n, sl = ((per + 63u) & ~63u) < (uint32_t)GS_SEG_ALL_MIN_LEN ? (uint32_t)GS_SEG_ALL_MIN_LEN : ((per + 63u) & ~63u);
     return w > sl ? sl : 0u;
 }
 int gs_seg_units(int front);         // workgroups a backward launch with list segments puts in front of the order's
