@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--schedule", type=int, default=0, help="gs_config.schedule (0 = library default = 3; 1 = tile order; 4 = forward by the previous frame when its slot has no history)")
     ap.add_argument("--no-view-slots", action="store_true", help="do not name view slots (the forward then launches in tile order)")
     ap.add_argument("--list-cap", type=int, default=0, help="gs_config.list_cap: 0 automatic (tile lists written as far as the view slot's previous frame walked them), 1 never, 2 also on small grids")
+    ap.add_argument("--bin-path", type=int, default=0, help="gs_config.bin_path: 0 default (two-level lists; small frames -- C1 -- by the two-launch small path), 3 two-level whatever the size (A/B), 2 / 1 the radix paths")
     ap.add_argument("--debug-flags", type=int, default=0, help="gs_config.debug_flags (A/B runs: 16 = super-tiles of 8 x 8 tiles on every grid, 8 = of 16 x 16)")
     ap.add_argument("--no-cull", action="store_true", help="gs_config.alpha_cull = 0: evaluate every walked entry per pixel")
     ap.add_argument("--settle-frames", type=int, default=24, help="untimed frames per rank the timed pass's renderer runs BEFORE its W warm-up "
@@ -279,7 +280,7 @@ def main():
     def make(t_min, profile_stages, sc=None):
         return R.getRenderer("GAUSSIAN_3D", (W, H, 3), (16, 16), (gx, gy), scene if sc is None else sc, device=local, order=args.order, t_min=t_min,
                              profile_stages=profile_stages, alpha_cull=not args.no_cull, rank_mode=args.rank_mode, schedule=args.schedule,
-                             list_cap=args.list_cap, debug_flags=args.debug_flags)
+                             list_cap=args.list_cap, debug_flags=args.debug_flags, bin_path=args.bin_path)
 
     sync_mode = [args.grad_sync]                                                # the exchange `step` uses (N > 1)
 
@@ -506,7 +507,7 @@ def main():
                        "view_slots": not args.no_view_slots,
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
                        "instances": I, "coarse_instances": I1, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
-                       "list_cap": args.list_cap, "tile_parts": tile_parts, "lists_capped": ls["capped"], "listed_entries": ls["listed"], "list_segments_appended_by_waves": ls["extended_segments"],
+                       "list_cap": args.list_cap, "bin_path_of_frame": lctx.bin_path_of_frame(), "tile_parts": tile_parts, "lists_capped": ls["capped"], "listed_entries": ls["listed"], "list_segments_appended_by_waves": ls["extended_segments"],
                        "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "counters_of": "the last view rendered",
                        "seed": seed},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

@@ -29,7 +29,7 @@ SYMBOLS = ("gs_default_config", "gs_abi_version", "gs_create", "gs_destroy", "gs
            "gs_comm_init", "gs_allreduce_grads", "gs_comm_destroy", "gs_color_grads_pack", "gs_sh_grads_from_views", "gs_grads_alloc", "gs_grads_read", "gs_num_gaussians", "gs_num_instances", "gs_get_array",
            "gs_get_stage_times", "gs_get_stage_stats", "gs_get_work_counters", "gs_get_work_counters_ex", "gs_debug_time_composite",
            "gs_debug_tile_clock", "gs_debug_clock_mhz", "gs_rank_probe_result", "gs_num_rounds", "gs_set_view_slot", "gs_num_coarse_instances",
-           "gs_get_list_stats", "gs_get_tile_parts", "gs_debug_set_window", "gs_debug_tile_clock_rows")
+           "gs_get_list_stats", "gs_get_tile_parts", "gs_get_bin_path", "gs_debug_set_window", "gs_debug_tile_clock_rows")
 
 GS_ABI_VERSION = 3          # include/gsplat.h; load() refuses a library that reports another version
 GS_DEBUG_WIDE_CURSORS = 1
@@ -124,6 +124,7 @@ def load():
     L.gs_num_coarse_instances.argtypes = [vp]; L.gs_num_coarse_instances.restype = C.c_int64
     L.gs_get_list_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gs_get_tile_parts.argtypes = [vp]
+    L.gs_get_bin_path.argtypes = [vp]
     L.gs_debug_set_window.argtypes = [vp, C.c_int32, C.c_int32]
     L.gs_debug_tile_clock_rows.argtypes = [vp]
     if L.gs_abi_version() != GS_ABI_VERSION:
@@ -409,6 +410,13 @@ class Context:
     def tile_parts_of_frame(self) -> int:
         """waves per tile (1, 2, 4) of the last frame's composite launches (gs_config.tile_parts)"""
         rc = self.L.gs_get_tile_parts(self.h)
+        if rc < 0:
+            self._chk(rc)
+        return int(rc)
+
+    def bin_path_of_frame(self) -> int:
+        """the path that built the last frame's lists: 0 two-level, 1 / 2 radix, 3 small-frame path (gs_config.bin_path)"""
+        rc = self.L.gs_get_bin_path(self.h)
         if rc < 0:
             self._chk(rc)
         return int(rc)

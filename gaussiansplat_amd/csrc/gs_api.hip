@@ -52,7 +52,7 @@ int gs_create(gs_ctx **out, int device, const gs_config *cfg) {
     if (!(c0.t_min >= 0.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: t_min must be >= 0");
     if (c0.schedule != 1 && c0.schedule != 3 && c0.schedule != 4) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad schedule (0, 1, 3 or 4)");
     if (c0.slab_mode < 0 || c0.slab_mode > 1) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad slab_mode");
-    if (c0.bin_path < 0 || c0.bin_path > 2) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad bin_path");
+    if (c0.bin_path < 0 || c0.bin_path > 3) return fail(nullptr, GS_ERR_INVALID, "gs_create: bad bin_path");
     if (!(c0.slab_max_ratio >= 0.0f && c0.slab_max_ratio <= 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_max_ratio must be in [0, 1]");
     for (int i = 0; i < 3; ++i)
         if (!(c0.slab_fractions[i] >= 0.0f && c0.slab_fractions[i] < 1.0f)) return fail(nullptr, GS_ERR_INVALID, "gs_create: slab_fractions must be in [0, 1)");
@@ -285,7 +285,7 @@ int gs_preprocess(gs_ctx *c) {
     c->range_valid = false;
     // the key range is folded only when this frame's depth sort can take the bucket path: while the classic sort runs (the 64-frame
     // fallback, N beyond the bucket path's limit) nothing would reset the accumulators and the atomics would be wasted
-    if (c->dsort_can_bucket() && c->order() != GS_ORDER_INDEX && c->n > 0) {
+    if (c->dsort_can_bucket() && c->order() != GS_ORDER_INDEX && c->n > 0 && !c->small_bin_possible()) {
         if (!c->key_range.p) {
             HIPCHK(c, c->key_range.ensure(sizeof(uint32_t) * gs_depth_range_words()));
             HIPCHK(c, gs_depth_range_reset(c->key_range.as<uint32_t>(), c->stream));

@@ -269,6 +269,66 @@ int settle_totals(gs_ctx *c, bool *redo, bool may_relist) {
     return GS_OK;
 }
 
+// The depth order of the frame (CUDA.sortperm, forward.jl:103) -> c->perm.  Also called by gs_get_array for a frame binned by the small
+// path, which needs no global order.
+int depth_order(gs_ctx *c, uint32_t **perm_out) {
+    const size_t n1 = c->n ? (size_t)c->n : 1;
+    StageTimer t(c, GS_STAGE_DEPTH_SORT);
+    HIPCHK(c, c->pairs_a.ensure(sizeof(uint64_t) * n1));
+    HIPCHK(c, c->pairs_b.ensure(sizeof(uint64_t) * n1));
+    HIPCHK(c, c->perm.ensure(sizeof(uint32_t) * n1));
+    HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n)));
+    HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 4 * 256));
+    int in_b = 0;
+    uint32_t *perm = c->perm.as<uint32_t>();            // the last pass writes the permutation itself (low word of the pairs)
+    // Two steps (256 key-range buckets, then one workgroup per bucket in LDS: 4 launches) when this frame's preprocess left the
+    // key range, the mean bucket is well inside a workgroup's capacity, and no oversize bucket was reported lately; else the
+    // classic four LSD passes (12 launches).  Same permutation either way.
+    const bool buckets = c->range_valid && c->dsort_can_bucket();
+    c->dsort_buckets_used = buckets;
+    if (c->range_valid && !buckets)                     // folded but not consumed (cannot happen with one predicate; kept so that a stale union never survives)
+        HIPCHK(c, gs_depth_range_reset(c->key_range.as<uint32_t>() + (size_t)c->range_parity * gs_depth_range_parity_words(), c->stream, 1));
+    if (buckets) {
+        uint32_t *range = c->key_range.as<uint32_t>() + (size_t)c->range_parity * gs_depth_range_parity_words();
+        uint32_t *other = c->key_range.as<uint32_t>() + (size_t)(c->range_parity ^ 1) * gs_depth_range_parity_words();
+        c->dsort_stat_parity = c->range_parity;
+        *c->dsort_stat() = 0u;                          // (no kernel of an earlier frame writes this parity's word any more: two frames back)
+        HIPCHK(c, gs_depth_sort_buckets(c->depth_key.as<uint32_t>(), c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, c->table.as<uint32_t>(),
+                                        c->digit_total.as<uint32_t>(), perm, range, other, c->dsort_stat(), c->stream, c->cfg.rank_mode != 0));
+    } else {
+        // (depth | id) pairs are formed by the first pass from the 32-bit keys; the last pass writes only the ids
+        HIPCHK(c, gs_radix_sort_u64(c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, 32, 64, c->table.as<uint32_t>(),
+                                    c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0, perm, c->depth_key.as<uint32_t>()));
+    }
+    *perm_out = perm;
+    return GS_OK;
+}
+
+// Small frames (gs_bin_small.hip): the whole of gs_bin in one launch, one workgroup per tile.  The ids buffer holds every (gaussian, tile)
+// pair the path admits, so nothing is speculative; the totals travel to the host as on the two-level path.
+static int bin_small(gs_ctx *c) {
+    const size_t n = (size_t)c->n, nt = (size_t)c->gx * c->gy;
+    c->n_rounds = 1; c->slab_lo[0] = 0; c->slab_lo[1] = c->n;
+    c->frame_capped = false; c->have_l2 = false; c->cap_src = nullptr; c->spec_lists = false;
+    HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * n * nt));
+    GsBinSmallArgs a{};
+    a.depth_key = c->order() != GS_ORDER_INDEX ? c->depth_key.as<uint32_t>() : nullptr; a.rect = c->rect.as<uint2>();
+    a.n = (int)c->n; a.gx = c->gx; a.gy = c->gy; a.ntiles = (int)nt;
+    a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.totals = c->bin_totals();
+    a.host_totals = c->pinned + 8 + 32; a.host_walked = c->pinned + 8; a.walked_src = c->counters.as<uint32_t>();
+    const bool same_grid = c->counters_grid == (((int64_t)c->gx << 32) | (int64_t)c->gy) && c->last_walked;
+    if (!same_grid) c->prev_counters_valid = false;
+    a.tile_walked = c->prev_counters_valid ? c->last_walked : nullptr; a.n_tile_walked = (int)nt;
+    {
+        StageTimer t(c, GS_STAGE_TILE_SORT);
+        HIPCHK(c, gs_bin_small(a, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
+    c->pending_totals = true;
+    c->did_bin = true; c->did_fwd = c->did_bwd = false;
+    return GS_OK;
+}
+
 extern "C" int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_pre) return fail(c, GS_ERR_INVALID, "gs_bin: gs_preprocess first");
@@ -279,34 +339,11 @@ extern "C" int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     const size_t n = (size_t)c->n, n1 = n ? n : 1;
     const int64_t ntiles = (int64_t)c->gx * c->gy;
     uint32_t *perm = nullptr;
-    if (c->order() != GS_ORDER_INDEX) {
-        StageTimer t(c, GS_STAGE_DEPTH_SORT);
-        HIPCHK(c, c->pairs_a.ensure(sizeof(uint64_t) * n1));
-        HIPCHK(c, c->pairs_b.ensure(sizeof(uint64_t) * n1));
-        HIPCHK(c, c->perm.ensure(sizeof(uint32_t) * n1));
-        HIPCHK(c, c->table.ensure(sizeof(uint32_t) * gs_sort_table_entries(c->n)));
-        HIPCHK(c, c->digit_total.ensure(sizeof(uint32_t) * 4 * 256));
-        int in_b = 0;
-        perm = c->perm.as<uint32_t>();                  // the last pass writes the permutation itself (low word of the pairs)
-        // Two steps (256 key-range buckets, then one workgroup per bucket in LDS: 4 launches) when this frame's preprocess left the
-        // key range, the mean bucket is well inside a workgroup's capacity, and no oversize bucket was reported lately; else the
-        // classic four LSD passes (12 launches).  Same permutation either way.
-        const bool buckets = c->range_valid && c->dsort_can_bucket();
-        c->dsort_buckets_used = buckets;
-        if (c->range_valid && !buckets)                 // folded but not consumed (cannot happen with one predicate; kept so that a stale union never survives)
-            HIPCHK(c, gs_depth_range_reset(c->key_range.as<uint32_t>() + (size_t)c->range_parity * gs_depth_range_parity_words(), c->stream, 1));
-        if (buckets) {
-            uint32_t *range = c->key_range.as<uint32_t>() + (size_t)c->range_parity * gs_depth_range_parity_words();
-            uint32_t *other = c->key_range.as<uint32_t>() + (size_t)(c->range_parity ^ 1) * gs_depth_range_parity_words();
-            c->dsort_stat_parity = c->range_parity;
-            *c->dsort_stat() = 0u;                      // (no kernel of an earlier frame writes this parity's word any more: two frames back)
-            HIPCHK(c, gs_depth_sort_buckets(c->depth_key.as<uint32_t>(), c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, c->table.as<uint32_t>(),
-                                            c->digit_total.as<uint32_t>(), perm, range, other, c->dsort_stat(), c->stream, c->cfg.rank_mode != 0));
-        } else {
-            // (depth | id) pairs are formed by the first pass from the 32-bit keys; the last pass writes only the ids
-            HIPCHK(c, gs_radix_sort_u64(c->pairs_a.as<uint64_t>(), c->pairs_b.as<uint64_t>(), c->n, 32, 64, c->table.as<uint32_t>(),
-                                        c->digit_total.as<uint32_t>(), &in_b, c->stream, c->cfg.rank_mode != 0, perm, c->depth_key.as<uint32_t>()));
-        }
+    const bool small = c->small_bin_possible();
+    c->small_bin = small;
+    c->perm_pending = small && c->order() != GS_ORDER_INDEX;               // the small path sorts nothing globally: renderer.sortIdxs on demand (gs_get_array)
+    if (c->order() != GS_ORDER_INDEX && !small) {
+        if (int rc = depth_order(c, &perm)) return rc;
     }
     c->perm_ptr = perm; c->perm_all = perm;
     int tile_bits = 1;
@@ -315,18 +352,19 @@ extern "C" int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     while ((1LL << gid_bits) < c->n) ++gid_bits;
     const int passes = (tile_bits + 7) / 8;
     const int lo_bits = passes <= 1 ? tile_bits : (tile_bits + 1) / 2, hi_bits = tile_bits - lo_bits;
-    const int bin_path = c->cfg.bin_path;
+    const int bin_path = c->cfg.bin_path == 3 ? 0 : c->cfg.bin_path;
     const bool fast = bin_path != 1 && passes <= 2 && hi_bits + gid_bits <= 32 && gs_tile_ranges_supported(c->gx, c->gy);
     // two-level path (gs_bin3.hip): lists per super-tile of 8 x 8 tiles first; its bitmap must fit in LDS
     c->sbs = gs_bin3_sb_shift(c->gx, c->gy, (c->cfg.debug_flags & GS_DEBUG_SUPER16) ? 4 : (c->cfg.debug_flags & GS_DEBUG_SUPER8) ? 3 : 0);
     const int sb = 1 << c->sbs;
     c->sgx = (c->gx + sb - 1) / sb; c->sgy = (c->gy + sb - 1) / sb;
-    c->two_level = fast && bin_path == 0 && gs_bin3_supported(c->sgx * c->sgy);
+    c->two_level = small || (fast && bin_path == 0 && gs_bin3_supported(c->sgx * c->sgy));
     c->tile_bits = tile_bits; c->gid_bits = gid_bits; c->lo_bits = lo_bits; c->hi_bits = hi_bits; c->fast_bin = fast;
     HIPCHK(c, c->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)(ntiles ? ntiles : 1)));
     HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
     // the slab plan needs the previous frame's walked share, which the read-back below delivers: the plan of THIS frame uses
     // the share known so far (one frame of lag; only speed depends on it)
+    if (small) return bin_small(c);
     const int R = plan_rounds(c);
     const int64_t n0 = c->slab_lo[1];                                       // list positions of round 0
     HIPCHK(c, c->block_sums.ensure(sizeof(uint32_t) * 3 * (n / 2048 + 2)));

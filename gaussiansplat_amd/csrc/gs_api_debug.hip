@@ -58,6 +58,11 @@ int gs_get_array(gs_ctx *c, int which, void *dst, int64_t bytes) {
         case GS_ARR_TILE_RECT: src = c->rect.p; need = sizeof(uint16_t) * 4 * n; break;
         case GS_ARR_SORT_IDXS: {
             if ((size_t)bytes != sizeof(uint32_t) * n) return fail(c, GS_ERR_INVALID, "gs_get_array: size mismatch");
+            if (c->perm_pending) {                                  // a frame binned by the small path (gs_bin_small.hip) sorted nothing globally
+                uint32_t *perm = nullptr;
+                if (int rc = depth_order(c, &perm)) return rc;
+                c->perm_ptr = c->perm_all = perm; c->perm_pending = false;
+            }
             if (c->perm_ptr) { src = c->perm_ptr; need = sizeof(uint32_t) * n; break; }
             uint32_t *o = static_cast<uint32_t *>(dst);
             for (size_t g = 0; g < n; ++g) o[g] = (uint32_t)g;
@@ -316,6 +321,12 @@ int gs_get_tile_parts(gs_ctx *c) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_fwd) return fail(c, GS_ERR_INVALID, "gs_get_tile_parts: gs_forward first");
     return c->frame_parts;
+}
+
+int gs_get_bin_path(gs_ctx *c) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->did_bin) return fail(c, GS_ERR_INVALID, "gs_get_bin_path: gs_bin first");
+    return c->small_bin ? 3 : c->two_level ? 0 : c->fast_bin ? 2 : 1;
 }
 
 int gs_get_work_counters_ex(gs_ctx *c, int64_t out[4]) {

@@ -232,6 +232,24 @@ hipError_t gs_bin3_build_lists(const GsBin3Args &a, hipStream_t s);
 hipError_t gs_bin3_write_lists(const GsBin3Args &a, hipStream_t s);      // the write pass alone (counts and ranges of the frame still valid)
 hipError_t gs_launch_super_done(const uint8_t *done, int gx, int gy, int sgx, int sgy, int sbs, uint8_t *sdone, hipStream_t s);
 
+// small frames (gs_bin_small.hip): the whole of gs_bin in one launch, one workgroup per tile
+#define GS_BIN_SMALL_MAX_N 16384
+#define GS_BIN_SMALL_MAX_TILES 1024
+#define GS_BIN_SMALL_MAX_PAIRS (4ll << 20)      // gaussians x tiles: every tile tests every gaussian, and the ids buffer is sized for all of them
+struct GsBinSmallArgs {
+    const uint32_t *depth_key; // [n] keys of the depth order; null: index order (nothing is sorted)
+    const uint2 *rect;         // [n] tile rectangles by gaussian id (x0 | x1 << 16, y0 | y1 << 16; 1-based inclusive; x0 == 0: none)
+    int n, gx, gy, ntiles;
+    uint32_t *ranges;          // out [2 x ntiles] [start, end) of every tile's list
+    uint32_t *ids;             // out the lists (at most n x ntiles entries)
+    uint32_t *totals;          // device, 3 words as GsBin3L1.totals: {0, listed, listed}
+    uint32_t *host_totals, *host_walked;   // coherent pinned host memory, as GsBin3L1
+    const uint32_t *walked_src, *tile_walked;
+    int n_tile_walked;
+};
+bool gs_bin_small_supported(int64_t n, int gx, int gy);
+hipError_t gs_bin_small(const GsBinSmallArgs &a, hipStream_t s);
+
 #define GS_TILE_CLOCK_WORDS 15
 #define GS_MAX_ROUNDS 4   // binning rounds (depth slabs) of one frame
 #define GS_G2D_STRIDE 16   // floats (or fixed-point words) per gaussian row of the composite backward's sums: ten used, padded to ONE

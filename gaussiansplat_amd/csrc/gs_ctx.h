@@ -154,6 +154,15 @@ struct gs_ctx {
     bool dsort_can_bucket() const {
         return cfg.depth_sort != 1 && (cfg.depth_sort == 2 || (n <= gs_depth_buckets_max_n() && frame_id > dsort_classic_until));
     }
+    // ---- small frames (gs_bin_small.hip): the whole of gs_bin in one launch.  Same predicate in gs_preprocess (which then folds no key
+    // range: nothing is sorted globally) and in gs_bin.  bin_path 0 only (3 = the two-level path whatever the size; tests, A/B)
+    bool small_bin = false;                  // the frame being built was binned by the small path
+    bool perm_pending = false;               // ... and its depth order (renderer.sortIdxs) has not been asked for yet
+    bool small_bin_possible() const {
+        if (cfg.bin_path != 0 || cfg.depth_sort != 0 || cfg.list_cap == 2 || cfg.slab_fractions[0] > 0.0f) return false;
+        if (cfg.debug_flags & (GS_DEBUG_WIDE_CURSORS | GS_DEBUG_SUPER8 | GS_DEBUG_SUPER16 | GS_DEBUG_TINY_CAPS)) return false;
+        return gs_bin_small_supported(n, gx, gy);
+    }
     float *bound_image = nullptr, *bound_trans = nullptr;   // gs_bind_outputs: caller-owned device buffers the forward writes directly
     float *img() { return bound_image ? bound_image : image.as<float>(); }
     float *tr() { return bound_trans ? bound_trans : trans.as<float>(); }
@@ -254,6 +263,7 @@ inline int order_index(const gs_ctx *c) { return c->view_slot >= 0 ? c->view_slo
 // gs_api_bin.hip
 int settle_totals(gs_ctx *c, bool *redo, bool may_relist);
 int bin_round(gs_ctx *c, int r);
+int depth_order(gs_ctx *c, uint32_t **perm_out);
 // gs_api_comm.hip
 void comm_release(gs_ctx *c);                // destroys the ctx's RCCL communicator, if any
 // gs_api_composite.hip

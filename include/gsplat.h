@@ -88,8 +88,11 @@ typedef struct {
     int32_t profile_stages;   /* 1: record hipEvents around every stage (gs_get_stage_times; costs ~3 % of a C3 frame);
                                  2 + s: around stage s (gs_stage) only; 0: none */
     int32_t bin_path;         /* tile lists (same lists on every path, bit for bit): 0 (default) two-level binning -- lists per
-                                 super-tile of 8 x 8 tiles from an LDS bitmap, tile lists as filtered copies; 2: radix sort of
-                                 instances generated in-pass (32-bit words); 1: explicit 64-bit tile|id instances + two radix passes */
+                                 super-tile of 8 x 8 tiles from an LDS bitmap, tile lists as filtered copies -- and, for SMALL frames
+                                 (up to 16 384 gaussians, 1024 tiles, 4 M gaussian x tile pairs: BASELINE C1), the whole of gs_bin in two
+                                 launches: depth order + tile ranges inside one workgroup's LDS, lists by one workgroup per tile;
+                                 3: two-level whatever the size (tests, A/B); 2: radix sort of instances generated in-pass (32-bit
+                                 words); 1: explicit 64-bit tile|id instances + two radix passes */
     int32_t rank_mode;        /* radix-sort stable ranks: 1 (default) = wave64 ballots (portable); 0 = one LDS atomic-add-return per
                                  key -- its pre-values come back in ascending lane order on gfx950, which is an observed, not a
                                  documented property: gs_create CHECKS it on the device with a probe kernel and falls back to 1 if
@@ -384,6 +387,11 @@ int gs_get_list_stats(gs_ctx *ctx, int64_t out[3]);
 /* Waves per tile (1, 2 or 4) of the last frame's composite launches (gs_config.tile_parts); negative: error.  Call after gs_forward.
  * No counterpart in the reference (one thread block per tile, splat.jl:224-231). */
 int gs_get_tile_parts(gs_ctx *ctx);
+
+/* The path that built the last frame's tile lists (gs_config.bin_path says what was asked for): 0 two-level binning, 1 / 2 the radix
+ * paths, 3 the small-frame path (gs_bin_small.hip: depth order and tile ranges in one workgroup, the lists by one workgroup per tile;
+ * taken by bin_path 0 for up to 16 384 gaussians x 1024 tiles).  Same lists on every path.  Negative: error.  Call after gs_bin. */
+int gs_get_bin_path(gs_ctx *ctx);
 
 /* out = {walked_fwd, walked_bwd, evaluated_fwd, evaluated_bwd}: `evaluated` counts the walked entries that
  * survived the alpha_cull no-op test and were evaluated per pixel (== walked when alpha_cull == 0). */

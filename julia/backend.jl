@@ -249,6 +249,8 @@ end
 
 # waves per tile (1, 2, 4) of the last frame's composite launches (GsConfig.tile_parts)
 hip_tileParts(r::HipRenderer) = ccall((:gs_get_tile_parts, libgs), Cint, (Ptr{Cvoid},), r.ctx)
+# the path that built the last frame's tile lists: 0 two-level, 1 / 2 radix, 3 the small-frame path (GsConfig.bin_path)
+hip_binPath(r::HipRenderer) = ccall((:gs_get_bin_path, libgs), Cint, (Ptr{Cvoid},), r.ctx)
 
 # renderer scratch arrays (gs_array ids of include/gsplat.h; e.g. 11 = sortIdxs, 12 = tile ranges, 13 = sorted ids) into a host array
 function hip_getArray!(r::HipRenderer, which::Integer, dst::Array)

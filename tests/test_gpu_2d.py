@@ -21,7 +21,7 @@ def _ctx(sc, W, H, **kw):
 
 
 @pytest.mark.parametrize("n,W,H,seed,shi", CASES)
-@pytest.mark.parametrize("bin_path", [0, 1, 2])
+@pytest.mark.parametrize("bin_path", [0, 1, 2, 3])
 def test_preprocess_and_lists_bit_exact(oracle, n, W, H, seed, shi, bin_path):
     from gaussiansplat_amd import backend as B
     O = oracle

@@ -18,7 +18,7 @@ from common import hip_context, scene_and_cameras
 pytestmark = pytest.mark.gpu
 
 
-def _check_lists(O, B, sc, cam, T, P, ocam, W, H, deg, order, bin_path=0, **kw):
+def _check_lists(O, B, sc, cam, T, P, ocam, W, H, deg, order, bin_path=3, **kw):      # 3: two-level whatever the size (0 hands small frames to gs_bin_small.hip)
     gx, gy = (W + 15) // 16, (H + 15) // 16
     pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam)
     ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0, bin_path=bin_path, **kw)
@@ -119,7 +119,7 @@ def test_render_through_two_level_lists_matches_radix_lists(oracle):
     sc = dict(sc); sc["scales"] = (sc["scales"] + np.float32(1.5)).astype(np.float32)
     dC = synthetic.make_dC(W, H, 3)
     out = []
-    for bp in (0, 2):
+    for bp in (3, 2):
         ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, bin_path=bp, deterministic=True)
         ctx.preprocess(); ctx.bin()
         img, tr = ctx.forward_host()
@@ -142,7 +142,7 @@ def test_speculative_lists_survive_growth_and_shrinkage(oracle):
     gx, gy = (W + 15) // 16, (H + 15) // 16
     sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, 123)
     dC = synthetic.make_dC(W, H, 9)
-    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, deterministic=True)
+    ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, deterministic=True, bin_path=3)
     base = sc["scales"].copy()
     counts = []
     for shift in (0.0, 1.8, -0.5, 0.1, 0.12):

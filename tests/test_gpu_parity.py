@@ -35,7 +35,7 @@ def _oracle_rects(O, bbs, gx, gy):
 
 
 @pytest.mark.parametrize("n,W,H,deg,seed", CASES)
-@pytest.mark.parametrize("order,bin_path,rank_mode", [(0, 0, 0), (1, 0, 0), (2, 0, 0), (1, 1, 0), (0, 1, 0), (1, 0, 1), (1, 1, 1), (1, 2, 0), (0, 2, 0), (1, 2, 1)])
+@pytest.mark.parametrize("order,bin_path,rank_mode", [(0, 0, 0), (1, 0, 0), (2, 0, 0), (1, 1, 0), (0, 1, 0), (1, 0, 1), (1, 1, 1), (1, 2, 0), (0, 2, 0), (1, 2, 1), (1, 3, 0), (0, 3, 0), (2, 3, 1)])
 def test_preprocess_and_binning_bit_exact(oracle, n, W, H, deg, seed, order, bin_path, rank_mode):
     from gaussiansplat_amd import backend as B
     O = oracle
