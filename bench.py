@@ -302,6 +302,7 @@ def main():
         return {k: (v[0], v[1]) for k, v in tot.items()}
 
     settled = {"steps": 0}
+    host_enqueue = {"ms_per_step": None}
 
     def timed(r, steps, warmup, k0=0, settle_frames=0):
         if settle_frames > 0:                                                # untimed: the fresh renderer (and the chip) reach their steady state
@@ -323,6 +324,7 @@ def main():
         t0 = time.perf_counter()
         for k in range(steps):
             step(r, k0 + warmup + k)
+        host_enqueue["ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3   # the host's share: when it approaches ms_per_step the frame is bound by the caller, not the GPU
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -376,6 +378,7 @@ def main():
     # Pass B: THE timed region -- W warmup steps, then exactly K steps between barriers + synchronize.
     r = make(args.t_min, 2 + STAGES.index(dom))
     dt = timed(r, args.steps, args.warmup, settle_frames=args.settle_frames)
+    host_ms = host_enqueue["ms_per_step"]
     dom_sum, dom_cnt = stage_stats(r)[dom]
     dom_ms = dom_sum / dom_cnt if dom_cnt else 0.0
     lctx = r._bench_hv.last_ctx                              # the ctx of the last view rendered
@@ -507,7 +510,7 @@ def main():
                        "view_slots": not args.no_view_slots,
                        "order": ["index", "depth_desc", "depth_asc"][args.order], "t_min": args.t_min, "tile": 16,
                        "instances": I, "coarse_instances": I1, "walked_fwd": wf, "walked_bwd": wb, "alpha_cull": not args.no_cull,
-                       "list_cap": args.list_cap, "bin_path_of_frame": lctx.bin_path_of_frame(), "tile_parts": tile_parts, "lists_capped": ls["capped"], "listed_entries": ls["listed"], "list_segments_appended_by_waves": ls["extended_segments"],
+                       "list_cap": args.list_cap, "bin_path_of_frame": lctx.bin_path_of_frame(), "host_enqueue_ms_per_step": round(host_ms, 4), "tile_parts": tile_parts, "lists_capped": ls["capped"], "listed_entries": ls["listed"], "list_segments_appended_by_waves": ls["extended_segments"],
                        "evaluated_fwd": wc["evaluated_fwd"], "evaluated_bwd": wc["evaluated_bwd"], "counters_of": "the last view rendered",
                        "seed": seed},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

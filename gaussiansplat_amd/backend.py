@@ -238,6 +238,16 @@ class Context:
                                        a[2].ctypes.data_as(fp), a[3].ctypes.data_as(fp), int(W), int(H)))
         self.W, self.H = int(W), int(H)
 
+    def camera_record(self, T, P, fx, fy, near, far, eye, lookAt, W, H):
+        """The arguments of gs_set_camera converted once (ctypes arrays): set_camera_record(rec) then costs one foreign call."""
+        f16, f3 = C.c_float * 16, C.c_float * 3
+        a = [np.ascontiguousarray(v, np.float32).reshape(-1) for v in (T, P, eye, lookAt)]
+        return (f16(*a[0]), f16(*a[1]), float(fx), float(fy), float(near), float(far), f3(*a[2]), f3(*a[3]), int(W), int(H))
+
+    def set_camera_record(self, rec):
+        self._chk(self.L.gs_set_camera(self.h, *rec))
+        self.W, self.H = rec[8], rec[9]
+
     def set_view_slot(self, slot: int):
         """gs_set_view_slot: name the view about to be rendered (e.g. the camera's id); -1 = none."""
         self._chk(self.L.gs_set_view_slot(self.h, int(slot)))

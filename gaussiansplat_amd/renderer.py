@@ -144,8 +144,7 @@ class GaussianRenderer3D:               # renderer.jl:205-219
 
     def _begin(self):
         """Bind the ctx to torch's current stream (handle 0 = the legacy default stream = GS_STREAM_LEGACY)."""
-        import torch
-        h = torch.cuda.current_stream(self.imageData.device).cuda_stream or 1
+        h = _current_stream_handle(self.imageData.device) or 1
         if h != self._stream_handle:
             self.ctx.set_stream(h)
             self._stream_handle = h
@@ -157,8 +156,20 @@ class GaussianRenderer3D:               # renderer.jl:205-219
         cam = camera or self.camera or default_camera()
         self.camera = cam
         H, W = self.transmittance.shape
-        self.ctx.set_camera(compute_transform(cam), compute_projection(cam, W, H), float(np.float32(cam.fx)), float(np.float32(cam.fy)),
-                            float(np.float32(cam.near)), float(np.float32(cam.far)), cam.eye, cam.lookAt, W, H)
+        # A small frame is bound by its caller (C1: ten thousand gaussians take the GPU 70 us, tools/host_rate.py): the view's matrices
+        # (computeTransform / computeProjection, camera.jl:53-111: 60 us of numpy) are kept with the camera object and rebuilt when
+        # one of its fields, or the image size, has changed
+        snap = (np.asarray(cam.eye, np.float32).tobytes(), np.asarray(cam.lookAt, np.float32).tobytes(), np.asarray(cam.up, np.float32).tobytes(),
+                cam.fx, cam.fy, cam.near, cam.far, W, H)
+        ent = getattr(cam, "_gs_view", None)
+        if ent is None or ent[0] != snap:
+            ent = (snap, self.ctx.camera_record(compute_transform(cam), compute_projection(cam, W, H), float(np.float32(cam.fx)), float(np.float32(cam.fy)),
+                                                float(np.float32(cam.near)), float(np.float32(cam.far)), cam.eye, cam.lookAt, W, H))
+            try:
+                cam._gs_view = ent
+            except AttributeError:                  # (a camera type without room for it: rebuilt every time)
+                pass
+        self.ctx.set_camera_record(ent[1])
         # the camera's id (camera.jl:10-22; `id` of cameras.json) names the view slot: a training loop cycles over a fixed
         # camera set and the library launches the forward's tiles heaviest-first by what the same view measured last time
         slot = getattr(cam, "id", None)
@@ -310,6 +321,16 @@ def preprocess(renderer, camera: Camera | None = None):
     renderer._begin()
     renderer.ctx.preprocess()
     return _LazyTps(renderer) if isinstance(renderer, GaussianRenderer3D) else None
+
+
+def _current_stream_handle(device) -> int:
+    """torch's current stream on `device` as a raw handle (0: the legacy default stream).  The private fast path costs 0.3 us, the
+    public one (a Stream object per call) 2.5 us -- four times per frame."""
+    import torch
+    try:
+        return int(torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device()))
+    except Exception:
+        return int(torch.cuda.current_stream(device).cuda_stream)
 
 
 class _LazyTps:
