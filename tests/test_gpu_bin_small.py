@@ -22,7 +22,7 @@ def _lists(B, ctx):
     return (ctx.get_array(B.ARR_SORT_IDXS), ctx.get_array(B.ARR_TILE_RANGES), ctx.get_array(B.ARR_SORTED_IDS), ctx.get_array(B.ARR_SORTED_KEYS))
 
 
-def _check(O, B, sc, cam, T, P, ocam, W, H, deg, order, frames=2, expect_small=True, **kw):
+def _check(O, B, sc, cam, T, P, ocam, W, H, deg, order, frames=2, expect_path=3, **kw):
     gx, gy = (W + 15) // 16, (H + 15) // 16
     pre = O.preprocess(sc["means"], sc["scales"], sc["quats"], sc["opacities"], sc["shs"], deg, ocam)
     ranges, ids, okeys = O.bin_lists(pre["bbs"], pre["tps"], order, 16, gx, gy)
@@ -30,7 +30,7 @@ def _check(O, B, sc, cam, T, P, ocam, W, H, deg, order, frames=2, expect_small=T
     ctx = hip_context(sc, cam, T, P, W, H, deg, order=order, t_min=0.0, **kw)
     for frame in range(frames):
         ctx.preprocess(); ctx.bin()
-        assert ctx.bin_path_of_frame() == (3 if expect_small else 0), frame
+        assert ctx.bin_path_of_frame() == expect_path, frame
         assert ctx.num_instances == len(ids)
         got = _lists(B, ctx)
         assert np.array_equal(got[0], perm), frame
@@ -60,13 +60,13 @@ def test_lists_match_the_oracle(oracle, n, W, H, grow, order):
         assert ni > 0.3 * n * ((W + 15) // 16) * ((H + 15) // 16)
 
 
-def test_beyond_the_limits_the_general_path_runs(oracle):
+def test_beyond_the_limits_other_paths_run(oracle):
     from gaussiansplat_amd import backend as B
     for n, W, H in [(16_385, 256, 256), (2000, 528, 512), (8192, 512, 272)]:     # one gaussian too many; 1056 tiles; 8192 x 544 pairs > 4 M
         sc, cam, T, P, ocam = scene_and_cameras(n, W, H, 0, 11)
-        _check(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, frames=1, expect_small=False)
+        _check(oracle, B, sc, cam, T, P, ocam, W, H, 0, 1, frames=1, expect_path=4)                      # the mid-size path (gs_bin_mid.hip)
     sc, cam, T, P, ocam = scene_and_cameras(3000, 256, 256, 0, 12)
-    _check(oracle, B, sc, cam, T, P, ocam, 256, 256, 0, 1, frames=1, expect_small=False, bin_path=3)     # asked for
+    _check(oracle, B, sc, cam, T, P, ocam, 256, 256, 0, 1, frames=1, expect_path=0, bin_path=3)          # asked for: two-level
 
 
 def test_without_tiles_duplicates_and_non_finite_depths(oracle):
