@@ -9,47 +9,57 @@
 //     rectangles (four +-1 per gaussian; its 2-D prefix sum is the hit count per tile), the number of hits of all tiles before tile t
 //     is sum over (y, x) of D[y][x] x #{tiles t' < t right of and below (y, x)} -- a closed-form weight per entry, a few thousand
 //     entries, added up by every tile's workgroup for itself.
-// bin_mid_l1_kernel (one thread per gaussian): the four difference atomics, and the gaussian's id + rectangle clipped to the super-tile
-//     into the candidate list of every super-tile (8 x 8 tiles) it touches -- slots handed out per workgroup through LDS, one global
-//     atomic per (workgroup, super-tile); the order inside a list does not matter.
+// bin_mid_l1_kernel (up to 32 workgroups of 1024): the four difference updates per gaussian, accumulated in LDS; and the gaussian's id +
+//     rectangle clipped to the super-tile into the candidate list of every super-tile (8 x 8 tiles) it touches -- slots handed out per
+//     workgroup through LDS, one global atomic per (workgroup, super-tile); the order inside a list does not matter.
 // bin_mid_tiles_kernel (one workgroup of four waves per tile): tests the candidates of its super-tile, gathers the depth keys of the
-//     hits, ranks them in LDS -- up to 512 by counting, up to 4096 by a bitonic network on the 64-bit (key, id) pairs -- and writes its
+//     hits, ranks them in LDS -- up to 64 by counting, up to 4096 by a bitonic network on the 64-bit (key, id) pairs -- and writes its
 //     range and ids (compactHits, compact.jl:3-21); the last tile's workgroup stores the frame's totals into pinned host memory.
 // Pairs are distinct, so the lists are the stable (key, id) order of the radix paths, bit for bit (tests/test_gpu_bin_mid.py).
 // What does not fit -- a super-tile with more candidates than its region holds, a tile with more than 4096 hits, lists beyond the ids
 // buffer -- is reported to the host with the totals: the tile's range stays empty, the host bins the frame again with the general path
 // and keeps to it for 64 frames (gs_api_bin.hip: settle_totals).
 #include "gs_common.h"
+#include <algorithm>
 
 #define BM_NT 256
 #define BM_NW (BM_NT / GS_WAVE)
-#define BM_COUNT_MAX (2 * BM_NT)                                                  // hits ranked by counting (two per thread)
-static_assert(GS_BIN_MID_MAX_SUPER <= BM_NT, "one super-tile per thread in the level-1 kernel");
+#define BM_COUNT_MAX GS_WAVE                                                      // hits ranked by counting (one per lane of the first wave); more: bitonic network
 
-__global__ __launch_bounds__(BM_NT) void bin_mid_l1_kernel(GsBinMidArgs a) {
+// A few large workgroups: the difference array and the candidate counts are accumulated in LDS and reach global memory as one atomic per
+// (workgroup, cell) -- same-address global atomics drain at ~ 64 ns each on this chip (4 M of them took 257 us, gs_bin2.hip), so the
+// 400 k corner updates of a C2 frame must not be global ones.
+#define BM_L1_NT 1024
+#define BM_L1_MAX_WG 32
+__global__ __launch_bounds__(BM_L1_NT) void bin_mid_l1_kernel(GsBinMidArgs a) {
+    extern __shared__ int ldiff[];                                                // (gy + 1) x (gx + 1)
     __shared__ uint32_t lcnt[GS_BIN_MID_MAX_SUPER], lbase[GS_BIN_MID_MAX_SUPER], ltake[GS_BIN_MID_MAX_SUPER];
-    const int tid = threadIdx.x;
-    const int g = (int)blockIdx.x * BM_NT + tid;
-    for (int i = tid; i < a.ns; i += BM_NT) { lcnt[i] = 0u; ltake[i] = 0u; }
+    const int tid = threadIdx.x, w = a.gx + 1, cells = w * (a.gy + 1);
+    for (int i = tid; i < cells; i += BM_L1_NT) ldiff[i] = 0;
+    for (int i = tid; i < a.ns; i += BM_L1_NT) { lcnt[i] = 0u; ltake[i] = 0u; }
     __syncthreads();
-    uint2 rc = make_uint2(0u, 0u);
-    if (g < a.n) rc = a.rect[g];
-    const uint32_t x0 = rc.x & 0xFFFFu, x1 = rc.x >> 16, y0 = rc.y & 0xFFFFu, y1 = rc.y >> 16;   // 1-based inclusive; x0 == 0: no tile
-    uint32_t sx0 = 1, sx1 = 0, sy0 = 1, sy1 = 0;
-    if (x0 != 0u) {
-        const int w = a.gx + 1;
-        atomicAdd(&a.diff_cur[(y0 - 1u) * w + (x0 - 1u)], 1);
-        atomicAdd(&a.diff_cur[(y0 - 1u) * w + x1], -1);
-        atomicAdd(&a.diff_cur[y1 * w + (x0 - 1u)], -1);
-        atomicAdd(&a.diff_cur[y1 * w + x1], 1);
-        sx0 = (x0 - 1u) >> 3; sx1 = (x1 - 1u) >> 3; sy0 = (y0 - 1u) >> 3; sy1 = (y1 - 1u) >> 3;
+    const int per = (a.n + (int)gridDim.x - 1) / (int)gridDim.x, g0 = (int)blockIdx.x * per, g1 = min(a.n, g0 + per);
+    for (int g = g0 + tid; g < g1; g += BM_L1_NT) {
+        const uint2 rc = a.rect[g];
+        const uint32_t x0 = rc.x & 0xFFFFu, x1 = rc.x >> 16, y0 = rc.y & 0xFFFFu, y1 = rc.y >> 16;   // 1-based inclusive; x0 == 0: no tile
+        if (x0 == 0u) continue;
+        atomicAdd(&ldiff[(y0 - 1u) * w + (x0 - 1u)], 1);
+        atomicAdd(&ldiff[(y0 - 1u) * w + x1], -1);
+        atomicAdd(&ldiff[y1 * w + (x0 - 1u)], -1);
+        atomicAdd(&ldiff[y1 * w + x1], 1);
+        const uint32_t sx0 = (x0 - 1u) >> 3, sx1 = (x1 - 1u) >> 3, sy0 = (y0 - 1u) >> 3, sy1 = (y1 - 1u) >> 3;
         for (uint32_t sy = sy0; sy <= sy1; ++sy)
             for (uint32_t sx = sx0; sx <= sx1; ++sx) atomicAdd(&lcnt[sy * (uint32_t)a.sgx + sx], 1u);
     }
     __syncthreads();
-    for (int i = tid; i < a.ns; i += BM_NT) lbase[i] = lcnt[i] ? atomicAdd(&a.scount_cur[i], lcnt[i]) : 0u;
+    for (int i = tid; i < a.ns; i += BM_L1_NT) lbase[i] = lcnt[i] ? atomicAdd(&a.scount_cur[i], lcnt[i]) : 0u;
+    for (int i = tid; i < cells; i += BM_L1_NT) { const int d = ldiff[i]; if (d != 0) atomicAdd(&a.diff_cur[i], d); }
     __syncthreads();
-    if (x0 != 0u)
+    for (int g = g0 + tid; g < g1; g += BM_L1_NT) {
+        const uint2 rc = a.rect[g];
+        const uint32_t x0 = rc.x & 0xFFFFu, x1 = rc.x >> 16, y0 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+        if (x0 == 0u) continue;
+        const uint32_t sx0 = (x0 - 1u) >> 3, sx1 = (x1 - 1u) >> 3, sy0 = (y0 - 1u) >> 3, sy1 = (y1 - 1u) >> 3;
         for (uint32_t sy = sy0; sy <= sy1; ++sy)
             for (uint32_t sx = sx0; sx <= sx1; ++sx) {
                 const uint32_t S = sy * (uint32_t)a.sgx + sx;
@@ -60,6 +70,7 @@ __global__ __launch_bounds__(BM_NT) void bin_mid_l1_kernel(GsBinMidArgs a) {
                     a.cand[(size_t)S * a.cap_s + slot] = make_uint2((uint32_t)g, lx0 | (lx1 << 3) | (ly0 << 6) | (ly1 << 9));
                 }
             }
+    }
 }
 
 __global__ __launch_bounds__(BM_NT) void bin_mid_tiles_kernel(GsBinMidArgs a) {
@@ -81,14 +92,17 @@ __global__ __launch_bounds__(BM_NT) void bin_mid_tiles_kernel(GsBinMidArgs a) {
     bool overflow = listed > a.cap_s;
     // ---- where my list starts: hits of all tiles before mine = sum of D[y][x] x #{t' < t : y' >= y, x' >= x}
     long long acc = 0;
-    for (int i = tid; i < nd; i += BM_NT) {
-        const int d = a.diff_cur[i];
-        if (d != 0) {
-            const int y = i / (a.gx + 1), x = i - y * (a.gx + 1);
-            const long long wgt = (long long)max(0, ty - y) * max(0, a.gx - x) + (ty >= y ? max(0, tx - x) : 0);
-            acc += (long long)d * wgt;
+    for (int x = lane; x <= a.gx; x += GS_WAVE)                                   // a lane per column, a wave per row (rows below mine weigh nothing), eight rows in flight
+        for (int y0 = q; y0 <= ty; y0 += 8 * BM_NW) {
+            int d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = a.diff_cur[min(y0 + u * BM_NW, ty) * (a.gx + 1) + x];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int y = y0 + u * BM_NW;
+                if (y <= ty) acc += (long long)d[u] * ((long long)(ty - y) * max(0, a.gx - x) + max(0, tx - x));
+            }
         }
-    }
 #pragma unroll
     for (int d = GS_WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d);
     if (lane == 0) wsum[q] = acc;
@@ -99,21 +113,21 @@ __global__ __launch_bounds__(BM_NT) void bin_mid_tiles_kernel(GsBinMidArgs a) {
     const uint32_t start = (uint32_t)start64;
     // ---- my super-tile's candidates: the ones whose clipped rectangle holds my tile, in any order
     const uint2 *cand = a.cand + (size_t)S * a.cap_s;
-    for (uint32_t base = 0; base < nc; base += BM_NT) {
-        const uint32_t i = base + (uint32_t)tid;
-        bool in = false;
-        uint32_t id = 0;
-        if (i < nc) {
-            const uint2 c = cand[i];
-            id = c.x;
-            in = (c.y & 7u) <= lx && lx <= ((c.y >> 3) & 7u) && ((c.y >> 6) & 7u) <= ly && ly <= ((c.y >> 9) & 7u);
+    for (uint32_t base = 0; base < nc; base += 8 * BM_NT) {                       // eight loads in flight per thread (the list was written by another XCD: every load is a trip to memory)
+        uint2 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = cand[min(base + (uint32_t)(u * BM_NT + tid), nc - 1u)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = base + (uint32_t)(u * BM_NT + tid);
+            const bool in = i < nc && (c[u].y & 7u) <= lx && lx <= ((c[u].y >> 3) & 7u) && ((c[u].y >> 6) & 7u) <= ly && ly <= ((c[u].y >> 9) & 7u);
+            const unsigned long long m = __ballot(in);
+            if (m == 0ull) continue;                                              // (wave-uniform)
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&lds_h, (uint32_t)__popcll(m));
+            pos = (uint32_t)__shfl((int)pos, 0) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (in && pos < GS_BIN_MID_TILE_CAP) hits[pos] = c[u].x;
         }
-        const unsigned long long m = __ballot(in);
-        if (m == 0ull) continue;                                                  // (wave-uniform)
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&lds_h, (uint32_t)__popcll(m));
-        pos = (uint32_t)__shfl((int)pos, 0) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (in && pos < GS_BIN_MID_TILE_CAP) hits[pos] = id;
     }
     __syncthreads();
     const uint32_t h = lds_h;                                                     // (exact even when it exceeds what was kept)
@@ -126,28 +140,41 @@ __global__ __launch_bounds__(BM_NT) void bin_mid_tiles_kernel(GsBinMidArgs a) {
         __syncthreads();
         if (h <= BM_COUNT_MAX) {
             // ---- every hit counts the pairs below its own (the same LDS word for the whole wave: a broadcast)
-            const unsigned long long me0 = (uint32_t)tid < h ? hits[tid] : ~0ull, me1 = (uint32_t)tid + BM_NT < h ? hits[tid + BM_NT] : ~0ull;
-            uint32_t b0 = 0, b1 = 0;
-            const uint32_t lim = (uint32_t)(q * GS_WAVE) < h ? h : 0u;            // (a wave without hits skips the loop)
-            for (uint32_t j = 0; j < lim; ++j) { const unsigned long long p = hits[j]; b0 += p < me0 ? 1u : 0u; b1 += p < me1 ? 1u : 0u; }
-            if ((uint32_t)tid < h) a.ids[start + b0] = (uint32_t)me0;
-            if ((uint32_t)tid + BM_NT < h) a.ids[start + b1] = (uint32_t)me1;
+            if ((uint32_t)tid < h) {
+                const unsigned long long me = hits[tid];
+                uint32_t below = 0;
+                for (uint32_t j = 0; j < h; ++j) below += hits[j] < me ? 1u : 0u;
+                a.ids[start + below] = (uint32_t)me;
+            }
         } else {
             // ---- bitonic network over the next power of two (padding sorts behind everything)
             uint32_t p2 = 1;
             while (p2 < h) p2 <<= 1;
             for (uint32_t i = h + tid; i < p2; i += BM_NT) hits[i] = ~0ull;
             __syncthreads();
-            for (uint32_t k = 2; k <= p2; k <<= 1)
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = tid; i < (p2 >> 1); i += BM_NT) {
-                        const uint32_t lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), hi = lo | j;      // the i-th pair of this step
-                        const unsigned long long x = hits[lo], y = hits[hi];
-                        const bool up = (lo & k) == 0u;
-                        if ((x > y) == up) { hits[lo] = y; hits[hi] = x; }
-                    }
+            // A compare-exchange with distance j <= 64 stays inside a block of 128 pairs = the 64 comparators of ONE wave: those steps need
+            // no workgroup barrier (a wave's LDS operations are performed in order), only the steps with j >= 128 do -- 6 barriers instead of
+            // 45 for 512 pairs, and the network is bound by exactly that latency.
+            volatile unsigned long long *vh = hits;
+            auto step = [&](uint32_t i, uint32_t j, uint32_t k) {
+                const uint32_t lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), hi = lo | j;          // the i-th pair of this step
+                const unsigned long long x = vh[lo], y = vh[hi];
+                if ((x > y) == ((lo & k) == 0u)) { vh[lo] = y; vh[hi] = x; }
+            };
+            const uint32_t nblk = p2 >> 7;                                         // (h > 64: at least one block)
+            for (uint32_t blk = q; blk < nblk; blk += BM_NW)
+                for (uint32_t k = 2; k <= 128u; k <<= 1)
+                    for (uint32_t j = k >> 1; j > 0; j >>= 1) { step(blk * GS_WAVE + lane, j, k); __builtin_amdgcn_wave_barrier(); }
+            __syncthreads();
+            for (uint32_t k = 256; k <= p2; k <<= 1) {
+                for (uint32_t j = k >> 1; j >= 128u; j >>= 1) {
+                    for (uint32_t i = tid; i < (p2 >> 1); i += BM_NT) step(i, j, k);
                     __syncthreads();
                 }
+                for (uint32_t blk = q; blk < nblk; blk += BM_NW)
+                    for (uint32_t j = 64; j > 0; j >>= 1) { step(blk * GS_WAVE + lane, j, k); __builtin_amdgcn_wave_barrier(); }
+                __syncthreads();
+            }
             for (uint32_t i = tid; i < h; i += BM_NT) a.ids[start + i] = (uint32_t)hits[i];
         }
     }
@@ -178,7 +205,15 @@ bool gs_bin_mid_supported(int64_t n, int gx, int gy) {
 }
 
 hipError_t gs_bin_mid(const GsBinMidArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(bin_mid_l1_kernel, dim3((unsigned)((a.n + BM_NT - 1) / BM_NT)), dim3(BM_NT), 0, s, a);
+    const size_t lds = sizeof(int) * (size_t)(a.gx + 1) * (a.gy + 1);
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bin_mid_l1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    const int wgs = std::max(1, std::min(BM_L1_MAX_WG, (a.n + 4095) / 4096));
+    hipLaunchKernelGGL(bin_mid_l1_kernel, dim3((unsigned)wgs), dim3(BM_L1_NT), lds, s, a);
     hipLaunchKernelGGL(bin_mid_tiles_kernel, dim3((unsigned)a.ntiles), dim3(BM_NT), 0, s, a);
     return hipGetLastError();
 }
