@@ -34,7 +34,6 @@ SOURCES = {
     "gs_bin2.hip": [],
     "gs_bin3.hip": [],
     "gs_bin_small.hip": [],
-    "gs_bin_mid.hip": [],
     # no SLP vectoriser: a v_pk_*_f32 issues at the cost of two plain operations on gfx950, and forming the pairs costs moves
     # (C3 1.328 -> 1.294 ms, C5 4.38 -> 4.26, same box, profiles/r04q_ab_no_slp.log; round 2's kernels had measured the opposite)
     "gs_composite.hip": ["-fno-slp-vectorize"],

@@ -117,7 +117,7 @@ int gs_destroy(gs_ctx *c) {
                       &c->invcov, &c->loss_maps, &c->loss_acc, &c->loss_in[0], &c->loss_in[1], &c->loss_dc, &c->view_cams, &c->tile_dead, &c->key_range, &c->tile_walked, &c->tile_walked_b, &c->tile_work_b};
     for (DevBuf *b : bufs) b->release();
     for (auto &v : c->slots) { v.order[0].release(); v.order[1].release(); v.walkbuf[0].release(); v.walkbuf[1].release(); }
-    for (DevBuf *b : {&c->tile_nopen, &c->smax, &c->tile_ext, &c->zero_tiles, &c->mid_diff, &c->mid_scount, &c->mid_cand}) b->release();
+    for (DevBuf *b : {&c->tile_nopen, &c->smax, &c->tile_ext, &c->zero_tiles}) b->release();
     for (auto &b : c->model) b.release();
     for (auto &b : c->dbg) b.release();
     for (int s = 0; s < GS_STAGE_COUNT; ++s)
@@ -285,7 +285,7 @@ int gs_preprocess(gs_ctx *c) {
     c->range_valid = false;
     // the key range is folded only when this frame's depth sort can take the bucket path: while the classic sort runs (the 64-frame
     // fallback, N beyond the bucket path's limit) nothing would reset the accumulators and the atomics would be wasted
-    if (c->dsort_can_bucket() && c->order() != GS_ORDER_INDEX && c->n > 0 && !c->small_bin_possible() && !c->mid_bin_possible()) {
+    if (c->dsort_can_bucket() && c->order() != GS_ORDER_INDEX && c->n > 0 && !c->small_bin_possible()) {
         if (!c->key_range.p) {
             HIPCHK(c, c->key_range.ensure(sizeof(uint32_t) * gs_depth_range_words()));
             HIPCHK(c, gs_depth_range_reset(c->key_range.as<uint32_t>(), c->stream));

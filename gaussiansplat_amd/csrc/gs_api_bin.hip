@@ -253,18 +253,6 @@ int settle_totals(gs_ctx *c, bool *redo, bool may_relist) {
     c->round_gen[0] = c->n_rounds > 1 ? (int64_t)fine_slab : c->n_inst;
     c->round_ids_off[0] = 0;
     c->coarse_listed = (int64_t)coarse;
-    if (c->mid_bin && *c->mid_overflow() != 0u) {
-        // a mid-size frame that did not fit (a super-tile's candidates, a tile's hits, the ids buffer): the tiles concerned have empty ranges.
-        // Bin it again with the general path, which sizes its buffers from the totals, and keep to that path for a while.
-        c->mid_bin = false;
-        c->mid_off_until = c->frame_id + 64;
-        if (c->mid_boost < 64) c->mid_boost *= 2;
-        if (!may_relist) { c->did_bin = false; return GS_OK; }
-        if (int rc = bin_frame(c, false)) return rc;
-        if (int rc = settle_totals(c, nullptr, true)) return rc;            // (the two-level path's own speculation settles inside)
-        if (redo) *redo = true;
-        return GS_OK;
-    }
     if (!c->spec_lists) return GS_OK;
     c->spec_lists = false;
     if ((size_t)coarse <= c->spec_cap_coarse && (size_t)fine_slab <= c->spec_cap_fine) return GS_OK;
@@ -345,55 +333,6 @@ static int bin_small(gs_ctx *c) {
     return GS_OK;
 }
 
-// Mid-size frames (gs_bin_mid.hip): two launches, nothing sorted globally.  Speculative like the two-level path -- the candidate regions and
-// the ids buffer are the ones at hand -- and what does not fit is found by settle_totals, which bins the frame again with the general path.
-static int bin_mid(gs_ctx *c) {
-    const size_t n = (size_t)c->n, nt = (size_t)c->gx * c->gy;
-    const int sgx = (c->gx + 7) / 8, sgy = (c->gy + 7) / 8, ns = sgx * sgy;
-    const size_t nd = (size_t)(c->gx + 1) * (c->gy + 1);
-    c->n_rounds = 1; c->slab_lo[0] = 0; c->slab_lo[1] = c->n;
-    c->frame_capped = false; c->have_l2 = false; c->cap_src = nullptr; c->spec_lists = false;
-    if (c->range_valid)                                                     // (gs_preprocess judged otherwise and folded the key range: nobody will consume it)
-        HIPCHK(c, gs_depth_range_reset(c->key_range.as<uint32_t>() + (size_t)c->range_parity * gs_depth_range_parity_words(), c->stream, 1));
-    const int64_t grid = ((int64_t)c->gx << 32) | (int64_t)c->gy;
-    if (c->mid_grid != grid) {                                              // both parities zero for this grid (afterwards each frame clears the next one's)
-        HIPCHK(c, c->mid_diff.ensure(sizeof(int) * 2 * nd));
-        HIPCHK(c, c->mid_scount.ensure(sizeof(uint32_t) * 2 * GS_BIN_MID_MAX_SUPER));
-        HIPCHK(c, hipMemsetAsync(c->mid_diff.p, 0, sizeof(int) * 2 * nd, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->mid_scount.p, 0, sizeof(uint32_t) * 2 * GS_BIN_MID_MAX_SUPER, c->stream));
-        c->mid_grid = grid; c->mid_parity = 0;
-    }
-    // a super-tile's region: eight times an even share of the model (a gaussian of BASELINE's scenes touches 1.4 super-tiles), doubled whenever one overflowed
-    const size_t want = ((size_t)8 * n / (size_t)ns + 1024) * (size_t)c->mid_boost;
-    if (c->mid_cand.cap < sizeof(uint2) * want * (size_t)ns) HIPCHK(c, c->mid_cand.ensure(sizeof(uint2) * want * (size_t)ns));
-    c->mid_cap_s = (uint32_t)std::min<size_t>(c->mid_cand.cap / sizeof(uint2) / (size_t)ns, 0x7FFFFFFFu);
-    if (c->ids.cap < sizeof(uint32_t) * 64 * n) HIPCHK(c, c->ids.ensure(sizeof(uint32_t) * 64 * n));          // a first guess (256 B per gaussian); a frame beyond it is binned again
-    GsBinMidArgs a{};
-    a.depth_key = c->order() != GS_ORDER_INDEX ? c->depth_key.as<uint32_t>() : nullptr; a.rect = c->rect.as<uint2>();
-    a.n = (int)c->n; a.gx = c->gx; a.gy = c->gy; a.ntiles = (int)nt; a.sgx = sgx; a.ns = ns;
-    a.diff_cur = c->mid_diff.as<int>() + (size_t)c->mid_parity * nd; a.diff_next = c->mid_diff.as<int>() + (size_t)(c->mid_parity ^ 1) * nd;
-    a.scount_cur = c->mid_scount.as<uint32_t>() + (size_t)c->mid_parity * GS_BIN_MID_MAX_SUPER;
-    a.scount_next = c->mid_scount.as<uint32_t>() + (size_t)(c->mid_parity ^ 1) * GS_BIN_MID_MAX_SUPER;
-    c->mid_parity ^= 1;
-    a.cand = c->mid_cand.as<uint2>(); a.cap_s = c->mid_cap_s;
-    a.ranges = c->ranges.as<uint32_t>(); a.ids = c->ids.as<uint32_t>(); a.cap_fine = (uint32_t)std::min<size_t>(c->ids.cap / sizeof(uint32_t), 0xFFFFFFFEu);
-    a.totals = c->bin_totals();
-    a.host_totals = c->pinned + 8 + 32; a.host_walked = c->pinned + 8; a.walked_src = c->counters.as<uint32_t>();
-    const bool same_grid = c->counters_grid == grid && c->last_walked;
-    if (!same_grid) c->prev_counters_valid = false;
-    a.tile_walked = c->prev_counters_valid ? c->last_walked : nullptr; a.n_tile_walked = (int)nt;
-    a.host_overflow = c->mid_overflow();
-    *c->mid_overflow() = 0u;                                                // (the previous frame's kernels are behind its ev_count: settled)
-    {
-        StageTimer t(c, GS_STAGE_TILE_SORT);
-        HIPCHK(c, gs_bin_mid(a, c->stream));
-    }
-    HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
-    c->pending_totals = true;
-    c->did_bin = true; c->did_fwd = c->did_bwd = false;
-    return GS_OK;
-}
-
 static int bin_frame(gs_ctx *c, bool special_paths);
 
 extern "C" int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
@@ -406,16 +345,15 @@ extern "C" int gs_bin(gs_ctx *c, int32_t gx, int32_t gy) {
     return bin_frame(c, true);
 }
 
-// special_paths: small and mid-size frames may take their own paths (false: a mid-size frame that did not fit is binned again)
+// special_paths: small frames may take their own path (gs_bin_small.hip)
 static int bin_frame(gs_ctx *c, bool special_paths) {
     const size_t n = (size_t)c->n;
     const int64_t ntiles = (int64_t)c->gx * c->gy;
     uint32_t *perm = nullptr;
     const bool small = special_paths && c->small_bin_possible();
-    const bool mid = special_paths && !small && c->mid_bin_possible();
-    c->small_bin = small; c->mid_bin = mid;
-    c->perm_pending = (small || mid) && c->order() != GS_ORDER_INDEX;      // these paths sort nothing globally: renderer.sortIdxs on demand (gs_get_array)
-    if (c->order() != GS_ORDER_INDEX && !small && !mid) {
+    c->small_bin = small;
+    c->perm_pending = small && c->order() != GS_ORDER_INDEX;               // the small path sorts nothing globally: renderer.sortIdxs on demand (gs_get_array)
+    if (c->order() != GS_ORDER_INDEX && !small) {
         if (int rc = depth_order(c, &perm)) return rc;
     }
     c->perm_ptr = perm; c->perm_all = perm;
@@ -431,14 +369,13 @@ static int bin_frame(gs_ctx *c, bool special_paths) {
     c->sbs = gs_bin3_sb_shift(c->gx, c->gy, (c->cfg.debug_flags & GS_DEBUG_SUPER16) ? 4 : (c->cfg.debug_flags & GS_DEBUG_SUPER8) ? 3 : 0);
     const int sb = 1 << c->sbs;
     c->sgx = (c->gx + sb - 1) / sb; c->sgy = (c->gy + sb - 1) / sb;
-    c->two_level = small || mid || (fast && bin_path == 0 && gs_bin3_supported(c->sgx * c->sgy));
+    c->two_level = small || (fast && bin_path == 0 && gs_bin3_supported(c->sgx * c->sgy));
     c->tile_bits = tile_bits; c->gid_bits = gid_bits; c->lo_bits = lo_bits; c->hi_bits = hi_bits; c->fast_bin = fast;
     HIPCHK(c, c->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)(ntiles ? ntiles : 1)));
     HIPCHK(c, c->counters.ensure(GS_COUNTER_BYTES));
     // the slab plan needs the previous frame's walked share, which the read-back below delivers: the plan of THIS frame uses
     // the share known so far (one frame of lag; only speed depends on it)
     if (small) return bin_small(c);
-    if (mid) return bin_mid(c);
     const int R = plan_rounds(c);
     const int64_t n0 = c->slab_lo[1];                                       // list positions of round 0
     HIPCHK(c, c->block_sums.ensure(sizeof(uint32_t) * 3 * (n / 2048 + 2)));

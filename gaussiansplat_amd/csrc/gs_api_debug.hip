@@ -326,7 +326,7 @@ int gs_get_tile_parts(gs_ctx *c) {
 int gs_get_bin_path(gs_ctx *c) {
     if (!c) return GS_ERR_INVALID;
     if (!c->did_bin) return fail(c, GS_ERR_INVALID, "gs_get_bin_path: gs_bin first");
-    return c->small_bin ? 3 : c->mid_bin ? 4 : c->two_level ? 0 : c->fast_bin ? 2 : 1;
+    return c->small_bin ? 3 : c->two_level ? 0 : c->fast_bin ? 2 : 1;
 }
 
 int gs_get_work_counters_ex(gs_ctx *c, int64_t out[4]) {

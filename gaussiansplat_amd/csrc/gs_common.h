@@ -250,29 +250,6 @@ struct GsBinSmallArgs {
 bool gs_bin_small_supported(int64_t n, int gx, int gy);
 hipError_t gs_bin_small(const GsBinSmallArgs &a, hipStream_t s);
 
-// mid-size frames (gs_bin_mid.hip): gs_bin in two launches -- unordered candidate lists per super-tile of 8 x 8 tiles, then one workgroup per tile
-#define GS_BIN_MID_MAX_N 262144
-#define GS_BIN_MID_MAX_TILES 8192
-#define GS_BIN_MID_MAX_SUPER 256
-#define GS_BIN_MID_TILE_CAP 4096                // hits a tile's workgroup ranks in LDS; a tile beyond it sends the frame to the general path
-struct GsBinMidArgs {
-    const uint32_t *depth_key; // [n] keys of the depth order; null: index order
-    const uint2 *rect;         // [n] tile rectangles by gaussian id (x0 | x1 << 16, y0 | y1 << 16; 1-based inclusive; x0 == 0: none)
-    int n, gx, gy, ntiles, sgx, ns;
-    int *diff_cur, *diff_next;             // (gy + 1) x (gx + 1) ints: this frame's difference array (zero on entry) / the next frame's (cleared here)
-    uint32_t *scount_cur, *scount_next;    // [ns] candidates per super-tile, likewise
-    uint2 *cand; uint32_t cap_s;           // ns regions of cap_s entries: {gaussian id, rectangle clipped to the super-tile}
-    uint32_t *ranges, *ids;                // out
-    uint32_t cap_fine;                     // entries ids can hold
-    uint32_t *totals;                      // device, 3 words as GsBin3L1.totals: {0, listed, listed}
-    uint32_t *host_totals, *host_walked;   // coherent pinned host memory, as GsBin3L1
-    const uint32_t *walked_src, *tile_walked;
-    int n_tile_walked;
-    uint32_t *host_overflow;               // pinned: set when something did not fit (the frame is binned again by the general path)
-};
-bool gs_bin_mid_supported(int64_t n, int gx, int gy);
-hipError_t gs_bin_mid(const GsBinMidArgs &a, hipStream_t s);
-
 #define GS_TILE_CLOCK_WORDS 15
 #define GS_MAX_ROUNDS 4   // binning rounds (depth slabs) of one frame
 #define GS_G2D_STRIDE 16   // floats (or fixed-point words) per gaussian row of the composite backward's sums: ten used, padded to ONE

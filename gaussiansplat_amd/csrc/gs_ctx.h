@@ -163,24 +163,6 @@ struct gs_ctx {
         if (cfg.debug_flags & (GS_DEBUG_WIDE_CURSORS | GS_DEBUG_SUPER8 | GS_DEBUG_SUPER16 | GS_DEBUG_TINY_CAPS)) return false;
         return gs_bin_small_supported(n, gx, gy);
     }
-    // ---- mid-size frames (gs_bin_mid.hip): gs_bin in two launches; what does not fit is binned again by the general path (settle_totals)
-    bool mid_bin = false;                    // the frame being built was binned by the mid path
-    int64_t mid_off_until = 0;               // frame id up to which the general path is used (a frame did not fit)
-    DevBuf mid_diff, mid_scount, mid_cand;   // two parities of the difference array / of the candidate counts; the candidate regions
-    int mid_parity = 0;
-    int64_t mid_grid = -1;                   // the grid (gx << 32 | gy) both parities are zero for
-    uint32_t mid_cap_s = 0;                  // entries per super-tile region
-    int mid_boost = 1;                       // doubles whenever a region overflowed
-    uint32_t *mid_overflow() { return pinned + 105; }
-    bool mid_bin_possible() const {
-        if (cfg.bin_path != 0 || cfg.depth_sort != 0 || cfg.list_cap == 2 || cfg.slab_fractions[0] > 0.0f) return false;
-        if (cfg.debug_flags & (GS_DEBUG_WIDE_CURSORS | GS_DEBUG_SUPER8 | GS_DEBUG_SUPER16 | GS_DEBUG_TINY_CAPS)) return false;
-        if (small_bin_possible() || frame_id <= mid_off_until || !gs_bin_mid_supported(n, gx, gy)) return false;
-        const int64_t nt = (int64_t)gx * gy;
-        if (cfg.t_min > 0.0f && nt > wave_slots && walked_ratio >= 0.0 && walked_ratio < 0.15 && cfg.list_cap == 0) return false;   // capped lists pay there (two-level path)
-        if (cfg.t_min > 0.0f && cfg.slab_mode == 1 && walked_ratio >= 0.0 && walked_ratio < (cfg.slab_max_ratio > 0.0f ? cfg.slab_max_ratio : 0.03f)) return false;   // depth slabs
-        return true;
-    }
     float *bound_image = nullptr, *bound_trans = nullptr;   // gs_bind_outputs: caller-owned device buffers the forward writes directly
     float *img() { return bound_image ? bound_image : image.as<float>(); }
     float *tr() { return bound_trans ? bound_trans : trans.as<float>(); }
