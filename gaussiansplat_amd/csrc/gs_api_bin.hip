@@ -323,10 +323,16 @@ static int bin_small(gs_ctx *c) {
     const bool same_grid = c->counters_grid == (((int64_t)c->gx << 32) | (int64_t)c->gy) && c->last_walked;
     if (!same_grid) c->prev_counters_valid = false;
     a.tile_walked = c->prev_counters_valid ? c->last_walked : nullptr; a.n_tile_walked = (int)nt;
+    {   // the rows the composite backward accumulates into (64 B per gaussian; nothing touches them between here and that kernel)
+        const size_t bytes = (c->cfg.deterministic ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n;
+        HIPCHK(c, c->g2d.ensure(bytes));
+        a.zero = c->g2d.as<uint4>(); a.zero_words16 = bytes / sizeof(uint4);
+    }
     {
         StageTimer t(c, GS_STAGE_TILE_SORT);
         HIPCHK(c, gs_bin_small(a, c->stream));
     }
+    c->g2d_clean = true;
     HIPCHK(c, hipEventRecord(c->ev_count, c->stream));
     c->pending_totals = true;
     c->did_bin = true; c->did_fwd = c->did_bwd = false;
@@ -351,7 +357,7 @@ static int bin_frame(gs_ctx *c, bool special_paths) {
     const int64_t ntiles = (int64_t)c->gx * c->gy;
     uint32_t *perm = nullptr;
     const bool small = special_paths && c->small_bin_possible();
-    c->small_bin = small;
+    c->small_bin = small; c->g2d_clean = false;
     c->perm_pending = small && c->order() != GS_ORDER_INDEX;               // the small path sorts nothing globally: renderer.sortIdxs on demand (gs_get_array)
     if (c->order() != GS_ORDER_INDEX && !small) {
         if (int rc = depth_order(c, &perm)) return rc;

@@ -277,7 +277,9 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         // from the forward's tiles, and the two event hand-shakes per frame delay the depth sort's launches)
         // (a fill with streaming stores, which would spare the caches 64 B per gaussian, was measured: the atomics of the composite backward then
         // find their rows in memory instead of the cache, C3 + 1 %; profiles/r04t_ab_nontemporal.log)
-        HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
+        // (a small frame's gs_bin kernel has cleared them already: gs_bin_small.hip)
+        if (!c->g2d_clean) HIPCHK(c, hipMemsetAsync(c->g2d.p, 0, (det ? sizeof(long long) : sizeof(float)) * GS_G2D_STRIDE * n1, c->stream));
+        c->g2d_clean = false;
         // launch order: the one the frame's forward used, or (no history) what the order kernel made of that forward
         if (lpt_schedule(c)) { a.tile_order = c->frame_order; a.order_len = c->frame_order ? lpt_order_entries(c) : 0; }
         a.split_ok = a.tile_order && lpt_front(c) > 0 && c->frame_parts == 1 && !c->frame_capped && c->n_rounds == 1;

@@ -171,6 +171,7 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
         ++a.nseg;
     }
     a.g2d = c->cfg.deterministic ? nullptr : c->g2d.as<float>(); a.g2d_fixed = c->cfg.deterministic ? c->g2d.as<long long>() : nullptr;
+    c->g2d_clean = false;
     if (c->frame_capped && c->n_rounds == 1) {
         a.tile_ext = c->tile_ext.as<uint2>(); a.cranges = c->cranges.as<uint32_t>(); a.cids = c->cids.as<uint32_t>(); a.clr = c->clr.as<uint16_t>();
         a.ids_w = c->ids.as<uint32_t>(); a.sgx = c->sgx; a.sbs = c->sbs; a.ext_count = c->ext_count();

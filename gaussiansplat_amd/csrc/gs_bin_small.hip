@@ -40,6 +40,7 @@ __global__ __launch_bounds__(BL_NT) void bin_small_kernel(GsBinSmallArgs a) {
     uint2 rc[BL_MAX_ROUNDS];
 #pragma unroll
     for (int r = 0; r < BL_MAX_ROUNDS; ++r) rc[r] = a.rect[min(first + min(r, rounds - 1) * GS_WAVE + lane, a.n - 1)];
+    for (size_t i = (size_t)t * BL_NT + tid; i < a.zero_words16; i += (size_t)a.ntiles * BL_NT) a.zero[i] = make_uint4(0u, 0u, 0u, 0u);
     unsigned long long hit[BL_MAX_ROUNDS];
     uint32_t mine = 0, before = 0;
 #pragma unroll

@@ -246,6 +246,7 @@ struct GsBinSmallArgs {
     uint32_t *host_totals, *host_walked;   // coherent pinned host memory, as GsBin3L1
     const uint32_t *walked_src, *tile_walked;
     int n_tile_walked;
+    uint4 *zero; size_t zero_words16;      // the gradient rows of the frame's backward (GsCompositeArgs.g2d): cleared here, which spares the frame a fill launch
 };
 bool gs_bin_small_supported(int64_t n, int gx, int gy);
 hipError_t gs_bin_small(const GsBinSmallArgs &a, hipStream_t s);

@@ -158,6 +158,7 @@ struct gs_ctx {
     // range: nothing is sorted globally) and in gs_bin.  bin_path 0 only (3 = the two-level path whatever the size; tests, A/B)
     bool small_bin = false;                  // the frame being built was binned by the small path
     bool perm_pending = false;               // ... and its depth order (renderer.sortIdxs) has not been asked for yet
+    bool g2d_clean = false;                  // ... and its kernel cleared the gradient rows: the frame's first composite backward needs no fill
     bool small_bin_possible() const {
         if (cfg.bin_path != 0 || cfg.depth_sort != 0 || cfg.list_cap == 2 || cfg.slab_fractions[0] > 0.0f) return false;
         if (cfg.debug_flags & (GS_DEBUG_WIDE_CURSORS | GS_DEBUG_SUPER8 | GS_DEBUG_SUPER16 | GS_DEBUG_TINY_CAPS)) return false;
