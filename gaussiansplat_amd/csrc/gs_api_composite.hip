@@ -159,7 +159,10 @@ int gs_forward(gs_ctx *c, float *image, float *transmittance, int mem) {
             // runs as 2 / 4 list segments; the forward's waves leave the snapshots
             if (hist && c->cfg.tile_parts == 0 && c->cfg.t_min > 0.0f && c->n_rounds == 1 && !c->frame_capped && !lpt_schedule(c) && c->kind == 0 &&
                 2 * (int64_t)ntiles <= c->wave_slots && ntiles > 0) {
-                c->frame_seg_n = 2;                        // (four segments lost to four pixel parts at C1: a tile there walks ~ 300 entries)
+                // (C1, lists of two or three batches: four segments instead of four pixel parts lost, 0.049 against 0.034 ms; three segments x four
+                // parts ran like two, 0.0239 against 0.0243 -- a lone wave needs 0.33 us per evaluated entry and the launch lasts as long as the
+                // batch with the most of them, which no cut at a batch boundary shortens)
+                c->frame_seg_n = 2;
                 c->seg_hist = vs.walked().as<uint32_t>();
             }
             c->last_walked = wb.as<uint32_t>();
@@ -268,7 +271,7 @@ static int backward_impl(gs_ctx *c, const float *dC, int mem, const gs_grads *gr
         // two list segments, and as many pixel parts on top as still fit the wave slots (C1: 4 x 2 waves per tile; C2: 1 x 2)
         const long long nt = (long long)c->gx * c->gy;
         a.snap = c->snap.as<float>(); a.seg_hist = c->seg_hist; a.seg_n = c->frame_seg_n;
-        a.parts = 8 * nt <= c->wave_slots ? 4 : 4 * nt <= c->wave_slots ? 2 : 1;
+        a.parts = 4 * a.seg_n * nt <= c->wave_slots ? 4 : 2 * a.seg_n * nt <= c->wave_slots ? 2 : 1;
     }
     if (!params_only) {
         c->last_dC = dC_dev;

@@ -191,7 +191,7 @@ static int debug_composite_args(gs_ctx *c, int which, int variant, GsCompositeAr
     if (which == 1 && c->frame_seg_n && c->n_rounds == 1 && !c->frame_capped && !a.tile_order) {   // small grid: the backward's list segments
         const long long nt = (long long)c->gx * c->gy;
         a.snap = c->snap.as<float>(); a.seg_hist = c->seg_hist; a.seg_n = c->frame_seg_n;
-        a.parts = 8 * nt <= c->wave_slots ? 4 : 4 * nt <= c->wave_slots ? 2 : 1;
+        a.parts = 4 * a.seg_n * nt <= c->wave_slots ? 4 : 2 * a.seg_n * nt <= c->wave_slots ? 2 : 1;
     }
     if (c->dbg_win_len > 0) {                                                // gs_debug_set_window: a slice of the launch order
         if (!a.tile_order || a.parts > 1) return fail(c, GS_ERR_INVALID, "gs_debug_set_window: the frame has no launch order (or several waves per tile)");
@@ -243,10 +243,13 @@ int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
     if (by_block) variant = -variant;                                         // out holds gs_debug_tile_clock_rows() rows
     if (int rc = debug_composite_args(c, which, variant, a)) return rc;
     if (by_block) {
-        if (!a.tile_order || (a.variant / 10) % 10 == 1) return fail(c, GS_ERR_INVALID, "gs_debug_tile_clock: records by workgroup need the frame's launch order");
+        // a frame with a launch order, or a small grid whose tiles are shared between waves (pixel parts / list segments)
+        if ((!a.tile_order && a.parts <= 1 && !a.seg_hist) || (a.variant / 10) % 10 == 1)
+            return fail(c, GS_ERR_INVALID, "gs_debug_tile_clock: records by workgroup need the frame's launch order (or a small grid's tile parts)");
         a.clock_by_block = 1;
     } else { a.split_ok = 0; a.snap = nullptr; }                              // records by tile: whole tiles only
-    const size_t rows = a.clock_by_block ? (size_t)(lpt_order_entries(c) + gs_seg_units(lpt_front(c))) : ntiles;
+    const size_t rows = !a.clock_by_block ? ntiles : a.tile_order ? (size_t)(lpt_order_entries(c) + gs_seg_units(lpt_front(c))) : (size_t)gs_debug_tile_clock_rows(c);
+    if (a.clock_by_block && (size_t)gs_composite_grid_blocks(a, which) > rows) return fail(c, GS_ERR_INVALID, "gs_debug_tile_clock: launch larger than its record");
     HIPCHK(c, c->tile_clock.ensure(sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * (rows ? rows : 1)));
     HIPCHK(c, hipMemsetAsync(c->tile_clock.p, 0, sizeof(uint64_t) * GS_TILE_CLOCK_WORDS * rows, c->stream));
     a.tile_clock = c->tile_clock.as<unsigned long long>();
@@ -260,7 +263,11 @@ int gs_debug_tile_clock(gs_ctx *c, int which, int variant, uint64_t *out) {
 
 int gs_debug_tile_clock_rows(gs_ctx *c) {
     if (!c) return GS_ERR_INVALID;
-    return lpt_schedule(c) ? lpt_order_entries(c) + gs_seg_units(lpt_front(c)) : 0;
+    if (lpt_schedule(c)) return lpt_order_entries(c) + gs_seg_units(lpt_front(c));
+    // small grids: blocks of one part x the most waves a tile is given (pixel parts x list segments of the backward); 0: one wave per tile
+    const int len = ((c->gx * c->gy + 7) / 8) * 8;
+    const int units = std::max(c->frame_parts, 1) * (c->frame_seg_n ? 4 * c->frame_seg_n : 1);
+    return units > 1 ? len * units : 0;
 }
 
 int gs_debug_clock_mhz(gs_ctx *c, float *mhz) {

@@ -358,11 +358,16 @@ hipError_t gs_launch_tile_lpt_order(const uint32_t *work_or_ranges, int ranges_m
 #define GS_SEG_ALL_NUM 5             // first-segment share of the slot's previous walk with two segments: 5 / 8 (measured at C2, composite backward:
 #define GS_SEG_ALL_DEN 8             // 3/8 0.131, 1/2 0.125, 5/8 0.121, 11/16 0.134, 3/4 0.141 ms -- the history is the walk of the tile's FIRST pixel part, a lower bound)
 #endif
+#ifndef GS_SEG_ALL_SHORT
+#define GS_SEG_ALL_SHORT 1           // a walk of up to three batches (C1: 50 ... 150 entries, the evaluated ones at the front) is cut after the FIRST batch; 0: by the rule below, which leaves most of them whole (A/B)
+#endif
 __host__ __device__ inline uint32_t gs_seg_len_all(uint32_t w, int seg_n) {
+    if (GS_SEG_ALL_SHORT && w >= 80u && w <= (seg_n == 2 ? 192u : 64u * (uint32_t)seg_n + 64u)) return 64u;   // (at least sixteen entries behind the first cut)
     const uint32_t per = seg_n == 2 ? (w * GS_SEG_ALL_NUM + GS_SEG_ALL_DEN - 1u) / GS_SEG_ALL_DEN : (w + (uint32_t)seg_n - 1u) / (uint32_t)seg_n, sl = ((per + 63u) & ~63u) < (uint32_t)GS_SEG_ALL_MIN_LEN ? (uint32_t)GS_SEG_ALL_MIN_LEN : ((per + 63u) & ~63u);
     return w > sl ? sl : 0u;
 }
-int gs_seg_units(int front);         // workgroups a backward launch with list segments puts in front of the order's
+int gs_seg_units(int front);
+int gs_composite_grid_blocks(const GsCompositeArgs &a, int bwd);      // workgroups of the launch these arguments describe
 hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a, hipStream_t s);
 hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a, hipStream_t s);
 

@@ -1217,6 +1217,8 @@ static dim3 composite_grid(const GsCompositeArgs &a, int ntiles, bool bwd = fals
     return dim3((unsigned)(len * (a.parts > 1 ? a.parts : 1) + ((bwd && a.snap && a.t_min > 0.0f) ? gs_seg_units(a.front) : 0)));
 }
 
+int gs_composite_grid_blocks(const GsCompositeArgs &a, int bwd) { return (int)composite_grid(a, a.gx * a.gy, bwd != 0).x; }   // (debug clocks by workgroup: rows of the record)
+
 // variant (debug launches, gs_debug_time_composite / gs_debug_tile_clock): tens digit 1 = tile order instead of the frame's launch order
 static GsCompositeArgs apply_sched_variant(const GsCompositeArgs &a0) {
     GsCompositeArgs a = a0;
@@ -1230,7 +1232,7 @@ hipError_t gs_launch_composite_fwd(const GsCompositeArgs &a0, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
     const dim3 grid = composite_grid(a, ntiles), block(64);
     const bool early = a.t_min > 0.0f;
-    if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.tile_pos || a.tile_clock)) return hipErrorInvalidValue;
+    if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.tile_pos || (a.tile_clock && !a.clock_by_block))) return hipErrorInvalidValue;
     if (a.split_ok && (!early || a.tile_ext || a.tile_pos || a.parts > 1)) return hipErrorInvalidValue;   // split entries: frames with the early-out, full lists, one round
     if (a.snap && !a.seg_hist && (!a.split_ok || !a.seg_len || !a.snap_walked || !a.tile_order || a.front <= 0)) return hipErrorInvalidValue;
     if (a.snap && a.seg_hist && (a.tile_order || a.seg_n < 2 || a.seg_n > GS_SEG_MAX || !early || a.tile_ext || a.tile_pos)) return hipErrorInvalidValue;
@@ -1269,7 +1271,7 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
     const dim3 grid = composite_grid(a, ntiles, true), block(64);
     if (a.snap && !a.seg_hist && (!a.split_ok || !a.seg_len || !a.snap_walked || !a.tile_order || a.front <= 0)) return hipErrorInvalidValue;
     if (a.snap && a.seg_hist && (a.tile_order || a.seg_n < 2 || a.seg_n > GS_SEG_MAX || !early || a.tile_ext || a.nseg > 1)) return hipErrorInvalidValue;
-    if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.nseg > 1 || a.tile_clock)) return hipErrorInvalidValue;
+    if (a.parts > 1 && ((a.parts != 2 && a.parts != 4) || !early || a.tile_ext || a.nseg > 1 || (a.tile_clock && !a.clock_by_block))) return hipErrorInvalidValue;
     if (a.split_ok && (!early || a.tile_ext || a.nseg > 1 || a.parts > 1)) return hipErrorInvalidValue;
 #define GS_B2(E, D) do { if (a.cull) hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, true>), grid, block, 0, s, a); \
                          else hipLaunchKernelGGL((composite_bwd_kernel<E, GS_BWD_MINW, D, false>), grid, block, 0, s, a); } while (0)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""What a small frame's composite launches are made of (GPU box):   python3 tools/small_frame_clocks.py [C1]
-Per workgroup of the production launch (gs_debug_tile_clock, negative variant = one record per workgroup): when it started and ended
-relative to the launch's first start, how long it ran, and the shader cycles inside / outside its per-entry loops."""
+"""What a small frame's composite launches are made of (GPU box)   python3 tools/small_frame_clocks.py [C1|C2] [tile_parts=0]
+One record per workgroup of the production launch (tile_parts 0: a tile has 2-8 waves), or per tile with one wave per tile (tile_parts 1): when each tile's wave started and ended relative to the
+launch's first start, how long it ran, the shader cycles inside / outside its per-entry loops, and the walked / evaluated entries per tile --
+with every wave resident at once the launch lasts as long as its slowest wave."""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,8 @@ n, W, H, deg = synthetic.CONFIGS[cfg]
 seed = 1234 + ["C1", "C2", "C3", "C4", "C5"].index(cfg)
 sc, cam, T, P, ocam = scene_and_cameras(n, W, H, deg, seed)
 import torch  # noqa: E402
-ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5)
+parts = int(sys.argv[2]) if len(sys.argv) > 2 else 0                   # gs_config.tile_parts: 0 = what production does, 1 = one wave per tile
+ctx = hip_context(sc, cam, T, P, W, H, deg, t_min=1e-5, tile_parts=parts)
 dC = torch.as_tensor(synthetic.make_dC(W, H, 1)).cuda()
 g = ctx.grads_alloc()
 ctx.set_view_slot(0)
@@ -24,7 +26,7 @@ ctx.synchronize()
 mhz = ctx.clock_mhz()
 out = {"config": cfg, "tile_parts": ctx.tile_parts_of_frame(), "shader_mhz": mhz}
 for which, name in ((0, "forward"), (1, "backward")):
-    clk = ctx.tile_clock(which, -30)
+    clk = ctx.tile_clock(which, 30 if parts == 1 else -30)
     ran = clk[:, 1] > 0
     c = clk[ran]
     st, en = c[:, 0].astype(np.int64), c[:, 1].astype(np.int64)
