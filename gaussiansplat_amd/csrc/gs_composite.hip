@@ -55,6 +55,9 @@
 #ifndef GS_FWD_NO_PREFETCH
 #define GS_FWD_NO_PREFETCH 0        // 1: measurement build -- no payload rows / ids gathered ahead of the early-out decision (exposes the gather latency)
 #endif
+#ifndef GS_BWD_PAIR
+#define GS_BWD_PAIR 1               // small grids: the backward keeps two entries in flight per wave (0: A/B builds)
+#endif
 #ifndef GS_FWD_UNROLL
 #define GS_FWD_UNROLL 2             // entries interleaved in the forward's per-entry loop
 #endif
@@ -707,7 +710,10 @@ __device__ __forceinline__ void backward_entry(const Entry &e, const float fx, c
     v[6] = dX * qx; v[7] = dX * q1s; v[8] = q2s;
 }
 
-template <bool EARLY, bool DET, bool CULL, bool CLK>
+template <bool EARLY, bool DET, bool CULL, bool CLK, bool PAIR = false>
+// PAIR (small grids: a wave is alone on its SIMD and the per-entry chain -- payload read, exp2, nine LDS writes, four LDS reads, adds, atomic -- is
+// pure latency, 0.33 us per evaluated entry): two staged entries in flight, reduced through two LDS buffers (`red` holds 2 x RED_FLOATS then).
+// Same sums per entry, same values; only the order in which the atomics of neighbouring entries are issued differs.
 // snap_in != null / seg_start, seg_end: this wave differentiates list entries [seg_start, seg_end) of the tile only (a heavy tile's backward
 // runs as segments of its list, GsCompositeArgs.snap), starting from the (C, T) the forward left at seg_start (snap_in: [4][256]; null:
 // the list's start).  seg_tile: the tile's counters are the sum over its segments.
@@ -866,7 +872,25 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
             if (base < s1 && pos2 < s1) id2 = ids[pos2];
         }
         if (CLK) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - t_mark; t_mark = t; }
-        for (int k = 0; k < nk; ++k) {
+        int k = 0;
+        if (PAIR) {
+            float *wrow2 = wrow + RED_FLOATS;
+            const float4 *rr = reinterpret_cast<const float4 *>(rrow), *rr2 = reinterpret_cast<const float4 *>(rrow + RED_FLOATS);
+            for (; k + 1 < nk; k += 2) {
+                const Entry ea = load_entry(sp, syhi, k), eb = load_entry(sp, syhi, k + 1);
+                const uint32_t gida = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]), gidb = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k + 1]);
+                float va[9], vb[9];
+                bool anya = true, anyb = true;
+                backward_entry(ea, fx, fy, nbig, dCr, dCg, dCb, T, S, va, anya, live_of(k));
+                backward_entry(eb, fx, fy, nbig, dCr, dCg, dCb, T, S, vb, anyb, live_of(k + 1));
+#pragma unroll
+                for (int c = 0; c < 9; ++c) { wrow[c * RS] = va[c]; wrow2[c * RS] = vb[c]; }
+                const float4 a0 = rr[0], a1 = rr[1], a2 = rr[2], a3 = rr[3], b0 = rr2[0], b1 = rr2[1], b2 = rr2[2], b3 = rr2[3];
+                r0 = a0; r1 = a1; r2 = a2; r3 = a3; pend_gid = gida; finish();
+                r0 = b0; r1 = b1; r2 = b2; r3 = b3; pend_gid = gidb; finish();
+            }
+        }
+        for (; k < nk; ++k) {
             const Entry e = load_entry(sp, syhi, k);
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)sid[k]);
             float v[9];
@@ -910,13 +934,13 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     }
 }
 
-template <bool EARLY, int MINW, bool DET, bool CULL, bool CLK = false>
+template <bool EARLY, int MINW, bool DET, bool CULL, bool CLK = false, bool PAIR = false>
 __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs a) {
     __shared__ float4 sp[CB * 3];
     __shared__ float syhi[CB];
     __shared__ uint32_t sid[CB];
     __shared__ uint32_t sstrip[CB];
-    __shared__ __attribute__((aligned(16))) float red[RED_FLOATS];
+    __shared__ __attribute__((aligned(16))) float red[PAIR ? 2 * RED_FLOATS : RED_FLOATS];
     const int ntiles = a.gx * a.gy;
     const float nbig = vgpr_const(-GS_BIG);
     int part = 0, nparts = 1, tile;
@@ -959,7 +983,7 @@ __global__ __launch_bounds__(64, MINW) void composite_bwd_kernel(GsCompositeArgs
             }
         }
     }
-    backward_tile<EARLY, DET, CULL, CLK>(a, tile, part, nparts, sp, syhi, sid, sstrip, red, nbig, snap_in, seg_start, seg_end, seg_tile);
+    backward_tile<EARLY, DET, CULL, CLK, PAIR>(a, tile, part, nparts, sp, syhi, sid, sstrip, red, nbig, snap_in, seg_start, seg_end, seg_tile);
 }
 
 // Longest-first order for a PLAIN launch (gs_config.schedule 3 / 4).  The dispatcher hands workgroups out in blockIdx order,
@@ -1280,6 +1304,12 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
         if (!a.cull || a.g2d_fixed) return hipErrorInvalidValue;
         if (early) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_BWD_MINW, false, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((composite_bwd_kernel<false, GS_BWD_MINW, false, true, true>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+    // small grids (several waves per tile: every wave alone on its SIMD): two entries in flight per wave, registers to spare (two waves per SIMD)
+    if (GS_BWD_PAIR && early && a.cull && !a.tile_order && (a.parts > 1 || a.seg_hist)) {
+        if (a.g2d_fixed) hipLaunchKernelGGL((composite_bwd_kernel<true, 2, true, true, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((composite_bwd_kernel<true, 2, false, true, false, true>), grid, block, 0, s, a);
         return hipGetLastError();
     }
     if (early) GS_B(true); else GS_B(false);
