@@ -153,7 +153,9 @@ typedef struct {
                                      tested against ITS pixels, so pixels may differ from the one-wave result by contributions below 2^-27
                                      -- the no-op rule of alpha_cull).  Once the frame's VIEW SLOT has history, the BACKWARD of every tile
                                      runs instead as two segments of its list (x pixel parts where they still fit): the forward's waves
-                                     leave a snapshot (C, T) of their pixels at the boundary, the second segment starts from it;
+                                     leave a snapshot (C, T) of their pixels at the boundary, the second segment starts from it (a list of
+                                     two or three batches is cut after its first batch, longer ones at 5/8 of the slot's previous walk), and
+                                     a wave keeps two entries in flight (it is alone on its SIMD there: the per-entry chain is latency);
                                  (b) on larger grids the launch order (schedule 3 / 4) gives the FEW tiles whose work stands far above an
                                      even share -- a trained scene's heavy tail -- two or four waves (by strips) in the forward, and up to
                                      eight list segments in the backward (snapshots as above); a spatially uniform scene splits nothing.
