@@ -85,3 +85,40 @@ def test_bench_self_launch_command():
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--backend", "gloo"] and cmd[-7].endswith("bench.py")
+
+
+def test_view_record_is_kept_with_the_camera_and_follows_its_fields():
+    """renderer._set_view (the host side of preprocess(renderer, camera), forward.jl:35-53): a small frame is bound by its caller, so the
+    view's matrices (computeTransform / computeProjection, camera.jl:53-111) are built once per camera and again whenever one of its
+    fields -- or the image size -- changes, in place or by assignment."""
+    from gaussiansplat_amd import renderer as R
+
+    class Ctx:                                          # what _set_view needs of backend.Context
+        def __init__(self): self.built, self.set, self.slots = [], [], []
+        def camera_record(self, T, P, fx, fy, near, far, eye, lookAt, W, H):
+            rec = (np.array(T, np.float32), np.array(P, np.float32), fx, fy, near, far, np.array(eye, np.float32), np.array(lookAt, np.float32), W, H)
+            self.built.append(rec); return rec
+        def set_camera_record(self, rec): self.set.append(rec)
+        def set_view_slot(self, s): self.slots.append(s)
+
+    class Fake:                                         # the two fields of GaussianRenderer3D it touches
+        def __init__(self, W, H): self.ctx, self.camera, self.transmittance = Ctx(), None, np.ones((H, W), np.float32)
+    f = Fake(64, 48)
+    a, b = synthetic.scene_camera(64, view=0), synthetic.scene_camera(64, view=4)
+    a.id, b.id = 0, 4
+    for cam in (a, b, a, b, a):
+        R.GaussianRenderer3D._set_view(f, cam)
+    assert len(f.ctx.built) == 2 and len(f.ctx.set) == 5 and f.ctx.slots == [0, 4, 0, 4, 0]
+    assert f.ctx.set[0] is f.ctx.set[2] and f.ctx.set[1] is f.ctx.set[3]
+    assert np.array_equal(f.ctx.built[0][0], gcam.compute_transform(a)) and np.array_equal(f.ctx.built[1][1], gcam.compute_projection(b, 64, 48))
+    a.eye[0] += np.float32(0.5)                          # in place
+    R.GaussianRenderer3D._set_view(f, a)
+    assert len(f.ctx.built) == 3 and np.array_equal(f.ctx.built[2][0], gcam.compute_transform(a))
+    b.fx = b.fx * 1.25                                  # by assignment
+    R.GaussianRenderer3D._set_view(f, b)
+    assert len(f.ctx.built) == 4 and np.array_equal(f.ctx.built[3][1], gcam.compute_projection(b, 64, 48))
+    g = Fake(80, 48)                                    # another image size: the same camera object is rebuilt for it
+    R.GaussianRenderer3D._set_view(g, a)
+    assert len(g.ctx.built) == 1 and g.ctx.built[0][8:] == (80, 48)
+    R.GaussianRenderer3D._set_view(f, a)
+    assert len(f.ctx.built) == 5                        # (one record per camera: the other size pushed it out)
