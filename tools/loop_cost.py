@@ -106,9 +106,12 @@ def main():
                        check=True, capture_output=True)
         asm = open(s_path).read()
     names = re.findall(r"^(_Z20composite_(?:fwd|bwd)_kernel\S*?):", asm, re.M)
-    # the production instantiations: early-out, 5 waves, cull; forward <EARLY=1, 5, CULL=1, CLK=0, SLAB=0>, backward <EARLY=1, 5, DET=0, CULL=1, CLK=0>
-    pick = {"composite_fwd": [n for n in names if "fwd_kernelILb1ELi5ELb1ELb0ELb0EE" in n],
-            "composite_bwd": [n for n in names if "bwd_kernelILb1ELi5ELb0ELb1ELb0EE" in n]}
+    # the production instantiations: early-out, 5 waves, cull; forward <EARLY=1, 5, CULL=1, CLK=0, SLAB=0, SNAP=0>, backward <EARLY=1, 5, DET=0, CULL=1, CLK=0, PAIR=0>
+    pick = {"composite_fwd": [n for n in names if "fwd_kernelILb1ELi5ELb1ELb0ELb0ELb0EE" in n],
+            "composite_bwd": [n for n in names if "bwd_kernelILb1ELi5ELb0ELb1ELb0ELb0EE" in n]}
+    missing = [k for k, v in pick.items() if not v]
+    if missing:
+        sys.exit("loop_cost.py: production instantiation not found for %s (template parameters changed?): %s" % (missing, names))
     res = {}
     for k, cand in pick.items():
         if not cand:
@@ -124,6 +127,10 @@ def main():
         info["entries_per_loop_iteration"] = max(1, n_exp // 4)
         info["model_cycles_per_entry_all_strips"] = round(info["model_cycles"] / info["entries_per_loop_iteration"], 1)
         info["valu_per_entry_all_strips"] = round(info["valu"] / info["entries_per_loop_iteration"], 1)
+        if k == "composite_fwd" and info["entries_per_loop_iteration"] > 2:
+            # since round 4 the forward has three per-entry loops (4 / 2 / 1 pixel slots, two entries per iteration) at one nesting depth and this
+            # region spans them: the counts are of all three together, not of one entry
+            info["note"] = "spans the forward's 4-, 2- and 1-slot loops: per-entry figures are NOT those of one loop"
         res[k] = info
     sys.path.insert(0, ROOT)
     import bench
