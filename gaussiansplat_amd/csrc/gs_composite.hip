@@ -41,7 +41,8 @@
 #pragma clang fp contract(off)
 
 #ifndef GS_BWD_MINW
-#define GS_BWD_MINW 5               // __launch_bounds__ waves/SIMD of the backward: 96 VGPRs (unconstrained: 104 -> 4 waves)
+#define GS_BWD_MINW 6               // __launch_bounds__ waves/SIMD of the backward: 80 VGPRs, which every production instantiation meets without a spill since
+                                    // the live rectangle comes from the live masks on the scalar unit (LiveRectAcc: 91 -> 79 VGPRs; round 2: 96 at five waves)
 #endif
 #ifndef GS_FWD_MINW
 #define GS_FWD_MINW 5               // __launch_bounds__ waves/SIMD of the forward (89 VGPRs)
@@ -196,6 +197,28 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+// The rectangle of the live pixels of a tile whose lanes own FIXED pixels (lane -> column lane & 15, row (lane >> 4) + 4 p of slot p): from the four
+// live masks, on the scalar unit -- the same numbers as four wave-wide min / max reductions (24 cross-lane moves) at a batch boundary where pixels froze.
+// tx0 / ty0: the tile's first pixel column / row (1-based).  No live pixel: (2^20, -1, 2^20, -1), as the reductions over nothing give.
+#ifndef GS_RECT_FROM_MASKS
+#define GS_RECT_FROM_MASKS 1
+#endif
+struct LiveRectAcc {
+    uint64_t any = 0; uint32_t rows = 0;
+    __device__ __forceinline__ void slot(const int p, const uint64_t m) {   // one slot's live mask at a time (few scalar registers alive)
+        any |= m;
+        uint64_t t = m | (m >> 8); t |= t >> 4; t |= t >> 2; t |= t >> 1;     // bit 16 r = row r of the slot has a live pixel
+        t &= 0x0001000100010001ull;
+        rows |= (uint32_t)((t | (t >> 15) | (t >> 30) | (t >> 45)) & 0xFull) << (4 * p);
+    }
+    __device__ __forceinline__ void rect(const int tx0, const int ty0, int &qx0, int &qx1, int &qy0, int &qy1) const {
+        const uint32_t cols = (uint32_t)((any | (any >> 16) | (any >> 32) | (any >> 48)) & 0xFFFFull);
+        if (cols == 0u) { qx0 = 1 << 20; qx1 = -1; qy0 = 1 << 20; qy1 = -1; return; }
+        qx0 = tx0 + (int)__builtin_ctz(cols); qx1 = tx0 + 31 - (int)__builtin_clz(cols);
+        qy0 = ty0 + (int)__builtin_ctz(rows); qy1 = ty0 + 31 - (int)__builtin_clz(rows);
+    }
+};
+
 // kept-entry slot of this lane inside the wave's keep mask
 __device__ __forceinline__ int slot_of(uint64_t m) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -321,6 +344,8 @@ __device__ __forceinline__ void forward_tile(const GsCompositeArgs &a, const int
     // boundaries, so both evaluate the same entries (C3: 6.8 % fewer than with the tile's rectangle, profiles/r04e_tile_tail_C3.json).
     int qx0, qx1, qy0, qy1;
     auto live_rect = [&]() {
+        // (the backward takes this rectangle from the four live masks on the scalar unit, LiveRectAcc; here the same code costs the kernel its last
+        // scalar registers -- 106, three to seven VGPRs spilled -- so the forward keeps the four wave reductions)
         int lx0 = 1 << 20, lx1 = -1, ly0 = 1 << 20, ly1 = -1;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -768,6 +793,13 @@ __device__ __forceinline__ void backward_tile(const GsCompositeArgs &a, const in
     // the same batch boundaries, so the same entries are evaluated)
     int qx0, qx1, qy0, qy1;
     auto live_rect = [&]() {
+        if (GS_RECT_FROM_MASKS && GS_LIVE_RECT) {
+            LiveRectAcc acc;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc.slot(p, __ballot(!dead[p]));
+            acc.rect(px - (lane & 15), ty0, qx0, qx1, qy0, qy1);
+            return;
+        }
         int lx0 = 1 << 20, lx1 = -1, ly0 = 1 << 20, ly1 = -1;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -1302,8 +1334,8 @@ hipError_t gs_launch_composite_bwd(const GsCompositeArgs &a0, hipStream_t s) {
 #define GS_B(E) do { if (a.g2d_fixed) GS_B2(E, true); else GS_B2(E, false); } while (0)
     if (a.tile_clock) {                                                   // debug clocks: instantiations of their own (alpha_cull on, float atomics only)
         if (!a.cull || a.g2d_fixed) return hipErrorInvalidValue;
-        if (early) hipLaunchKernelGGL((composite_bwd_kernel<true, GS_BWD_MINW, false, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((composite_bwd_kernel<false, GS_BWD_MINW, false, true, true>), grid, block, 0, s, a);
+        if (early) hipLaunchKernelGGL((composite_bwd_kernel<true, 5, false, true, true>), grid, block, 0, s, a);        // (the clocks cost registers: five waves)
+        else hipLaunchKernelGGL((composite_bwd_kernel<false, 5, false, true, true>), grid, block, 0, s, a);
         return hipGetLastError();
     }
     // small grids (several waves per tile: every wave alone on its SIMD): two entries in flight per wave, registers to spare (two waves per SIMD)

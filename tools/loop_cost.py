@@ -106,9 +106,9 @@ def main():
                        check=True, capture_output=True)
         asm = open(s_path).read()
     names = re.findall(r"^(_Z20composite_(?:fwd|bwd)_kernel\S*?):", asm, re.M)
-    # the production instantiations: early-out, 5 waves, cull; forward <EARLY=1, 5, CULL=1, CLK=0, SLAB=0, SNAP=0>, backward <EARLY=1, 5, DET=0, CULL=1, CLK=0, PAIR=0>
+    # the production instantiations: early-out, 5 waves, cull; forward <EARLY=1, 5, CULL=1, CLK=0, SLAB=0, SNAP=0>, backward <EARLY=1, 6, DET=0, CULL=1, CLK=0, PAIR=0>
     pick = {"composite_fwd": [n for n in names if "fwd_kernelILb1ELi5ELb1ELb0ELb0ELb0EE" in n],
-            "composite_bwd": [n for n in names if "bwd_kernelILb1ELi5ELb0ELb1ELb0ELb0EE" in n]}
+            "composite_bwd": [n for n in names if "bwd_kernelILb1ELi6ELb0ELb1ELb0ELb0EE" in n]}
     missing = [k for k, v in pick.items() if not v]
     if missing:
         sys.exit("loop_cost.py: production instantiation not found for %s (template parameters changed?): %s" % (missing, names))
